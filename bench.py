@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- APG iterations/s of the scenario-tree SMPC solve path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE accelerated-proximal-gradient iteration (extrapolation, backward+forward tree sweep, prox,
+residual, dual update -- the loop body of SmpcController::algorithmApg, SmpcController.cu:1512-1522) on the
+headline workload of BASELINE.json: Barcelona-style DWN (63 states / 114 inputs / nv = 97), N = 24, 493 scenarios
+(17 x 29 tree, 10 864 nodes), fp64, synthetic data (rapidnet_amd/synth.py, seed 20260103), all inputs resident in HBM.
+For N > 1 the SAME tree is sharded by subtree below stage 2 (18 crown nodes replicated, 493 chains dealt round-robin)
+with one RCCL all-reduce of the cut parents' children sums per iteration => strong scaling.
+
+Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="barcelona493", help="named config of rapidnet_amd.synth.CONFIGS")
+    ap.add_argument("--precision", default=None, help="f64 | f32 (default: f64, f32 for wide4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(problem_name, nodes_full):
+    """The CPU oracle ("port" of the reference's sweep, 1 thread) on a bounded sample of the same workload:
+    the same network and horizon with a 2 x 29 tree (58 of the 493 scenarios, 1 279 nodes).  Per-node work is
+    uniform, so iterations/s of the full tree = sample rate x nodes_sample / nodes_full."""
+    from oracle import oracle as oracle_mod
+    from oracle.oracle import Oracle
+    from rapidnet_amd import synth
+
+    try:
+        oracle_mod.build(force=True, march="native")  # time the baseline with the host's full ISA
+    except Exception:
+        pass
+    idx, nx, nu, nd, ne, N, branching = synth.CONFIGS[problem_name]
+    sample_branching = [2, 29] if problem_name == "barcelona493" else branching
+    synth.CONFIGS["_cpu_sample"] = (idx, nx, nu, nd, ne, N, sample_branching)
+    p = synth.make_problem("_cpu_sample", step_size=1e-6)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o.initialise(dh, ah)
+    o.apg_reset()
+    th = o.apg_continue(2, [1.0, 1.0])
+    iters, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 12.0:
+        th = o.apg_continue(5, th)
+        iters += 5
+    dt = time.perf_counter() - t0
+    rate_sample = iters / dt
+    return {
+        "value": rate_sample * o.nodes / nodes_full, "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": "%d iterations in %.1f s of oracle/apg_oracle.c (gcc -O3 -march=native, 1 thread) on the same network, "
+                  "N=%d, %s tree (%d nodes); scaled by nodes %d/%d to the full workload" % (
+                      iters, dt, N, "x".join(map(str, sample_branching)), o.nodes, o.nodes, nodes_full),
+        "sample_iterations_per_s": rate_sample, "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # rendezvous, barrier and max-over-ranks only; the data path is RCCL in C
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+    from rapidnet_amd import capi, synth
+    from rapidnet_amd import partition
+
+    precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
+    problem = synth.make_problem(args.workload)
+    nodes_full = int(problem["tree"]["nodes"][0])
+    dh, ah = synth.forecast_at(problem["forecast"], 0)
+    cut_stage = -1
+    tree = problem["tree"]
+    if world > 1:
+        cut_stage = partition.default_cut_stage(problem["tree"])
+        tree, _ = partition.local_tree(problem["tree"], rank, world, cut_stage)
+    s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank)
+    if world > 1:
+        import torch
+
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        s.commInit(rank, world, uid[0])
+        s.setCutStage(cut_stage)
+    s.initialiseSmpcController(dh, ah)
+    s.apgReset()
+
+    def barrier():
+        s.synchronize()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    s.apgIterate(args.warmup, history=False)
+    barrier()
+    t0 = time.perf_counter()
+    s.apgIterate(args.steps, history=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-launch hipEvent pass on the solver's own stream (events bracket every k_backward_stage launch)
+    roofline = None
+    classes = {}
+    if args.profile_steps > 0:
+        s.profileEnable(1)
+        s.profileReset()
+        s.apgIterate(args.profile_steps, history=False)
+        ms, n = s.profileRead()
+        s.profileEnable(0)
+        bwd_bytes, dual_bytes = s.algorithmicBytes()
+        names = ("backward_sweep", "forward_sweep", "dual_update", "bookkeeping")
+        for i, nm in enumerate(names):
+            classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
+        launches_per_sweep = s.N
+        avg_s = 1e-3 * ms[0] / max(n[0], 1)
+        bytes_per_launch = bwd_bytes / launches_per_sweep
+        achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_backward_stage_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_backward_stage", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_s,
+                    "launches_per_step": launches_per_sweep,
+                    "dual_update": {"achieved": dual_bytes / (1e-3 * ms[2] / max(n[2], 1)) / 1e9 if ms[2] > 0 else 0.0,
+                                    "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": float(1e3 * ms[2] / max(n[2], 1))}}
+        roofline["dual_update"]["frac"] = roofline["dual_update"]["achieved"] / 8000.0
+
+    if rank == 0:
+        out = {
+            "metric": "apg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if precision == "f64" else "f32", "data": "synthetic",
+            "config": {"workload": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (
+                args.workload, s.nx, s.nu, s.nv, s.nd, s.N, int(problem["tree"]["K"][0]), nodes_full),
+                "operator_storage": "dense per-node blocks (reference storage model)",
+                "ms_per_controlStep_500it": 500 * 1e3 * dt / args.steps,
+                "parallelism": "1 GPU" if world == 1 else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
+            "roofline": roofline, "kernel_classes": classes,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, nodes_full)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

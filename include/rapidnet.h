@@ -1,0 +1,186 @@
+/*
+ * rapidnet.h -- C ABI of the MI355X-native APG solve path (librapidnet_hip.so).
+ *
+ * The reference (GPUEngineering/RapidNet) has no FFI layer: its seam is the C++ class surface
+ * Engine / SmpcController and raw device pointers.  This header is the boundary a
+ * maintainer binds instead: every entry point names the reference member function it replaces
+ * (file:line relative to /root/reference/src).  The C++ classes in rapidnet_amd/csrc/host/ (same names and
+ * signatures as the reference's) are a thin layer over exactly these functions.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every HOST array is `double` whatever the device precision;
+ *   - matrices are column-major, per-node vectors node-major `[node][dim]`, tree indices as in the
+ *     reference's JSON (1-based `ancestor`, root = 0; `nodesPerStage` N+1 entries, `...Cumul` N+2);
+ *   - every function returns 0 on success or a negative RN_E_* code and never calls exit();
+ *     rn_last_error() returns a message for the last failure on that context;
+ *   - one host thread per context, one HIP stream per context; contexts are independent.
+ */
+#ifndef RAPIDNET_H_
+#define RAPIDNET_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rn_ctx rn_ctx;
+
+enum { RN_F32 = 0, RN_F64 = 1 };
+
+enum {
+    RN_OK = 0,
+    RN_E_ARG = -1,      /* bad argument / dimension mismatch */
+    RN_E_HIP = -2,      /* HIP runtime error (message in rn_last_error) */
+    RN_E_STATE = -3,    /* call order violated (e.g. iterate before factor step) */
+    RN_E_SINGULAR = -4, /* L'WL singular: Engine::inverseBatchMat, Engine.cu:1334-1353 */
+    RN_E_COMM = -5      /* RCCL error */
+};
+
+/* problem dimensions: DwnNetwork.cuh:67-87, SmpcConfiguration.cuh:60-75, ScenarioTree.cuh:64-84 */
+typedef struct {
+    int nx, nu, nv, nd; /* tanks, controls, reduced inputs (nu - ne), demands */
+    int N, K;           /* prediction horizon, scenarios */
+    int nodes, nNonLeafNodes;
+} rn_dims;
+
+/* scenario tree exactly as ScenarioTree's getters return it (ScenarioTree.cuh:92-154) */
+typedef struct {
+    const int *stages;             /* [nodes]   0-based stage of each node              */
+    const int *nodesPerStage;      /* [N+1]                                             */
+    const int *nodesPerStageCumul; /* [N+2]                                             */
+    const int *ancestor;           /* [nodes]   1-based parent, root = 0                */
+    const int *nChildren;          /* [nNonLeafNodes]                                   */
+    const int *nChildrenCumul;     /* [nodes]                                           */
+    const double *probNode;        /* [nodes]                                           */
+} rn_tree;
+
+/* inputs of the factor step: what Engine::initialiseSystemDevice (Engine.cu:382-463) reads from DwnNetwork
+ * and SmpcConfiguration */
+typedef struct {
+    const double *matB;          /* nx x nu */
+    const double *matGd;         /* nx x nd */
+    const double *matL;          /* nu x nv  null-space basis of E (config "matL")      */
+    const double *matLhat;       /* nu x nd  -pinv(E) Ed          (config "matLhat")   */
+    const double *costW;         /* nu x nu */
+    const double *matDiagPrecnd; /* [N][nu | nx | nx] dual preconditioner diagonal      */
+    const double *vecXmin, *vecXmax, *vecXsafe; /* nx */
+    const double *vecUmin, *vecUmax;            /* nu */
+    const double *costAlpha1;                   /* nu */
+} rn_system;
+
+/* buffer ids for rn_get / rn_set: the protected device vectors of SmpcController (SmpcController.cuh:336-462)
+ * and the affine-term arrays of Engine (Engine.cuh:426-648), in the reference's node-major layout */
+enum {
+    RN_BUF_X = 0,      /* devVecX            nodes*nx   */
+    RN_BUF_U,          /* devVecU            nodes*nu   */
+    RN_BUF_V,          /* devVecV            nodes*nv   */
+    RN_BUF_XI,         /* devVecXi           nodes*2nx  (y)        */
+    RN_BUF_PSI,        /* devVecPsi          nodes*nu              */
+    RN_BUF_ACC_XI,     /* devVecAcceleratedXi   (w)                */
+    RN_BUF_ACC_PSI,    /* devVecAcceleratedPsi                     */
+    RN_BUF_UPD_XI,     /* devVecUpdateXi        (y+)               */
+    RN_BUF_UPD_PSI,    /* devVecUpdatePsi                          */
+    RN_BUF_PRIMAL_XI,  /* devVecPrimalXi        (Hx)               */
+    RN_BUF_PRIMAL_PSI, /* devVecPrimalPsi                          */
+    RN_BUF_DUAL_XI,    /* devVecDualXi          (z)                */
+    RN_BUF_DUAL_PSI,   /* devVecDualPsi                            */
+    RN_BUF_RES_XI,     /* devVecFixedPointResidualXi               */
+    RN_BUF_RES_PSI,    /* devVecFixedPointResidualPsi              */
+    RN_BUF_UHAT,       /* Engine devVecUhat  nodes*nu   */
+    RN_BUF_E,          /* Engine devVecE     nodes*nx   */
+    RN_BUF_BETA,       /* Engine devVecBeta  nodes*nv   */
+    RN_BUF_ALPHA,      /* Engine devVecAlpha nodes*nu (getPriceAlpha) */
+    RN_BUF_XMIN, RN_BUF_XMAX, RN_BUF_XS, /* scaled bounds, nodes*nx */
+    RN_BUF_UMIN, RN_BUF_UMAX,            /* nodes*nu */
+    RN_BUF_COUNT
+};
+
+/* per-node operator blocks of Engine::factorStep for rn_get_operator (Engine.cuh getMatPhi() ...) */
+enum { RN_OP_PHI = 0 /* nv x 2nx */, RN_OP_PSI /* nv x nu */, RN_OP_D /* nv x 2nx */, RN_OP_F /* nv x nu */,
+       RN_OP_OMEGA /* nv x nv */, RN_OP_THETA /* nv x nx */, RN_OP_G /* nv x nx */ };
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* Engine::Engine + allocate*Device (Engine.cu:126-380) and SmpcController::allocateSmpcController /
+ * allocateApgAlgorithm (SmpcController.cu:117-232).  `device` is the HIP device ordinal. */
+int rn_create(const rn_dims *dims, const rn_tree *tree, int precision, int device, rn_ctx **out);
+int rn_destroy(rn_ctx *ctx);
+const char *rn_last_error(const rn_ctx *ctx);
+int rn_synchronize(rn_ctx *ctx);
+
+/* ---- Engine -------------------------------------------------------------------------------------- */
+/* Engine::factorStep (Engine.cu:671-774) incl. initialiseSystemDevice / preconditioning kernels. */
+int rn_factor_step(rn_ctx *ctx, const rn_system *sys);
+/* tree errors uploaded once (the reference re-uploads them every control step, Engine.cu:1205,1228) */
+int rn_set_tree_errors(rn_ctx *ctx, const double *errorDemandNode /* nodes*nd */, const double *errorPriceNode /* nodes*nu */);
+/* Engine::setDemandUncertaintyFlag / setPriceUncertaintyFlag / SmpcConfiguration::getWeightEconomical */
+int rn_set_uncertainty(rn_ctx *ctx, int demandUncertainty, int priceUncertainty, double weightEconomical);
+/* Engine::updateStateControl (Engine.cu:1300-1316) */
+int rn_update_state_control(rn_ctx *ctx, const double *currentX, const double *prevU, const double *prevDemand);
+/* Engine::eliminateInputDistubanceCoupling (Engine.cu:1147-1298): nominalDemand [N][nd], nominalPrices [N][nu] */
+int rn_eliminate_input_disturbance_coupling(rn_ctx *ctx, const double *nominalDemand, const double *nominalPrices);
+
+/* ---- SmpcController: algorithm parameters -------------------------------------------------------- */
+/* stepSize, penaltyStateX, penaltySafetyX (SmpcConfiguration.cuh:120-135) */
+int rn_set_parameters(rn_ctx *ctx, double stepSize, double penaltyStateX, double penaltySafetyX);
+
+/* ---- SmpcController: the APG loop ---------------------------------------------------------------- */
+/* SmpcController::initialiseAlgorithm (SmpcController.cu:420-450): zero the duals, theta = {1,1} */
+int rn_apg_reset(rn_ctx *ctx);
+/* `n` iterations of the loop body of SmpcController::algorithmApg (SmpcController.cu:1512-1522), device
+ * resident, no host synchronisation.  primalInfs (may be NULL) receives vecPrimalInfs[] for these n
+ * iterations (this copy synchronises). */
+int rn_apg_iterate(rn_ctx *ctx, int n, double *primalInfs);
+/* SmpcController::algorithmApg (SmpcController.cu:1500-1525) = rn_apg_reset + rn_apg_iterate(maxIterations) */
+int rn_algorithm_apg(rn_ctx *ctx, int maxIterations, double *primalInfs);
+/* SmpcController::controlAction(real_t*) (SmpcController.cu:1607-1625) without the leak check:
+ * update state, eliminate, APG, copy u of the root node (nu reals) to the host. */
+int rn_control_action(rn_ctx *ctx, const double *currentX, const double *prevU, const double *prevDemand,
+                      const double *nominalDemand, const double *nominalPrices, int maxIterations,
+                      int projectOnBounds, double *u0);
+
+/* step-wise entry points mirroring the protected methods the reference's known-answer tests call */
+int rn_dual_extrapolation_step(rn_ctx *ctx, double lambda); /* SmpcController.cu:535-557  */
+int rn_solve_step(rn_ctx *ctx);                             /* SmpcController.cu:563-755  */
+int rn_proximal_fun_g(rn_ctx *ctx);                         /* SmpcController.cu:759-835  */
+int rn_compute_fixed_point_residual(rn_ctx *ctx);           /* SmpcController.cu:839-850  */
+int rn_dual_update(rn_ctx *ctx);                            /* SmpcController.cu:854-864  */
+int rn_update_primal_infeasibility(rn_ctx *ctx, double *value); /* SmpcController.cu:1480-1496 */
+/* tree-global distances computed by the last prox (SmpcController.cu:792,810) */
+int rn_get_prox_distances(rn_ctx *ctx, double *distanceXcst, double *distanceXs);
+
+/* ---- raw access (tests, closed loop) ------------------------------------------------------------- */
+size_t rn_buffer_size(const rn_ctx *ctx, int buffer_id); /* element count, 0 for a bad id */
+int rn_get(rn_ctx *ctx, int buffer_id, double *host, size_t n);
+int rn_set(rn_ctx *ctx, int buffer_id, const double *host, size_t n);
+/* one node's operator block, reference layout (col-major, ld = nv) */
+int rn_get_operator(rn_ctx *ctx, int op_id, int node, double *host, size_t n);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* per-kernel-class device time accumulated by hipEvents when profiling is on (costs a little; off by default).
+ * classes: 0 backward sweep, 1 forward sweep, 2 fused dual update, 3 bookkeeping. ms[] receives the totals,
+ * launches[] the launch counts since the last rn_profile_reset. */
+int rn_profile_enable(rn_ctx *ctx, int on);
+int rn_profile_reset(rn_ctx *ctx);
+int rn_profile_read(rn_ctx *ctx, double ms[4], long launches[4]);
+/* algorithmic HBM bytes of ONE launch of the dominant kernels, as defined in DESIGN.md */
+int rn_algorithmic_bytes(const rn_ctx *ctx, double *backwardStageBytesTotal, double *dualUpdateBytes);
+/* the context's stream as a hipStream_t (void* to keep HIP types out of this header) */
+void *rn_stream(rn_ctx *ctx);
+
+/* ---- multi-GPU: subtree sharding with one RCCL all-reduce at the cut per iteration ---------------- */
+/* see DESIGN.md "multi-GPU"; ncclUniqueId bytes are produced by rn_comm_unique_id on rank 0 and
+ * distributed by the caller (bench.py uses torch.distributed for that). */
+int rn_comm_unique_id(void *id128 /* 128 bytes out */);
+int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
+/* stage c of the (rank-local) tree whose nodes are the roots of the sharded subtrees: the children sums of the
+ * stage c-1 nodes (replicated on every rank) are all-reduced once per iteration; -1 switches sharding off. */
+int rn_set_cut_stage(rn_ctx *ctx, int stage);
+/* per-iteration {max|res_xi|, signed entry, max|res_psi|, signed entry} for iterations [first, first+n), so that
+ * ranks can combine their local arg-max into the tree-global vecPrimalInfs (SmpcController.cu:1480-1496) */
+int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out /* 4*n */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPIDNET_H_ */

@@ -103,19 +103,32 @@ static void gemv_t(int m, int n, real alpha, const real *A, int lda, const real 
         y[j] = alpha * s + ((beta == (real)0) ? (real)0 : beta * y[j]);
     }
 }
-/* C[m x n] = alpha*op(A)*op(B) + beta*C, all col-major. ta/tb: 0 = N, 1 = T */
+/* C[m x n] = alpha*op(A)*op(B) + beta*C, all col-major. ta/tb: 0 = N, 1 = T.
+ * Column-saxpy order so that gcc vectorises it; terms whose op(B) entry is an exact zero are skipped (the
+ * reference multiplies by dense-stored diagonal F_i/G_i; adding 0*a changes nothing). */
 static void gemm(int ta, int tb, int m, int n, int k, real alpha, const real *A, int lda, const real *Bm, int ldb,
                  real beta, real *C, int ldc) {
-    for (int j = 0; j < n; j++)
-        for (int i = 0; i < m; i++) {
-            real s = 0;
-            for (int p = 0; p < k; p++) {
-                real a = ta ? A[p + (size_t)i * lda] : A[i + (size_t)p * lda];
-                real b = tb ? Bm[j + (size_t)p * ldb] : Bm[p + (size_t)j * ldb];
-                s += a * b;
-            }
-            C[i + (size_t)j * ldc] = alpha * s + ((beta == (real)0) ? (real)0 : beta * C[i + (size_t)j * ldc]);
+    real *At = NULL;
+    if (ta) { /* materialise op(A) = A' as an m x k col-major matrix */
+        At = (real *)malloc((size_t)m * k * sizeof(real));
+        for (int p = 0; p < k; p++)
+            for (int i = 0; i < m; i++) At[i + (size_t)p * m] = A[p + (size_t)i * lda];
+        A = At; lda = m;
+    }
+    real *acc = (real *)malloc((size_t)m * sizeof(real));
+    for (int j = 0; j < n; j++) {
+        for (int i = 0; i < m; i++) acc[i] = 0;
+        for (int p = 0; p < k; p++) {
+            real b = tb ? Bm[j + (size_t)p * ldb] : Bm[p + (size_t)j * ldb];
+            if (b == 0) continue;
+            const real *col = A + (size_t)p * lda;
+            for (int i = 0; i < m; i++) acc[i] += col[i] * b;
         }
+        real *c = C + (size_t)j * ldc;
+        if (beta == (real)0) for (int i = 0; i < m; i++) c[i] = alpha * acc[i];
+        else for (int i = 0; i < m; i++) c[i] = alpha * acc[i] + beta * c[i];
+    }
+    free(acc); free(At);
 }
 
 /* inverse of an n x n col-major matrix via LU with partial pivoting (getrfBatched + getriBatched,
@@ -436,7 +449,13 @@ void oracle_solve_step(oracle_t *o) {
             gemv_n(nv, 2 * nx, 1, o->D + (size_t)i * nv * 2 * nx, nv, xi, 1, rj);                /* :633 */
             gemv_n(nv, nu, 1, o->Ftil + (size_t)i * nv * nu, nv, psi, 1, rj);                    /* :638 */
             if (k < N - 1) gemv_n(nv, nx, 1, o->Gtil, nv, qj, 1, rj);                            /* :644 */
-            gemv_t(2 * nx, nx, 1, o->sysF + (size_t)i * 2 * nx * nx, 2 * nx, xi, (k < N - 1) ? (real)1 : (real)0, qj); /* :651/656 */
+            { /* q = F'xi (+ q)  :651/656 ; F_i = [diag; diag] stored dense, only its non-zeros are touched */
+                const real *F = o->sysF + (size_t)i * 2 * nx * nx;
+                for (int t = 0; t < nx; t++) {
+                    real s = F[(size_t)2 * nx * t + t] * xi[t] + F[(size_t)2 * nx * t + nx + t] * xi[nx + t];
+                    qj[t] = (k < N - 1) ? s + qj[t] : s;
+                }
+            }
         }
         if (k > 0) {
             int pn = o->nodesPerStage[k - 1], pc = o->nodesPerStageCumul[k - 1];
@@ -491,8 +510,12 @@ void oracle_solve_step(oracle_t *o) {
     }
     /* Hx  (:744-747) */
     for (int i = 0; i < nodes; i++) {
-        gemv_n(2 * nx, nx, 1, o->sysF + (size_t)i * 2 * nx * nx, 2 * nx, o->x + (size_t)i * nx, 0, o->primalXi + (size_t)i * 2 * nx);
-        gemv_n(nu, nu, 1, o->sysG + (size_t)i * nu * nu, nu, o->u + (size_t)i * nu, 0, o->primalPsi + (size_t)i * nu);
+        const real *F = o->sysF + (size_t)i * 2 * nx * nx, *G = o->sysG + (size_t)i * nu * nu;
+        for (int t = 0; t < nx; t++) {
+            o->primalXi[(size_t)i * 2 * nx + t] = F[(size_t)2 * nx * t + t] * o->x[(size_t)i * nx + t];
+            o->primalXi[(size_t)i * 2 * nx + nx + t] = F[(size_t)2 * nx * t + nx + t] * o->x[(size_t)i * nx + t];
+        }
+        for (int t = 0; t < nu; t++) o->primalPsi[(size_t)i * nu + t] = G[(size_t)nu * t + t] * o->u[(size_t)i * nu + t];
     }
     free(tmpQ); free(tmpR); free(Lv);
 }

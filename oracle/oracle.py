@@ -22,13 +22,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
-def build(force=False):
-    """Compile apg_oracle.c into liboracle_f64.so / liboracle_f32.so next to this file."""
+def build(force=False, march=None):
+    """Compile apg_oracle.c into liboracle_f64.so / liboracle_f32.so next to this file.
+
+    Default -march=x86-64-v3 so that a library built in one container runs on another host; bench.py's
+    cpu_baseline leg rebuilds with march="native" on the machine it times."""
+    march = march or os.environ.get("ORACLE_MARCH", "x86-64-v3")
     src = os.path.join(_HERE, "apg_oracle.c")
     for tag, define in (("f64", []), ("f32", ["-DORACLE_REAL=float"])):
         out = os.path.join(_HERE, "liboracle_%s.so" % tag)
         if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-            cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=c99"] + define + ["-o", out, src, "-lm"]
+            cmd = ["gcc", "-O3", "-march=" + march, "-fPIC", "-shared", "-std=c99"] + define + ["-o", out, src, "-lm"]
             subprocess.check_call(cmd)
     return _HERE
 

@@ -1,0 +1,33 @@
+"""Builds the in-tree native libraries (hipcc cross-compiles for gfx950 without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_HIP = os.path.join(HERE, "librapidnet_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build_hip(force=False, verbose=False):
+    """librapidnet_hip.so: the C-ABI (include/rapidnet.h) + every HIP kernel, for gfx950 only."""
+    srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "rapidnet.h")]
+    if force or _stale(LIB_HIP, srcs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+               "-o", LIB_HIP, srcs[0], "-ldl"]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return LIB_HIP
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose="-v" in sys.argv))

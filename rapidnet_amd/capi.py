@@ -1,0 +1,304 @@
+"""ctypes binding of include/rapidnet.h (librapidnet_hip.so) and a thin Python controller on top of it.
+
+There is no CPU fallback: if the HIP library is missing or fails to load this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+RN_F32, RN_F64 = 0, 1
+(BUF_X, BUF_U, BUF_V, BUF_XI, BUF_PSI, BUF_ACC_XI, BUF_ACC_PSI, BUF_UPD_XI, BUF_UPD_PSI, BUF_PRIMAL_XI,
+ BUF_PRIMAL_PSI, BUF_DUAL_XI, BUF_DUAL_PSI, BUF_RES_XI, BUF_RES_PSI, BUF_UHAT, BUF_E, BUF_BETA, BUF_ALPHA,
+ BUF_XMIN, BUF_XMAX, BUF_XS, BUF_UMIN, BUF_UMAX) = range(24)
+OP_PHI, OP_PSI, OP_D, OP_F, OP_OMEGA, OP_THETA, OP_G = range(7)
+
+# every symbol include/rapidnet.h declares
+SYMBOLS = [
+    "rn_create", "rn_destroy", "rn_last_error", "rn_synchronize", "rn_factor_step", "rn_set_tree_errors",
+    "rn_set_uncertainty", "rn_update_state_control", "rn_eliminate_input_disturbance_coupling", "rn_set_parameters",
+    "rn_apg_reset", "rn_apg_iterate", "rn_algorithm_apg", "rn_control_action", "rn_dual_extrapolation_step",
+    "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
+    "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
+    "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
+    "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts",
+]
+
+
+class RnDims(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("nx", "nu", "nv", "nd", "N", "K", "nodes", "nNonLeafNodes")]
+
+
+class RnTree(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("stages", "nodesPerStage", "nodesPerStageCumul", "ancestor", "nChildren",
+                                         "nChildrenCumul", "probNode")]
+
+
+class RnSystem(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("matB", "matGd", "matL", "matLhat", "costW", "matDiagPrecnd", "vecXmin",
+                                         "vecXmax", "vecXsafe", "vecUmin", "vecUmax", "costAlpha1")]
+
+
+_LIB = None
+
+
+def lib_path():
+    return _build.LIB_HIP
+
+
+def load():
+    """Load librapidnet_hip.so (must have been built: `python -m rapidnet_amd.build`)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("librapidnet_hip.so is missing (%s); run __graft_entry__.build() -- there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
+    lib.rn_create.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree), ip, ip, C.POINTER(vp)]
+    lib.rn_destroy.argtypes = [vp]
+    lib.rn_last_error.argtypes = [vp]
+    lib.rn_last_error.restype = C.c_char_p
+    lib.rn_synchronize.argtypes = [vp]
+    lib.rn_factor_step.argtypes = [vp, C.POINTER(RnSystem)]
+    lib.rn_set_tree_errors.argtypes = [vp, dp, dp]
+    lib.rn_set_uncertainty.argtypes = [vp, ip, ip, C.c_double]
+    lib.rn_update_state_control.argtypes = [vp, dp, dp, dp]
+    lib.rn_eliminate_input_disturbance_coupling.argtypes = [vp, dp, dp]
+    lib.rn_set_parameters.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    lib.rn_apg_reset.argtypes = [vp]
+    lib.rn_apg_iterate.argtypes = [vp, ip, dp]
+    lib.rn_algorithm_apg.argtypes = [vp, ip, dp]
+    lib.rn_control_action.argtypes = [vp, dp, dp, dp, dp, dp, ip, ip, dp]
+    lib.rn_dual_extrapolation_step.argtypes = [vp, C.c_double]
+    for f in ("rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update"):
+        getattr(lib, f).argtypes = [vp]
+    lib.rn_update_primal_infeasibility.argtypes = [vp, dp]
+    lib.rn_get_prox_distances.argtypes = [vp, dp, dp]
+    lib.rn_buffer_size.argtypes = [vp, ip]
+    lib.rn_buffer_size.restype = C.c_size_t
+    lib.rn_get.argtypes = [vp, ip, dp, C.c_size_t]
+    lib.rn_set.argtypes = [vp, ip, dp, C.c_size_t]
+    lib.rn_get_operator.argtypes = [vp, ip, ip, dp, C.c_size_t]
+    lib.rn_profile_enable.argtypes = [vp, ip]
+    lib.rn_profile_reset.argtypes = [vp]
+    lib.rn_profile_read.argtypes = [vp, dp, dp]
+    lib.rn_algorithmic_bytes.argtypes = [vp, dp, dp]
+    lib.rn_stream.argtypes = [vp]
+    lib.rn_stream.restype = vp
+    lib.rn_comm_unique_id.argtypes = [dp]
+    lib.rn_comm_init.argtypes = [vp, ip, ip, dp]
+    lib.rn_set_cut_stage.argtypes = [vp, ip]
+    lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
+    _LIB = lib
+    return lib
+
+
+class RapidNetError(RuntimeError):
+    pass
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel().astype(np.int32))
+
+
+def _s(d, k):
+    v = d[k]
+    return v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
+
+
+class Solver:
+    """Python mirror of the reference's Engine + SmpcController pair for one (network, tree, config) triple.
+
+    Method names follow the reference (Engine.cuh:74-93, SmpcController.cuh:57-203); every method is one call
+    through the C-ABI.  `problem` dicts use the reference's JSON schema.
+    """
+
+    def __init__(self, network, tree, config, precision="f64", device=0):
+        self.lib = load()
+        self.network, self.tree, self.config = network, tree, config
+        self.nx, self.nu, self.nd = (int(_s(network, k)) for k in ("nx", "nu", "nd"))
+        self.nv = int(_s(config, "nv"))
+        self.N, self.K, self.nodes = (int(_s(tree, k)) for k in ("N", "K", "nodes"))
+        self.ny = 2 * self.nx + self.nu
+        self.max_iterations = int(_s(config, "maxIterations"))
+        dims = RnDims(self.nx, self.nu, self.nv, self.nd, self.N, self.K, self.nodes, int(_s(tree, "nNonLeafNodes")))
+        keep = [_i32(tree[k]) for k in ("stages", "nodesPerStage", "nodesPerStageCumul", "ancestor", "nChildren", "nChildrenCumul")]
+        keep.append(_f64(tree["probNode"]))
+        if len(keep[1]) < self.N + 1 or len(keep[2]) < self.N + 2:
+            raise RapidNetError("nodesPerStage needs N+1 and nodesPerStageCumul N+2 entries (ScenarioTree.cu:66-75)")
+        t = RnTree(*[a.ctypes.data for a in keep])
+        h = C.c_void_p()
+        rc = self.lib.rn_create(C.byref(dims), C.byref(t), RN_F64 if precision == "f64" else RN_F32, int(device), C.byref(h))
+        if rc != 0:
+            raise RapidNetError("rn_create failed (%d): %s" % (rc, self.lib.rn_last_error(None).decode()))
+        self.h = h
+        self._check(self.lib.rn_set_parameters(self.h, float(_s(config, "stepSize")), float(_s(config, "penaltyStateX")),
+                                               float(_s(config, "penaltySafetyX"))))
+        ed, ep = _f64(tree["errorDemandNode"]), _f64(tree["errorPriceNode"])
+        self._check(self.lib.rn_set_tree_errors(self.h, ed.ctypes.data, ep.ctypes.data))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RapidNetError("rapidnet error %d: %s" % (rc, self.lib.rn_last_error(self.h).decode()))
+
+    # ---- Engine -------------------------------------------------------------------------------------------
+    def factorStep(self):
+        n, c = self.network, self.config
+        arrs = [_f64(n["matB"]), _f64(n["matGd"]), _f64(c["matL"]), _f64(c["matLhat"]), _f64(c["costW"]),
+                _f64(c["matDiagPrecnd"]), _f64(n["vecXmin"]), _f64(n["vecXmax"]), _f64(n["vecXsafe"]), _f64(n["vecUmin"]),
+                _f64(n["vecUmax"]), _f64(n["costAlpha1"])]
+        assert arrs[0].size == self.nx * self.nu and arrs[2].size == self.nu * self.nv and arrs[3].size == self.nu * self.nd
+        assert arrs[4].size == self.nu * self.nu and arrs[5].size == self.N * (2 * self.nx + self.nu)
+        s = RnSystem(*[a.ctypes.data for a in arrs])
+        self._check(self.lib.rn_factor_step(self.h, C.byref(s)))
+
+    def updateStateControl(self, currentX=None, prevU=None, prevDemand=None):
+        c = self.config
+        a = [_f64(c["currentX"] if currentX is None else currentX), _f64(c["prevU"] if prevU is None else prevU),
+             _f64(c["prevDemand"] if prevDemand is None else prevDemand)]
+        assert a[0].size == self.nx and a[1].size == self.nu and a[2].size == self.nd
+        self._check(self.lib.rn_update_state_control(self.h, *[v.ctypes.data for v in a]))
+
+    def eliminateInputDistubanceCoupling(self, nominalDemand, nominalPrices):
+        dh, ah = _f64(nominalDemand), _f64(nominalPrices)
+        assert dh.size == self.N * self.nd and ah.size == self.N * self.nu
+        self._check(self.lib.rn_eliminate_input_disturbance_coupling(self.h, dh.ctypes.data, ah.ctypes.data))
+
+    def setUncertainty(self, demand=True, price=True, weightEconomical=1.0):
+        self._check(self.lib.rn_set_uncertainty(self.h, int(demand), int(price), float(weightEconomical)))
+
+    def initialiseSmpcController(self, nominalDemand, nominalPrices):
+        """SmpcController::initialiseSmpcController, SmpcController.cu:476-487."""
+        self.factorStep()
+        self.updateStateControl()
+        self.eliminateInputDistubanceCoupling(nominalDemand, nominalPrices)
+
+    # ---- SmpcController -------------------------------------------------------------------------------------
+    def apgReset(self):
+        self._check(self.lib.rn_apg_reset(self.h))
+
+    def apgIterate(self, n, history=True):
+        hist = np.zeros(max(n, 1)) if history else None
+        self._check(self.lib.rn_apg_iterate(self.h, int(n), hist.ctypes.data if history else None))
+        return hist[:n] if history else None
+
+    def algorithmApg(self, maxIterations=None):
+        n = self.max_iterations if maxIterations is None else int(maxIterations)
+        hist = np.zeros(max(n, 1))
+        self._check(self.lib.rn_algorithm_apg(self.h, n, hist.ctypes.data))
+        return hist[:n]
+
+    def controlAction(self, nominalDemand, nominalPrices, currentX=None, prevU=None, prevDemand=None, maxIterations=None,
+                      project=False):
+        c = self.config
+        a = [_f64(c["currentX"] if currentX is None else currentX), _f64(c["prevU"] if prevU is None else prevU),
+             _f64(c["prevDemand"] if prevDemand is None else prevDemand), _f64(nominalDemand), _f64(nominalPrices)]
+        u0 = np.zeros(self.nu)
+        n = self.max_iterations if maxIterations is None else int(maxIterations)
+        self._check(self.lib.rn_control_action(self.h, *[v.ctypes.data for v in a], n, int(project), u0.ctypes.data))
+        return u0
+
+    def dualExtrapolationStep(self, lam):
+        self._check(self.lib.rn_dual_extrapolation_step(self.h, float(lam)))
+
+    def solveStep(self):
+        self._check(self.lib.rn_solve_step(self.h))
+
+    def proximalFunG(self):
+        self._check(self.lib.rn_proximal_fun_g(self.h))
+
+    def computeFixedPointResidual(self):
+        self._check(self.lib.rn_compute_fixed_point_residual(self.h))
+
+    def dualUpdate(self):
+        self._check(self.lib.rn_dual_update(self.h))
+
+    def updatePrimalInfeasibity(self):
+        v = C.c_double(0)
+        self._check(self.lib.rn_update_primal_infeasibility(self.h, C.byref(v)))
+        return v.value
+
+    def proxDistances(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self.lib.rn_get_prox_distances(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- raw access -----------------------------------------------------------------------------------------
+    def get(self, buf):
+        n = self.lib.rn_buffer_size(self.h, buf)
+        out = np.zeros(n)
+        self._check(self.lib.rn_get(self.h, buf, out.ctypes.data, n))
+        return out
+
+    def set(self, buf, values):
+        v = _f64(values)
+        self._check(self.lib.rn_set(self.h, buf, v.ctypes.data, v.size))
+
+    def getOperator(self, op, node):
+        nx, nu, nv = self.nx, self.nu, self.nv
+        n = {OP_PHI: nv * 2 * nx, OP_D: nv * 2 * nx, OP_PSI: nv * nu, OP_F: nv * nu, OP_OMEGA: nv * nv, OP_THETA: nv * nx,
+             OP_G: nv * nx}[op]
+        out = np.zeros(n)
+        self._check(self.lib.rn_get_operator(self.h, op, int(node), out.ctypes.data, n))
+        return out
+
+    def synchronize(self):
+        self._check(self.lib.rn_synchronize(self.h))
+
+    # ---- measurement ----------------------------------------------------------------------------------------
+    def profileEnable(self, on=1):
+        self._check(self.lib.rn_profile_enable(self.h, int(on)))
+
+    def profileReset(self):
+        self._check(self.lib.rn_profile_reset(self.h))
+
+    def profileRead(self):
+        ms = np.zeros(4)
+        n = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.rn_profile_read(self.h, ms.ctypes.data, n.ctypes.data))
+        return ms, n
+
+    def algorithmicBytes(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self.lib.rn_algorithmic_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- multi-GPU ------------------------------------------------------------------------------------------
+    def commInit(self, rank, nranks, unique_id_bytes):
+        buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
+        self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
+
+    def setCutStage(self, stage):
+        self._check(self.lib.rn_set_cut_stage(self.h, int(stage)))
+
+    def historyParts(self, first, n):
+        out = np.zeros(4 * n)
+        self._check(self.lib.rn_get_history_parts(self.h, int(first), int(n), out.ctypes.data))
+        return out.reshape(n, 4)
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = load().rn_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise RapidNetError("rn_comm_unique_id failed (%d)" % rc)
+    return bytes(buf.raw)

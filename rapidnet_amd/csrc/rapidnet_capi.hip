@@ -1,0 +1,840 @@
+// rapidnet_capi.hip -- implementation of include/rapidnet.h (librapidnet_hip.so).
+//
+// Host side of the boundary: owns every device allocation, drives the kernels of kernels.hpp on one HIP
+// stream, never synchronises inside the APG loop.  No torch types, no cuBLAS/rocBLAS: the only external
+// libraries are the HIP runtime and (lazily, for multi-GPU) RCCL.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rapidnet.h"
+#include "kernels.hpp"
+
+namespace rn {
+
+#define RN_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char b_[512];                                                                              \
+            snprintf(b_, sizeof b_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); \
+            err = b_;                                                                                  \
+            return RN_E_HIP;                                                                           \
+        }                                                                                              \
+    } while (0)
+
+#define RN_CHECK(cond, code, msg)  \
+    do {                           \
+        if (!(cond)) {             \
+            err = (msg);           \
+            return (code);         \
+        }                          \
+    } while (0)
+
+// ---- minimal RCCL binding, resolved at run time (so single-GPU users never load it) ---------------------
+struct NcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+        AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+        CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+        return GetUniqueId && AllReduce && dlsym(h, "ncclCommInitRank");
+    }
+};
+static NcclApi g_nccl;
+struct UniqueId128 { char b[128]; };
+
+struct CtxBase {
+    std::string err;
+    virtual ~CtxBase() {}
+    virtual int factor_step(const rn_system *) = 0;
+    virtual int set_tree_errors(const double *, const double *) = 0;
+    virtual int set_uncertainty(int, int, double) = 0;
+    virtual int update_state_control(const double *, const double *, const double *) = 0;
+    virtual int eliminate(const double *, const double *) = 0;
+    virtual int set_parameters(double, double, double) = 0;
+    virtual int apg_reset() = 0;
+    virtual int apg_iterate(int, double *) = 0;
+    virtual int control_action(const double *, const double *, const double *, const double *, const double *, int, int,
+                               double *) = 0;
+    virtual int extrapolate(double) = 0;
+    virtual int solve_step() = 0;
+    virtual int prox() = 0;
+    virtual int residual() = 0;
+    virtual int dual_update() = 0;
+    virtual int primal_infeasibility(double *) = 0;
+    virtual int prox_distances(double *, double *) = 0;
+    virtual size_t buffer_size(int) const = 0;
+    virtual int get(int, double *, size_t) = 0;
+    virtual int set(int, const double *, size_t) = 0;
+    virtual int get_operator(int, int, double *, size_t) = 0;
+    virtual int profile_enable(int) = 0;
+    virtual int profile_reset() = 0;
+    virtual int profile_read(double *, long *) = 0;
+    virtual int algorithmic_bytes(double *, double *) const = 0;
+    virtual int synchronize() = 0;
+    virtual void *stream_handle() = 0;
+    virtual int comm_init(int, int, const void *) = 0;
+    virtual int set_cut_stage(int) = 0;
+    virtual int hist_parts(int, int, double *) = 0;
+};
+
+// dense host helpers (fp64, column-major) ---------------------------------------------------------------
+static void h_gemm(bool ta, bool tb, int m, int n, int k, const double *A, int lda, const double *B, int ldb, double *C) {
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < m; i++) {
+            double s = 0;
+            for (int p = 0; p < k; p++)
+                s += (ta ? A[p + (size_t)i * lda] : A[i + (size_t)p * lda]) * (tb ? B[j + (size_t)p * ldb] : B[p + (size_t)j * ldb]);
+            C[i + (size_t)j * m] = s;
+        }
+}
+static int h_inverse(int n, std::vector<double> A, double *Ainv) {  // LU with partial pivoting
+    std::vector<int> piv(n);
+    for (int k = 0; k < n; k++) {
+        int p = k; double mx = std::fabs(A[k + (size_t)k * n]);
+        for (int i = k + 1; i < n; i++) if (std::fabs(A[i + (size_t)k * n]) > mx) { mx = std::fabs(A[i + (size_t)k * n]); p = i; }
+        piv[k] = p;
+        if (mx == 0.0 || !std::isfinite(mx)) return k + 1;
+        if (p != k) for (int j = 0; j < n; j++) std::swap(A[k + (size_t)j * n], A[p + (size_t)j * n]);
+        const double d = A[k + (size_t)k * n];
+        for (int i = k + 1; i < n; i++) A[i + (size_t)k * n] /= d;
+        for (int j = k + 1; j < n; j++) { const double akj = A[k + (size_t)j * n]; for (int i = k + 1; i < n; i++) A[i + (size_t)j * n] -= A[i + (size_t)k * n] * akj; }
+    }
+    std::vector<double> b(n);
+    for (int c = 0; c < n; c++) {
+        for (int i = 0; i < n; i++) b[i] = (i == c) ? 1.0 : 0.0;
+        for (int k = 0; k < n; k++) if (piv[k] != k) std::swap(b[k], b[piv[k]]);
+        for (int k = 0; k < n; k++) { const double bk = b[k]; for (int i = k + 1; i < n; i++) b[i] -= A[i + (size_t)k * n] * bk; }
+        for (int k = n - 1; k >= 0; k--) { b[k] /= A[k + (size_t)k * n]; const double bk = b[k]; for (int i = 0; i < k; i++) b[i] -= A[i + (size_t)k * n] * bk; }
+        for (int i = 0; i < n; i++) Ainv[i + (size_t)c * n] = b[i];
+    }
+    return 0;
+}
+
+template <typename T>
+struct Ctx : CtxBase {
+    rn_dims d{};
+    int ny = 0, LD = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool factored = false, affine_ready = false;
+    // host copies of the tree and of the shared factors (fp64)
+    std::vector<int> h_stageCum, h_parent, h_childStart, h_childCount, h_stageOf;
+    std::vector<double> h_prob, h_Rinv, h_Bbt, h_diag /* [N][nu|nx|nx] as given */;
+    // device allocations
+    std::vector<void *> allocs;
+    int *d_stageCum = nullptr, *d_parent = nullptr, *d_childStart = nullptr, *d_childCount = nullptr, *d_stageOf = nullptr;
+    T *d_sqrtp = nullptr, *d_prob = nullptr, *d_dy = nullptr;
+    T *d_A = nullptr, *d_Rinv = nullptr, *d_Bbt = nullptr, *d_L = nullptr, *d_B = nullptr, *d_Lt = nullptr, *d_WLt = nullptr;
+    T *d_T1 = nullptr, *d_T2 = nullptr, *d_Gd = nullptr, *d_Lhat = nullptr, *d_alpha1 = nullptr, *d_blo = nullptr, *d_bhi = nullptr;
+    T *d_errD = nullptr, *d_errP = nullptr, *d_dhat = nullptr, *d_ahat = nullptr;
+    T *d_curX = nullptr, *d_prevU = nullptr, *d_prevUhat = nullptr, *d_prevD = nullptr;
+    T *d_beta = nullptr, *d_uhat = nullptr, *d_e = nullptr, *d_alpha = nullptr;
+    T *d_x = nullptr, *d_u = nullptr, *d_v = nullptr, *d_rt = nullptr, *d_q = nullptr, *d_hx = nullptr;
+    T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
+    T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
+    T *d_tmp = nullptr;  // nodes*max(2nx,nu) staging for reference-layout get/set
+    T *d_cut = nullptr;  // multi-GPU all-reduce payload
+    // logical views (see DESIGN.md "iterate buffers")
+    T *p_xi = nullptr, *p_upd = nullptr, *p_acc = nullptr, *p_acc_other = nullptr, *p_acc_view = nullptr;
+    bool acc_ready = false;
+    IterState *d_state = nullptr;
+    Partial *d_partials = nullptr;
+    double *d_lam = nullptr, *d_hist = nullptr, *d_histParts = nullptr;
+    int lamCap = 0, histCap = 0;
+    int h_it = 0;
+    double theta0 = 1, theta1 = 1;
+    std::vector<double> h_lam;
+    double stepSize = 1e-4, penX = 1e6, penXs = 1e4, wEco = 1.0;
+    int useErrD = 1, useErrP = 1;
+    int eltBlocks = 1;
+    // profiling
+    int prof = 0;
+    struct EvPair { int cls; hipEvent_t a, b; };
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> freeEvents;
+    double prof_ms[4] = {0, 0, 0, 0};
+    long prof_n[4] = {0, 0, 0, 0};
+    // multi-GPU
+    void *comm = nullptr;
+    int rank = 0, nranks = 1, cutStage = -1;
+
+    ~Ctx() override {
+        if (comm && g_nccl.CommDestroy) g_nccl.CommDestroy(comm);
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        for (auto e : freeEvents) (void)hipEventDestroy(e);
+        for (void *p : allocs) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    template <typename U> int dalloc(U **p, size_t n) {
+        void *q = nullptr;
+        RN_HIP(hipMalloc(&q, (n ? n : 1) * sizeof(U)));
+        allocs.push_back(q);
+        *p = (U *)q;
+        return RN_OK;
+    }
+    int upload(T *dst, const double *src, size_t n) {
+        std::vector<T> tmp(n);
+        for (size_t i = 0; i < n; i++) tmp[i] = (T)src[i];
+        RN_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice, stream));
+        RN_HIP(hipStreamSynchronize(stream));  // tmp goes out of scope
+        return RN_OK;
+    }
+    int download(double *dst, const T *src, size_t n) {
+        std::vector<T> tmp(n);
+        RN_HIP(hipMemcpyAsync(tmp.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
+        return RN_OK;
+    }
+    int upload_int(int *dst, const std::vector<int> &v) {
+        RN_HIP(hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        return RN_OK;
+    }
+
+    TreeDev<T> tree_dev() const { return TreeDev<T>{d_stageCum, d_parent, d_childStart, d_childCount, d_stageOf, d_sqrtp, d_prob, d_dy}; }
+    SweepArgs<T> sweep_args() const {
+        SweepArgs<T> a{};
+        a.tr = tree_dev();
+        a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD;
+        a.A = d_A; a.Rinv = d_Rinv; a.Bbt = d_Bbt; a.L = d_L; a.B = d_B;
+        a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
+        a.w = p_acc; a.v = d_v; a.rt = d_rt; a.q = d_q; a.x = d_x; a.u = d_u; a.hx = d_hx;
+        a.cutSums = (nranks > 1 && cutStage > 0) ? d_cut : nullptr;
+        a.cutStage = cutStage;
+        return a;
+    }
+    long long ntot() const { return (long long)d.nodes * ny; }
+
+    // ---- construction --------------------------------------------------------------------------------
+    int init(const rn_dims *dims, const rn_tree *tr, int dev) {
+        d = *dims; device = dev;
+        RN_CHECK(d.nx > 0 && d.nu > 0 && d.nv > 0 && d.nd > 0 && d.N > 0 && d.K > 0 && d.nodes > 0, RN_E_ARG, "rn_create: non-positive dimension");
+        RN_CHECK(d.nv <= d.nu, RN_E_ARG, "rn_create: nv must not exceed nu");
+        ny = 2 * d.nx + d.nu;
+        LD = (2 * d.nv + RPL - 1) / RPL * RPL;
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        const int N = d.N, nodes = d.nodes;
+        // validate and convert the tree (reference conventions -> 0-based parent/children ranges)
+        h_stageCum.assign(tr->nodesPerStageCumul, tr->nodesPerStageCumul + N + 1);
+        RN_CHECK(h_stageCum[0] == 0 && h_stageCum[N] == nodes, RN_E_ARG, "rn_create: nodesPerStageCumul inconsistent with nodes");
+        h_parent.resize(nodes); h_childStart.assign(nodes, 0); h_childCount.assign(nodes, 0); h_stageOf.resize(nodes); h_prob.resize(nodes);
+        for (int k = 0; k < N; k++) {
+            RN_CHECK(tr->nodesPerStage[k] == h_stageCum[k + 1] - h_stageCum[k] && tr->nodesPerStage[k] > 0, RN_E_ARG, "rn_create: nodesPerStage inconsistent");
+            for (int i = h_stageCum[k]; i < h_stageCum[k + 1]; i++) {
+                RN_CHECK(tr->stages[i] == k, RN_E_ARG, "rn_create: nodes are not numbered stage by stage");
+                h_stageOf[i] = k;
+            }
+        }
+        RN_CHECK(h_stageCum[1] == 1 && tr->ancestor[0] == 0, RN_E_ARG, "rn_create: node 0 must be the only root");
+        h_parent[0] = -1;
+        for (int i = 0; i < nodes; i++) {
+            h_prob[i] = tr->probNode[i];
+            RN_CHECK(h_prob[i] > 0.0 && std::isfinite(h_prob[i]), RN_E_ARG, "rn_create: probNode must be positive");
+            if (i == 0) continue;
+            const int par = tr->ancestor[i] - 1;
+            RN_CHECK(par >= 0 && par < i && h_stageOf[par] == h_stageOf[i] - 1, RN_E_ARG, "rn_create: ancestor must be a node of the previous stage");
+            RN_CHECK(par >= h_parent[i - 1] || h_stageOf[i - 1] != h_stageOf[i], RN_E_ARG, "rn_create: children of a node must be contiguous");
+            h_parent[i] = par;
+            if (h_childCount[par] == 0) h_childStart[par] = i;
+            RN_CHECK(h_childStart[par] + h_childCount[par] == i, RN_E_ARG, "rn_create: children of a node must be contiguous");
+            h_childCount[par]++;
+        }
+        int leaves = 0, nonleaf = 0;
+        for (int i = 0; i < nodes; i++) (h_childCount[i] == 0 ? leaves : nonleaf)++;
+        RN_CHECK(nonleaf == d.nNonLeafNodes, RN_E_ARG, "rn_create: nNonLeafNodes inconsistent with ancestor[]");
+        (void)leaves;
+        if (int rc = dalloc(&d_stageCum, N + 1)) return rc;
+        if (int rc = dalloc(&d_parent, nodes)) return rc;
+        if (int rc = dalloc(&d_childStart, nodes)) return rc;
+        if (int rc = dalloc(&d_childCount, nodes)) return rc;
+        if (int rc = dalloc(&d_stageOf, nodes)) return rc;
+        if (int rc = upload_int(d_stageCum, h_stageCum)) return rc;
+        if (int rc = upload_int(d_parent, h_parent)) return rc;
+        if (int rc = upload_int(d_childStart, h_childStart)) return rc;
+        if (int rc = upload_int(d_childCount, h_childCount)) return rc;
+        if (int rc = upload_int(d_stageOf, h_stageOf)) return rc;
+        const size_t n = nodes;
+        const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd;
+#define DA(ptr, cnt) if (int rc = dalloc(&ptr, (size_t)(cnt))) return rc;
+        DA(d_sqrtp, n) DA(d_prob, n) DA(d_dy, (size_t)N * ny)
+        DA(d_A, n * ny * LD)
+        DA(d_Rinv, nv * nv) DA(d_Bbt, nv * nx) DA(d_L, nu * nv) DA(d_B, nx * nu) DA(d_Lt, nv * nu) DA(d_WLt, nv * nu)
+        DA(d_T1, nv * nx) DA(d_T2, nv * nu) DA(d_Gd, nx * nd) DA(d_Lhat, nu * nd) DA(d_alpha1, nu) DA(d_blo, ny) DA(d_bhi, ny)
+        DA(d_errD, n * nd) DA(d_errP, n * nu) DA(d_dhat, (size_t)N * nd) DA(d_ahat, (size_t)N * nu)
+        DA(d_curX, nx) DA(d_prevU, nu) DA(d_prevUhat, nu) DA(d_prevD, nd)
+        DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
+        DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_rt, n * nv) DA(d_q, n * nx) DA(d_hx, n * ny)
+        DA(d_lo, n * ny) DA(d_hi, n * ny) DA(d_z, n * ny) DA(d_res, n * ny)
+        DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
+        DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
+        DA(d_cut, (size_t)nodes * (nv + nx))  // upper bound on cut parents
+        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS)
+#undef DA
+        std::vector<double> sq(nodes);
+        for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
+        if (int rc = upload(d_sqrtp, sq.data(), nodes)) return rc;
+        if (int rc = upload(d_prob, h_prob.data(), nodes)) return rc;
+        RN_HIP(hipMemsetAsync(d_errD, 0, n * nd * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_errP, 0, n * nu * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_z, 0, n * ny * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_res, 0, n * ny * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_x, 0, n * nx * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_u, 0, n * nu * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_v, 0, n * nv * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(d_hx, 0, n * ny * sizeof(T), stream));
+        const long long want = (ntot() + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
+        eltBlocks = (int)std::max<long long>(1, std::min<long long>(ELT_MAX_BLOCKS, want));
+        p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
+        return apg_reset();
+    }
+
+    // ---- Engine ----------------------------------------------------------------------------------------
+    int factor_step(const rn_system *s) override {
+        RN_CHECK(s && s->matB && s->matGd && s->matL && s->matLhat && s->costW && s->matDiagPrecnd && s->vecXmin && s->vecXmax &&
+                     s->vecXsafe && s->vecUmin && s->vecUmax && s->costAlpha1, RN_E_ARG, "rn_factor_step: null input");
+        RN_HIP(hipSetDevice(device));
+        const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd, N = d.N;
+        // Rbar = L' W L  (Engine.cu:412-416), inverse once: Omega_i = Rbar^-1 / p_i (Engine.cu:707-714)
+        std::vector<double> WL((size_t)nu * nv), Rbar((size_t)nv * nv), Lt((size_t)nv * nu), WLt((size_t)nv * nu);
+        h_gemm(false, false, nu, nv, nu, s->costW, nu, s->matL, nu, WL.data());
+        h_gemm(true, false, nv, nv, nu, s->matL, nu, WL.data(), nu, Rbar.data());
+        h_Rinv.assign((size_t)nv * nv, 0.0);
+        RN_CHECK(h_inverse(nv, Rbar, h_Rinv.data()) == 0, RN_E_SINGULAR, "rn_factor_step: L'WL is singular");
+        h_Bbt.assign((size_t)nv * nx, 0.0);
+        h_gemm(true, true, nv, nx, nu, s->matL, nu, s->matB, nx, h_Bbt.data());  // Bbar' = L'B' (Engine.cu:702-705)
+        std::vector<double> T1((size_t)nv * nx), T2((size_t)nv * nu);
+        for (int i = 0; i < nu; i++) for (int j = 0; j < nv; j++) { Lt[j + (size_t)i * nv] = s->matL[i + (size_t)j * nu]; WLt[j + (size_t)i * nv] = WL[i + (size_t)j * nu]; }
+        h_gemm(false, false, nv, nx, nv, h_Rinv.data(), nv, h_Bbt.data(), nv, T1.data());
+        h_gemm(false, false, nv, nu, nv, h_Rinv.data(), nv, Lt.data(), nv, T2.data());
+        // preconditioner diagonal re-ordered to y order: (d_x | d_xs | d_u) per stage
+        h_diag.assign(s->matDiagPrecnd, s->matDiagPrecnd + (size_t)N * (2 * nx + nu));
+        std::vector<double> dy((size_t)N * ny), blo(ny), bhi(ny);
+        for (int k = 0; k < N; k++) {
+            const double *dk = s->matDiagPrecnd + (size_t)k * (2 * nx + nu);
+            for (int t = 0; t < 2 * nx; t++) dy[(size_t)k * ny + t] = dk[nu + t];
+            for (int t = 0; t < nu; t++) dy[(size_t)k * ny + 2 * nx + t] = dk[t];
+        }
+        // "no upper bound" on the safety half: the reference memsets bytes 0x7F (Engine.cu:454-455)
+        T big; std::memset(&big, 0x7F, sizeof(T));
+        for (int t = 0; t < nx; t++) { blo[t] = s->vecXmin[t]; bhi[t] = s->vecXmax[t]; blo[nx + t] = s->vecXsafe[t]; bhi[nx + t] = (double)big; }
+        for (int t = 0; t < nu; t++) { blo[2 * nx + t] = s->vecUmin[t]; bhi[2 * nx + t] = s->vecUmax[t]; }
+#define UP(dst, src, cnt) if (int rc = upload(dst, src, (size_t)(cnt))) return rc;
+        UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
+        UP(d_Lt, Lt.data(), nv * nu) UP(d_WLt, WLt.data(), nv * nu) UP(d_T1, T1.data(), nv * nx) UP(d_T2, T2.data(), nv * nu)
+        UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu)
+        UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
+#undef UP
+        ExpandArgs<T> ea{};
+        ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.nodes = d.nodes;
+        ea.T1 = d_T1; ea.T2 = d_T2; ea.Bbt = d_Bbt; ea.Lt = d_Lt; ea.A = d_A; ea.blo = d_blo; ea.bhi = d_bhi; ea.lo = d_lo; ea.hi = d_hi;
+        const int colChunks = std::min(ny, 8);
+        hipLaunchKernelGGL(k_expand_operators<T>, dim3(d.nodes, colChunks), dim3(LD >= 192 ? 256 : (LD >= 96 ? 128 : 64)), 0, stream, ea);
+        RN_HIP(hipGetLastError());
+        RN_HIP(hipStreamSynchronize(stream));
+        factored = true;
+        return RN_OK;
+    }
+    int set_tree_errors(const double *ed, const double *ep) override {
+        RN_CHECK(ed && ep, RN_E_ARG, "rn_set_tree_errors: null input");
+        RN_HIP(hipSetDevice(device));
+        if (int rc = upload(d_errD, ed, (size_t)d.nodes * d.nd)) return rc;
+        return upload(d_errP, ep, (size_t)d.nodes * d.nu);
+    }
+    int set_uncertainty(int dflag, int pflag, double w) override { useErrD = dflag ? 1 : 0; useErrP = pflag ? 1 : 0; wEco = w; return RN_OK; }
+    int update_state_control(const double *x0, const double *up, const double *dp) override {
+        RN_CHECK(factored, RN_E_STATE, "rn_update_state_control before rn_factor_step");
+        RN_CHECK(x0 && up && dp, RN_E_ARG, "rn_update_state_control: null input");
+        RN_HIP(hipSetDevice(device));
+        if (int rc = upload(d_curX, x0, d.nx)) return rc;
+        if (int rc = upload(d_prevU, up, d.nu)) return rc;
+        if (int rc = upload(d_prevD, dp, d.nd)) return rc;
+        hipLaunchKernelGGL(k_gemv_small<T>, dim3(1), dim3(128), 0, stream, d_Lhat, d.nu, d.nd, d_prevD, d_prevUhat);  // Engine.cu:1314
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
+    int eliminate(const double *dhat, const double *ahat) override {
+        RN_CHECK(factored, RN_E_STATE, "rn_eliminate_input_disturbance_coupling before rn_factor_step");
+        RN_CHECK(dhat && ahat, RN_E_ARG, "rn_eliminate_input_disturbance_coupling: null input");
+        RN_HIP(hipSetDevice(device));
+        if (int rc = upload(d_dhat, dhat, (size_t)d.N * d.nd)) return rc;
+        if (int rc = upload(d_ahat, ahat, (size_t)d.N * d.nu)) return rc;
+        AffineArgs<T> a{};
+        a.tr = tree_dev(); a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.nd = d.nd;
+        a.Gd = d_Gd; a.Lhat = d_Lhat; a.WLt = d_WLt; a.Lt = d_Lt; a.errD = d_errD; a.errP = d_errP; a.dhat = d_dhat; a.ahat = d_ahat;
+        a.alpha1 = d_alpha1; a.prevUhat = d_prevUhat; a.wEco = (T)wEco; a.useErrD = useErrD; a.useErrP = useErrP;
+        a.e = d_e; a.uhat = d_uhat; a.alpha = d_alpha; a.beta = d_beta;
+        const size_t sh1 = (size_t)(((d.nd + 3) & ~3) + ((std::max(d.nx, d.nu) + 3) & ~3) + AFF_THREADS) * sizeof(T);
+        const size_t sh2 = (size_t)(2 * ((d.nu + 3) & ~3) + 2 * ((d.nv + 3) & ~3) + AFF_THREADS) * sizeof(T);
+        const hipEvent_t *e0 = prof_begin(3);
+        hipLaunchKernelGGL(k_affine_demand<T>, dim3(d.nodes), dim3(AFF_THREADS), sh1, stream, a);
+        hipLaunchKernelGGL(k_affine_beta<T>, dim3(d.nodes), dim3(AFF_THREADS), sh2, stream, a);
+        prof_end(e0);
+        RN_HIP(hipGetLastError());
+        affine_ready = true;
+        return RN_OK;
+    }
+    int set_parameters(double step, double px, double pxs) override {
+        RN_CHECK(step > 0 && std::isfinite(step), RN_E_ARG, "rn_set_parameters: stepSize must be positive");
+        stepSize = step; penX = px; penXs = pxs;
+        return RN_OK;
+    }
+
+    // ---- profiling helpers -----------------------------------------------------------------------------
+    hipEvent_t get_event() {
+        if (!freeEvents.empty()) { hipEvent_t e = freeEvents.back(); freeEvents.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    const hipEvent_t *prof_begin(int cls) {
+        if (!prof) return nullptr;
+        if (pending.size() >= 60000) (void)prof_flush();
+        pending.push_back(EvPair{cls, get_event(), get_event()});
+        (void)hipEventRecord(pending.back().a, stream);
+        return &pending.back().b;
+    }
+    void prof_end(const hipEvent_t *e) { if (e) (void)hipEventRecord(*e, stream); }
+    int prof_flush() {
+        if (pending.empty()) return RN_OK;
+        RN_HIP(hipStreamSynchronize(stream));
+        for (auto &p : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof_ms[p.cls] += ms; prof_n[p.cls]++; }
+            freeEvents.push_back(p.a); freeEvents.push_back(p.b);
+        }
+        pending.clear();
+        return RN_OK;
+    }
+    int profile_enable(int on) override { if (!on) { int rc = prof_flush(); prof = 0; return rc; } prof = on; return RN_OK; }
+    int profile_reset() override { int rc = prof_flush(); for (int i = 0; i < 4; i++) { prof_ms[i] = 0; prof_n[i] = 0; } return rc; }
+    int profile_read(double *ms, long *n) override {
+        int rc = prof_flush();
+        for (int i = 0; i < 4; i++) { ms[i] = prof_ms[i]; n[i] = prof_n[i]; }
+        return rc;
+    }
+    int algorithmic_bytes(double *bwd, double *dual) const override {
+        // backward sweep: A_i once + read w, beta, children rt/q; write v, rt, q   (all stages of one sweep)
+        const double s = sizeof(T), n = d.nodes;
+        if (bwd) *bwd = n * ((double)2 * d.nv * ny + ny + 3.0 * d.nv + 2.0 * d.nx + (d.nv + d.nx)) * s;
+        if (dual) *dual = 7.0 * (double)ntot() * s;
+        return RN_OK;
+    }
+    int synchronize() override { RN_HIP(hipSetDevice(device)); RN_HIP(hipStreamSynchronize(stream)); return RN_OK; }
+    void *stream_handle() override { return (void *)stream; }
+
+    // ---- the sweep ---------------------------------------------------------------------------------------
+    size_t bwd_lds() const {
+        const int LDp = (LD + 3) & ~3;
+        return (size_t)(((ny + 3) & ~3) + 2 * ((d.nv + 3) & ~3) + ((d.nx + 3) & ~3) + BWD_WAVES * LDp + BWD_THREADS) * sizeof(T);
+    }
+    size_t fwd_lds() const {
+        return (size_t)(((d.nv + 3) & ~3) + ((d.nu + 3) & ~3) + ((std::max(d.nu, d.nx) + 3) & ~3) + FWD_THREADS) * sizeof(T);
+    }
+    int launch_sweep() {
+        SweepArgs<T> a = sweep_args();
+        const size_t lb = bwd_lds(), lf = fwd_lds();
+        for (int k = d.N - 1; k >= 0; k--) {
+            const int nk = h_stageCum[k + 1] - h_stageCum[k];
+            if (a.cutSums && k == cutStage - 1) {   // multi-GPU: all-reduce the children sums of the cut parents
+                const hipEvent_t *ec = prof_begin(3);
+                hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk), dim3(128), 0, stream, a, d_cut);
+                const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk * (d.nv + d.nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
+                                                0 /*ncclSum*/, comm, stream);
+                prof_end(ec);
+                RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+            }
+            const hipEvent_t *e0 = prof_begin(0);
+            hipLaunchKernelGGL(k_backward_stage<T>, dim3(nk), dim3(BWD_THREADS), lb, stream, a, k);
+            prof_end(e0);
+        }
+        const hipEvent_t *e1 = prof_begin(1);
+        for (int k = 0; k < d.N; k++) {
+            const int nk = h_stageCum[k + 1] - h_stageCum[k];
+            hipLaunchKernelGGL(k_forward_stage<T>, dim3(nk), dim3(FWD_THREADS), lf, stream, a, k);
+        }
+        prof_end(e1);
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
+    DualArgs<T> dual_args() const {
+        DualArgs<T> a{};
+        a.hx = d_hx; a.w = p_acc; a.yprev = p_upd; a.lo = d_lo; a.hi = d_hi;
+        a.ynew = p_xi; a.wnext = p_acc_other; a.z = d_z; a.res = d_res;
+        a.n = ntot(); a.nx = d.nx; a.ny = ny;
+        a.lambda = (T)stepSize; a.invLambda = (T)(1.0 / stepSize);
+        a.lamNext = d_lam; a.thrX = penX / stepSize; a.thrS = penXs / stepSize;
+        a.st = d_state; a.partials = d_partials;
+        a.crownElems = 0; a.countCrown = 1;
+        if (nranks > 1 && cutStage > 0) { a.crownElems = h_stageCum[cutStage] * ny; a.countCrown = (rank == 0); }
+        return a;
+    }
+    int ensure_tables(int upto) {  // lambda table and history capacity for iterations [0, upto]
+        while ((int)h_lam.size() <= upto + 1) {   // theta recursion, SmpcController.cu:1513-1520
+            h_lam.push_back(theta1 * (1.0 / theta0 - 1.0));
+            theta0 = theta1;
+            theta1 = 0.5 * (std::sqrt(std::pow(theta1, 4) + 4 * std::pow(theta1, 2)) - std::pow(theta1, 2));
+        }
+        if (upto + 2 > lamCap) {
+            const int cap = std::max(1024, 2 * (upto + 2));
+            double *nl = nullptr, *nh = nullptr, *np = nullptr;
+            if (int rc = dalloc(&nl, cap)) return rc;
+            if (int rc = dalloc(&nh, cap)) return rc;
+            if (int rc = dalloc(&np, (size_t)4 * cap)) return rc;
+            RN_HIP(hipStreamSynchronize(stream));
+            if (d_hist && histCap) {
+                RN_HIP(hipMemcpy(nh, d_hist, histCap * sizeof(double), hipMemcpyDeviceToDevice));
+                RN_HIP(hipMemcpy(np, d_histParts, (size_t)4 * histCap * sizeof(double), hipMemcpyDeviceToDevice));
+            }
+            d_lam = nl; d_hist = nh; d_histParts = np; lamCap = cap; histCap = cap;   // old arrays are freed with the context
+        }
+        // (re)upload the table prefix that may have grown
+        RN_HIP(hipMemcpyAsync(d_lam, h_lam.data(), std::min((size_t)lamCap, h_lam.size()) * sizeof(double), hipMemcpyHostToDevice, stream));
+        RN_HIP(hipStreamSynchronize(stream));   // h_lam may be re-allocated by the next call
+        return RN_OK;
+    }
+    int apg_reset() override {
+        RN_HIP(hipSetDevice(device));
+        const size_t bytes = (size_t)ntot() * sizeof(T);
+        for (int i = 0; i < 2; i++) { RN_HIP(hipMemsetAsync(d_ybuf[i], 0, bytes, stream)); RN_HIP(hipMemsetAsync(d_wbuf[i], 0, bytes, stream)); }
+        RN_HIP(hipMemsetAsync(d_hx, 0, bytes, stream));
+        RN_HIP(hipMemsetAsync(d_z, 0, bytes, stream));
+        RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
+        p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
+        acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
+        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
+        return ensure_tables(0);
+    }
+    int apg_iterate(int n, double *primalInfs) override {
+        RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
+        RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
+        RN_HIP(hipSetDevice(device));
+        const int first = h_it;
+        if (int rc = ensure_tables(h_it + n)) return rc;
+        for (int k = 0; k < n; k++) {
+            if (!acc_ready) {   // re-derive w_t after manual buffer edits (SmpcController.cu:1514)
+                hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
+                acc_ready = true;
+            }
+            if (int rc = launch_sweep()) return rc;
+            DualArgs<T> a = dual_args();
+            const bool last = (k == n - 1);
+            const hipEvent_t *e2 = prof_begin(2);
+            if (last) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            prof_end(e2);
+            const hipEvent_t *e3 = prof_begin(3);
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
+            if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
+            prof_end(e3);
+            // rotate: y_t := y+_{t-1} (old upd), y+_t := buffer just written; w_{t+1} becomes the sweep input
+            std::swap(p_xi, p_upd);
+            p_acc_view = p_acc;
+            std::swap(p_acc, p_acc_other);
+            h_it++;
+        }
+        RN_HIP(hipGetLastError());
+        if (primalInfs && n > 0) {
+            RN_HIP(hipStreamSynchronize(stream));
+            RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        return RN_OK;
+    }
+    int hist_parts(int first, int n, double *out) override {
+        RN_CHECK(first >= 0 && n >= 0 && first + n <= h_it, RN_E_ARG, "rn_get_history_parts: range outside the iterations run");
+        RN_HIP(hipStreamSynchronize(stream));
+        RN_HIP(hipMemcpy(out, d_histParts + (size_t)4 * first, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost));
+        return RN_OK;
+    }
+    int control_action(const double *x0, const double *up, const double *dp, const double *dhat, const double *ahat, int maxIt,
+                       int project, double *u0) override {
+        RN_CHECK(u0, RN_E_ARG, "rn_control_action: null output");
+        if (int rc = update_state_control(x0, up, dp)) return rc;
+        if (int rc = eliminate(dhat, ahat)) return rc;
+        if (int rc = apg_reset()) return rc;
+        if (int rc = apg_iterate(maxIt, nullptr)) return rc;
+        T *src = d_u;
+        if (project) {  // SmpcController.cu:1647-1650: clamp with the (scaled) bounds of the root node
+            RN_HIP(hipMemcpyAsync(d_tmp, d_u, d.nu * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(k_clamp_vec<T>, dim3(1), dim3(128), 0, stream, d_tmp, d_lo + 2 * d.nx, d_hi + 2 * d.nx, d.nu);
+            src = d_tmp;
+        }
+        return download(u0, src, d.nu);
+    }
+
+    // ---- step-wise API -----------------------------------------------------------------------------------
+    int extrapolate(double lambda) override {
+        RN_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)lambda, ntot());
+        RN_HIP(hipGetLastError());
+        p_acc_view = p_acc; acc_ready = true;
+        return RN_OK;
+    }
+    int solve_step() override {
+        RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_solve_step before the factor step / affine terms");
+        RN_HIP(hipSetDevice(device));
+        p_acc_view = p_acc;
+        return launch_sweep();
+    }
+    int prox() override {
+        RN_CHECK(factored, RN_E_STATE, "rn_proximal_fun_g before the factor step");
+        RN_HIP(hipSetDevice(device));
+        DualArgs<T> a = dual_args();
+        a.w = p_acc_view;
+        hipLaunchKernelGGL(k_prox_clamp<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
+        hipLaunchKernelGGL(k_prox_soft<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
+    int residual() override {
+        RN_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_axpby<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, d_res, d_hx, d_z, (T)1, (T)-1, ntot());
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
+    int dual_update() override {
+        RN_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_axpby<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_upd, p_acc_view, d_res, (T)1, (T)stepSize, ntot());
+        RN_HIP(hipGetLastError());
+        acc_ready = false;
+        return RN_OK;
+    }
+    int primal_infeasibility(double *value) override {
+        RN_CHECK(value, RN_E_ARG, "rn_update_primal_infeasibility: null output");
+        RN_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_absmax<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, d_res, ntot(), d.nx, ny, d_partials);
+        RN_HIP(hipGetLastError());
+        std::vector<Partial> hp(eltBlocks);
+        RN_HIP(hipMemcpyAsync(hp.data(), d_partials, eltBlocks * sizeof(Partial), hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        double aX = -1, vX = 0, aP = -1, vP = 0; long long iX = 0x7fffffffffffffffLL, iP = iX;
+        for (auto &p : hp) {
+            if (p.absXi > aX || (p.absXi == aX && p.idxXi < iX)) { aX = p.absXi; vX = p.valXi; iX = p.idxXi; }
+            if (p.absPsi > aP || (p.absPsi == aP && p.idxPsi < iP)) { aP = p.absPsi; vP = p.valPsi; iP = p.idxPsi; }
+        }
+        *value = vX > vP ? vX : vP;
+        return RN_OK;
+    }
+    int prox_distances(double *dx, double *ds) override {
+        IterState st;
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipMemcpyAsync(&st, d_state, sizeof st, hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        if (dx) *dx = st.distX;
+        if (ds) *ds = st.distS;
+        return RN_OK;
+    }
+
+    // ---- raw access --------------------------------------------------------------------------------------
+    // maps a buffer id to (y-layout base, offset, dim) or to a plain array
+    bool ymap(int id, T **base, int *off, int *dim) {
+        const int nx = d.nx, nu = d.nu;
+        switch (id) {
+            case RN_BUF_XI: *base = p_xi; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_PSI: *base = p_xi; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_ACC_XI: *base = p_acc_view; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_ACC_PSI: *base = p_acc_view; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_UPD_XI: *base = p_upd; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_UPD_PSI: *base = p_upd; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_PRIMAL_XI: *base = d_hx; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_PRIMAL_PSI: *base = d_hx; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_DUAL_XI: *base = d_z; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_DUAL_PSI: *base = d_z; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_RES_XI: *base = d_res; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_RES_PSI: *base = d_res; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_XMIN: *base = d_lo; *off = 0; *dim = nx; return true;
+            case RN_BUF_XMAX: *base = d_hi; *off = 0; *dim = nx; return true;
+            case RN_BUF_XS: *base = d_lo; *off = nx; *dim = nx; return true;
+            case RN_BUF_UMIN: *base = d_lo; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_UMAX: *base = d_hi; *off = 2 * nx; *dim = nu; return true;
+            default: return false;
+        }
+    }
+    T *plain(int id, size_t *n) {
+        const size_t N_ = d.nodes;
+        switch (id) {
+            case RN_BUF_X: *n = N_ * d.nx; return d_x;
+            case RN_BUF_U: *n = N_ * d.nu; return d_u;
+            case RN_BUF_V: *n = N_ * d.nv; return d_v;
+            case RN_BUF_UHAT: *n = N_ * d.nu; return d_uhat;
+            case RN_BUF_E: *n = N_ * d.nx; return d_e;
+            case RN_BUF_BETA: *n = N_ * d.nv; return d_beta;
+            case RN_BUF_ALPHA: *n = N_ * d.nu; return d_alpha;
+            default: *n = 0; return nullptr;
+        }
+    }
+    size_t buffer_size(int id) const override {
+        T *b; int off, dim; size_t n;
+        Ctx *self = const_cast<Ctx *>(this);
+        if (self->ymap(id, &b, &off, &dim)) return (size_t)d.nodes * dim;
+        self->plain(id, &n);
+        return n;
+    }
+    int get(int id, double *host, size_t n) override {
+        RN_CHECK(host, RN_E_ARG, "rn_get: null host pointer");
+        RN_HIP(hipSetDevice(device));
+        T *b; int off, dim; size_t cnt;
+        if (ymap(id, &b, &off, &dim)) {
+            RN_CHECK(n == (size_t)d.nodes * dim, RN_E_ARG, "rn_get: size mismatch");
+            hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b, d_tmp, ny, off, dim, (long long)d.nodes, 0);
+            RN_HIP(hipGetLastError());
+            return download(host, d_tmp, n);
+        }
+        T *p = plain(id, &cnt);
+        RN_CHECK(p != nullptr, RN_E_ARG, "rn_get: unknown buffer id");
+        RN_CHECK(n == cnt, RN_E_ARG, "rn_get: size mismatch");
+        return download(host, p, n);
+    }
+    int set(int id, const double *host, size_t n) override {
+        RN_CHECK(host, RN_E_ARG, "rn_set: null host pointer");
+        RN_HIP(hipSetDevice(device));
+        T *b; int off, dim; size_t cnt;
+        if (ymap(id, &b, &off, &dim)) {
+            RN_CHECK(id < RN_BUF_XMIN, RN_E_ARG, "rn_set: the scaled bounds are read-only");
+            RN_CHECK(n == (size_t)d.nodes * dim, RN_E_ARG, "rn_set: size mismatch");
+            if (int rc = upload(d_tmp, host, n)) return rc;
+            hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b, d_tmp, ny, off, dim, (long long)d.nodes, 1);
+            RN_HIP(hipGetLastError());
+            RN_HIP(hipStreamSynchronize(stream));
+            if (id == RN_BUF_ACC_XI || id == RN_BUF_ACC_PSI) {   // the view becomes the sweep input
+                if (p_acc_view != p_acc) std::swap(p_acc, p_acc_other);
+                acc_ready = true;
+            } else if (id == RN_BUF_XI || id == RN_BUF_PSI || id == RN_BUF_UPD_XI || id == RN_BUF_UPD_PSI) {
+                acc_ready = false;
+            }
+            return RN_OK;
+        }
+        T *p = plain(id, &cnt);
+        RN_CHECK(p != nullptr, RN_E_ARG, "rn_set: unknown buffer id");
+        RN_CHECK(n == cnt, RN_E_ARG, "rn_set: size mismatch");
+        if (id == RN_BUF_UHAT || id == RN_BUF_E || id == RN_BUF_BETA) affine_ready = true;
+        return upload(p, host, n);
+    }
+    int get_operator(int op, int node, double *host, size_t n) override {
+        RN_CHECK(factored, RN_E_STATE, "rn_get_operator before rn_factor_step");
+        RN_CHECK(host && node >= 0 && node < d.nodes, RN_E_ARG, "rn_get_operator: bad node");
+        const int nx = d.nx, nu = d.nu, nv = d.nv;
+        const double p = h_prob[node];
+        if (op == RN_OP_OMEGA) { RN_CHECK(n == (size_t)nv * nv, RN_E_ARG, "rn_get_operator: size"); for (size_t i = 0; i < n; i++) host[i] = h_Rinv[i] / p; return RN_OK; }
+        if (op == RN_OP_G) { RN_CHECK(n == (size_t)nv * nx, RN_E_ARG, "rn_get_operator: size"); for (size_t i = 0; i < n; i++) host[i] = h_Bbt[i]; return RN_OK; }
+        if (op == RN_OP_THETA) {
+            RN_CHECK(n == (size_t)nv * nx, RN_E_ARG, "rn_get_operator: size");
+            std::vector<double> t((size_t)nv * nx);
+            h_gemm(false, false, nv, nx, nv, h_Rinv.data(), nv, h_Bbt.data(), nv, t.data());
+            for (size_t i = 0; i < n; i++) host[i] = -0.5 * t[i] / p;
+            return RN_OK;
+        }
+        RN_CHECK(op == RN_OP_PHI || op == RN_OP_PSI || op == RN_OP_D || op == RN_OP_F, RN_E_ARG, "rn_get_operator: unknown operator id");
+        const bool xiCols = (op == RN_OP_PHI || op == RN_OP_D), top = (op == RN_OP_PHI || op == RN_OP_PSI);
+        const int cols = xiCols ? 2 * nx : nu, c0 = xiCols ? 0 : 2 * nx, r0 = top ? 0 : nv;
+        RN_CHECK(n == (size_t)nv * cols, RN_E_ARG, "rn_get_operator: size");
+        RN_HIP(hipSetDevice(device));
+        std::vector<double> blk((size_t)ny * LD);
+        if (int rc = download(blk.data(), d_A + (size_t)node * ny * LD, (size_t)ny * LD)) return rc;
+        for (int c = 0; c < cols; c++) for (int r = 0; r < nv; r++) host[r + (size_t)c * nv] = blk[(size_t)(c0 + c) * LD + r0 + r];
+        return RN_OK;
+    }
+
+    // ---- multi-GPU ---------------------------------------------------------------------------------------
+    int comm_init(int rk, int nr, const void *id) override {
+        RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
+        rank = rk; nranks = nr;
+        if (nr == 1) return RN_OK;
+        RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
+        RN_HIP(hipSetDevice(device));
+        typedef int (*init_t)(void **, int, UniqueId128, int);
+        init_t f = (init_t)dlsym(g_nccl.h, "ncclCommInitRank");
+        UniqueId128 u; std::memcpy(u.b, id, 128);
+        const int rc = f(&comm, nr, u, rk);
+        RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+        return RN_OK;
+    }
+    int set_cut_stage(int c) override {
+        RN_CHECK(c == -1 || (c >= 1 && c < d.N), RN_E_ARG, "rn_set_cut_stage: stage out of range");
+        cutStage = c;
+        return RN_OK;
+    }
+};
+
+}  // namespace rn
+
+struct rn_ctx { rn::CtxBase *impl; };
+static std::string g_create_error;
+
+#define RN_GUARD(ctx) if (!(ctx) || !(ctx)->impl) return RN_E_ARG
+
+extern "C" {
+
+int rn_create(const rn_dims *dims, const rn_tree *tree, int precision, int device, rn_ctx **out) {
+    if (!dims || !tree || !out) return RN_E_ARG;
+    if (!tree->stages || !tree->nodesPerStage || !tree->nodesPerStageCumul || !tree->ancestor || !tree->probNode) return RN_E_ARG;
+    *out = nullptr;
+    int rc;
+    rn::CtxBase *impl;
+    if (precision == RN_F64) { auto *c = new rn::Ctx<double>(); impl = c; rc = c->init(dims, tree, device); }
+    else if (precision == RN_F32) { auto *c = new rn::Ctx<float>(); impl = c; rc = c->init(dims, tree, device); }
+    else return RN_E_ARG;
+    if (rc != RN_OK) { g_create_error = impl->err; delete impl; return rc; }
+    *out = new rn_ctx{impl};
+    return RN_OK;
+}
+int rn_destroy(rn_ctx *ctx) { RN_GUARD(ctx); delete ctx->impl; delete ctx; return RN_OK; }
+const char *rn_last_error(const rn_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->err.c_str() : g_create_error.c_str(); }
+int rn_synchronize(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->synchronize(); }
+int rn_factor_step(rn_ctx *ctx, const rn_system *sys) { RN_GUARD(ctx); return ctx->impl->factor_step(sys); }
+int rn_set_tree_errors(rn_ctx *ctx, const double *ed, const double *ep) { RN_GUARD(ctx); return ctx->impl->set_tree_errors(ed, ep); }
+int rn_set_uncertainty(rn_ctx *ctx, int dflag, int pflag, double w) { RN_GUARD(ctx); return ctx->impl->set_uncertainty(dflag, pflag, w); }
+int rn_update_state_control(rn_ctx *ctx, const double *x, const double *u, const double *dm) { RN_GUARD(ctx); return ctx->impl->update_state_control(x, u, dm); }
+int rn_eliminate_input_disturbance_coupling(rn_ctx *ctx, const double *dh, const double *ah) { RN_GUARD(ctx); return ctx->impl->eliminate(dh, ah); }
+int rn_set_parameters(rn_ctx *ctx, double s, double px, double pxs) { RN_GUARD(ctx); return ctx->impl->set_parameters(s, px, pxs); }
+int rn_apg_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->apg_reset(); }
+int rn_apg_iterate(rn_ctx *ctx, int n, double *h) { RN_GUARD(ctx); return ctx->impl->apg_iterate(n, h); }
+int rn_algorithm_apg(rn_ctx *ctx, int n, double *h) { RN_GUARD(ctx); if (int rc = ctx->impl->apg_reset()) return rc; return ctx->impl->apg_iterate(n, h); }
+int rn_control_action(rn_ctx *ctx, const double *x, const double *u, const double *dm, const double *dh, const double *ah, int maxIt,
+                      int project, double *u0) { RN_GUARD(ctx); return ctx->impl->control_action(x, u, dm, dh, ah, maxIt, project, u0); }
+int rn_dual_extrapolation_step(rn_ctx *ctx, double l) { RN_GUARD(ctx); return ctx->impl->extrapolate(l); }
+int rn_solve_step(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->solve_step(); }
+int rn_proximal_fun_g(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->prox(); }
+int rn_compute_fixed_point_residual(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->residual(); }
+int rn_dual_update(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->dual_update(); }
+int rn_update_primal_infeasibility(rn_ctx *ctx, double *v) { RN_GUARD(ctx); return ctx->impl->primal_infeasibility(v); }
+int rn_get_prox_distances(rn_ctx *ctx, double *a, double *b) { RN_GUARD(ctx); return ctx->impl->prox_distances(a, b); }
+size_t rn_buffer_size(const rn_ctx *ctx, int id) { return (ctx && ctx->impl) ? ctx->impl->buffer_size(id) : 0; }
+int rn_get(rn_ctx *ctx, int id, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->get(id, h, n); }
+int rn_set(rn_ctx *ctx, int id, const double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->set(id, h, n); }
+int rn_get_operator(rn_ctx *ctx, int op, int node, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->get_operator(op, node, h, n); }
+int rn_profile_enable(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->profile_enable(on); }
+int rn_profile_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->profile_reset(); }
+int rn_profile_read(rn_ctx *ctx, double ms[4], long n[4]) { RN_GUARD(ctx); return ctx->impl->profile_read(ms, n); }
+int rn_algorithmic_bytes(const rn_ctx *ctx, double *b, double *dl) { RN_GUARD(ctx); return ctx->impl->algorithmic_bytes(b, dl); }
+void *rn_stream(rn_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->stream_handle() : nullptr; }
+int rn_comm_unique_id(void *id128) {
+    if (!id128) return RN_E_ARG;
+    if (!rn::g_nccl.load()) return RN_E_COMM;
+    return rn::g_nccl.GetUniqueId(id128) == 0 ? RN_OK : RN_E_COMM;
+}
+int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128) { RN_GUARD(ctx); return ctx->impl->comm_init(rank, nranks, id128); }
+int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
+int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
+
+}  // extern "C"

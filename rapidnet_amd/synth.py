@@ -1,0 +1,263 @@
+"""Deterministic synthetic DWN / scenario-tree / controller-config generator.
+
+The reference ships only the 3-tank fixture; its Barcelona network.json and large trees are missing
+(/root/reference/.MISSING_LARGE_BLOBS).  This module synthesises inputs of the same *shape* and in the
+same JSON schema the reference's loaders read (DwnNetwork.cuh:23-37, ScenarioTree.cuh:23-40,
+SmpcConfiguration.cuh:24-47, Forecaster.cu:94,108): scalars are 1-element lists, matrices are
+column-major flat lists, tree indices are 1-based (`ancestor`, `children`, `leaves`), `nodesPerStage`
+has N+1 entries and `nodesPerStageCumul` N+2.
+
+Seed convention: 20260101 + config index.
+"""
+import json
+import os
+
+import numpy as np
+
+# name -> (config index, nx, nu, nd, ne, N, branching)
+CONFIGS = {
+    "toy": (0, 3, 6, 4, 2, 5, []),                       # BASELINE.json configs[0]: N=5, 1 scenario
+    "barcelona31": (1, 63, 114, 88, 17, 24, [31]),       # configs[1]: K=31, nodes=714
+    "barcelona493": (2, 63, 114, 88, 17, 24, [17, 29]),  # configs[2]/[3]: K=493, nodes=10864 (headline)
+    "wide4096": (4, 200, 360, 280, 54, 24, [16, 16, 16]),  # configs[4]: K=4096, nodes=86289
+    # small shapes for parity tests
+    "tiny": (10, 3, 6, 4, 2, 6, [2, 2]),
+    "small": (11, 5, 9, 6, 3, 8, [3, 2, 2]),
+    "odd": (12, 7, 13, 5, 4, 7, [2, 3]),
+    "medium": (13, 21, 38, 30, 6, 12, [4, 5]),
+}
+
+
+def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
+    """Stage-contiguous BFS tree that branches in the leading stages, then chains to N.
+
+    branching[k] = children per node of stage k (uniform per stage).  Returns the tree dict in the
+    reference schema.  The only shape the reference's operator aliasing supports (Engine.cu:210-221).
+    """
+    per_stage = [1]
+    for b in branching:
+        per_stage.append(per_stage[-1] * b)
+    while len(per_stage) < N:
+        per_stage.append(per_stage[-1])
+    per_stage = per_stage[:N]
+    assert len(branching) < N
+    cumul = np.concatenate([[0], np.cumsum(per_stage)]).astype(int)
+    nodes = int(cumul[-1])
+    K = per_stage[-1]
+    stages = np.concatenate([np.full(n, k) for k, n in enumerate(per_stage)]).astype(int)
+    ancestor = np.zeros(nodes, int)  # 1-based, root = 0
+    prob = np.ones(nodes)
+    n_children = []
+    children = []
+    for k in range(N - 1):
+        b = branching[k] if k < len(branching) else 1
+        for j in range(per_stage[k]):
+            i = cumul[k] + j
+            first = cumul[k + 1] + j * b
+            w = rng.dirichlet(np.ones(b) * 4.0) if b > 1 else np.ones(1)
+            for c in range(b):
+                ancestor[first + c] = i + 1
+                prob[first + c] = prob[i] * w[c]
+                children.append(first + c + 1)
+            n_children.append(b)
+    n_nonleaf = nodes - K
+    n_children_cumul = np.zeros(nodes, int)
+    n_children_cumul[:n_nonleaf] = np.cumsum(n_children)
+    n_children_cumul[n_nonleaf:] = n_children_cumul[n_nonleaf - 1] if n_nonleaf > 0 else 0
+    leaves = np.arange(cumul[N - 1], nodes) + 1
+    if dhat is None:
+        dhat = np.ones((N, nd))
+    if ahat is None:
+        ahat = np.ones((N, nu))
+    err_d = err_scale * rng.standard_normal((nodes, nd)) * dhat[stages]
+    err_a = err_scale * rng.standard_normal((nodes, nu)) * ahat[stages]
+    err_d[0] = 0.0
+    err_a[0] = 0.0
+    return {
+        "N": [N], "K": [K], "dimDemand": [nd], "dimPrice": [nu], "nodes": [nodes],
+        "nChildrenTot": [nodes - 1], "nNonLeafNodes": [n_nonleaf],
+        "stages": stages.tolist(),
+        "nodesPerStage": list(per_stage) + [0],
+        "nodesPerStageCumul": cumul.tolist() + [nodes],
+        "leaves": leaves.tolist(), "children": children, "ancestor": ancestor.tolist(),
+        "nChildren": n_children, "nChildrenCumul": n_children_cumul.tolist(),
+        "probNode": prob.tolist(),
+        "errorDemandNode": err_d.ravel().tolist(), "errorPriceNode": err_a.ravel().tolist(),
+    }
+
+
+def make_network(nx, nu, nd, ne, rng):
+    """Sparse incidence-style DWN: x+ = x + B u + Gd d, 0 = E u + Ed d (DwnNetwork.cuh:41-57)."""
+    B = np.zeros((nx, nu))
+    for j in range(nu):
+        B[rng.integers(nx), j] = 1.0           # every actuator fills one tank ...
+        if rng.random() < 0.35:
+            t = rng.integers(nx)
+            if B[t, j] == 0:
+                B[t, j] = -1.0                 # ... and some drain another
+    for i in range(nx):                        # no isolated tank
+        if not B[i].any():
+            B[i, rng.integers(nu)] = 1.0
+    Gd = np.zeros((nx, nd))
+    for j in range(nd):
+        Gd[rng.integers(nx), j] = -1.0
+    E = np.zeros((ne, nu))
+    cols = rng.permutation(nu)[:ne]
+    for i in range(ne):                        # dedicated pivot column per mixing node => full row rank
+        E[i, cols[i]] = 1.0
+        for j in rng.permutation(nu)[:3]:
+            if j not in cols:
+                E[i, j] = rng.choice([-1.0, 1.0])
+    Ed = np.zeros((ne, nd))
+    for i in range(ne):
+        Ed[i, rng.integers(nd)] = -1.0
+    xmax = rng.uniform(500, 5000, nx).round(0)
+    xsafe = (rng.uniform(0.05, 0.15, nx) * xmax).round(1)
+    umax = rng.uniform(100, 2000, nu).round(0)
+    alpha1 = np.where(rng.random(nu) < 0.3, rng.uniform(0.02, 0.15, nu), 0.0).round(4)
+    col = lambda M: M.ravel(order="F").tolist()
+    return {
+        "nx": [nx], "nu": [nu], "ne": [ne], "nd": [nd],
+        "matA": col(np.eye(nx)), "matB": col(B), "matGd": col(Gd), "matE": col(E), "matEd": col(Ed),
+        "vecXmin": [0.0] * nx, "vecXmax": xmax.tolist(), "vecXsafe": xsafe.tolist(),
+        "vecUmin": [0.0] * nu, "vecUmax": umax.tolist(), "costAlpha1": alpha1.tolist(),
+    }
+
+
+def null_space_and_particular(E, Ed):
+    """L = null(E) taken as the trailing left singular vectors of E' and Lhat = -pinv(E) Ed, exactly the
+    construction of Engine::calculateMatLandMatLhat (Engine.cu:466-669) but on the host in fp64."""
+    ne, nu = E.shape
+    U, S, Vt = np.linalg.svd(E.T, full_matrices=True)  # E' = U S V'
+    L = U[:, ne:]
+    Sinv = np.where(np.abs(S) > 0, 1.0 / S, 0.0)
+    pinvE = U[:, :ne] @ (Sinv[:, None] * Vt)
+    return L, -pinvE @ Ed
+
+
+class _Structured:
+    """numpy evaluation of the *linear part* of the dual-gradient sweep (beta = uhat = e = 0, x0 = 0), used
+    only to estimate the Lipschitz constant for the generated stepSize.  Uses the algebraic structure of the
+    reference's operators: every per-node block is a shared matrix times a per-stage
+    diagonal times a power of p_i."""
+
+    def __init__(self, network, tree, config):
+        g = lambda d, k: int(d[k][0])
+        self.nx, self.nu, self.nd = g(network, "nx"), g(network, "nu"), g(network, "nd")
+        self.nv, self.N = g(config, "nv"), g(tree, "N")
+        nx, nu, nv, N = self.nx, self.nu, self.nv, self.N
+        self.B = np.array(network["matB"], float).reshape(nx, nu, order="F")
+        self.L = np.array(config["matL"], float).reshape(nu, nv, order="F")
+        W = np.array(config["costW"], float).reshape(nu, nu, order="F")
+        self.Rinv = np.linalg.inv(self.L.T @ W @ self.L)
+        self.Bbar_t = self.L.T @ self.B.T
+        self.diag = np.array(config["matDiagPrecnd"], float).reshape(N, 2 * nx + nu)
+        self.cum = np.array(tree["nodesPerStageCumul"], int)
+        self.nps = np.array(tree["nodesPerStage"], int)
+        self.anc = np.array(tree["ancestor"], int) - 1
+        self.p = np.array(tree["probNode"], float)
+        self.stage = np.array(tree["stages"], int)
+        self.nodes = g(tree, "nodes")
+
+    def apply(self, xi, psi):
+        nx, nu, nv, N = self.nx, self.nu, self.nv, self.N
+        sp = np.sqrt(self.p)[:, None]
+        du, dx, dxs = self.diag[:, :nu], self.diag[:, nu:nu + nx], self.diag[:, nu + nx:]
+        a = sp * (dx[self.stage] * xi[:, :nx] + dxs[self.stage] * xi[:, nx:])
+        b = sp * du[self.stage] * psi
+        c = a @ self.Bbar_t.T + b @ self.L
+        r = np.zeros((self.nodes, nv))
+        q = np.zeros((self.nodes, nx))
+        v = np.zeros((self.nodes, nv))
+        for k in range(N - 1, -1, -1):
+            sl = slice(self.cum[k], self.cum[k + 1])
+            r[sl] += c[sl]
+            q[sl] += a[sl]
+            v[sl] = (-0.5 / self.p[sl, None]) * (r[sl] @ self.Rinv.T)
+            if k > 0:
+                np.add.at(r, self.anc[sl], r[sl] + q[sl] @ self.Bbar_t.T)
+                np.add.at(q, self.anc[sl], q[sl])
+        w = np.zeros((self.nodes, nu))
+        x = np.zeros((self.nodes, nx))
+        for k in range(N):
+            sl = slice(self.cum[k], self.cum[k + 1])
+            w[sl] = v[sl] @ self.L.T
+            x[sl] = w[sl] @ self.B.T
+            if k > 0:
+                w[sl] += w[self.anc[sl]]
+                x[sl] = x[self.anc[sl]] + w[sl] @ self.B.T
+        return np.hstack([sp * dx[self.stage] * x, sp * dxs[self.stage] * x]), sp * du[self.stage] * w
+
+
+def lipschitz_estimate(network, tree, config, iters=40, seed=0):
+    op = _Structured(network, tree, config)
+    rng = np.random.default_rng(seed)
+    xi = rng.standard_normal((op.nodes, 2 * op.nx))
+    psi = rng.standard_normal((op.nodes, op.nu))
+    lam = 1.0
+    for _ in range(iters):
+        nrm = np.sqrt((xi ** 2).sum() + (psi ** 2).sum())
+        xi, psi = xi / nrm, psi / nrm
+        xi, psi = op.apply(xi, psi)
+        lam = np.sqrt((xi ** 2).sum() + (psi ** 2).sum())
+    return float(lam)
+
+
+def make_problem(name, max_iterations=500, sim_horizon=2, penalty_x=1e6, penalty_xs=1e4, step_size=None):
+    """Returns {"network","tree","config","forecast"} dicts (reference JSON schema) for a named config."""
+    idx, nx, nu, nd, ne, N, branching = CONFIGS[name]
+    rng = np.random.default_rng(20260101 + idx)
+    network = make_network(nx, nu, nd, ne, rng)
+    nv = nu - ne
+    hours = np.arange(N + sim_horizon)
+    base_d = rng.uniform(5, 80, nd)
+    base_a = rng.uniform(0.05, 0.15, nu)
+    dhat_all = base_d[None, :] * (1 + 0.3 * np.sin(2 * np.pi * (hours[:, None] + rng.uniform(0, 24, nd)[None, :]) / 24))
+    ahat_all = base_a[None, :] * (1 + 0.5 * np.sin(2 * np.pi * (hours[:, None] + 6) / 24))
+    tree = make_tree(N, branching, rng, nd, nu, dhat=dhat_all[:N], ahat=ahat_all[:N])
+    E = np.array(network["matE"], float).reshape(ne, nu, order="F")
+    Ed = np.array(network["matEd"], float).reshape(ne, nd, order="F")
+    L, Lhat = null_space_and_particular(E, Ed)
+    W = np.diag(rng.uniform(0.5, 2.0, nu))
+    diag = rng.uniform(0.8, 2.2, (N, 2 * nx + nu))
+    xmax = np.array(network["vecXmax"])
+    umax = np.array(network["vecUmax"])
+    col = lambda M: np.asarray(M).ravel(order="F").tolist()
+    config = {
+        "nx": [nx], "nu": [nu], "ne": [ne], "nv": [nv], "nd": [nd], "N": [N],
+        "matL": col(L), "matLhat": col(Lhat), "matDiagPrecnd": diag.ravel().tolist(), "costW": col(W),
+        "currentX": (0.5 * xmax).tolist(), "prevDemand": dhat_all[0].tolist(),
+        "prevU": (rng.uniform(0.1, 0.4, nu) * umax).tolist(),
+        "stepSize": [1e-4], "maxIterations": [max_iterations],
+        "penaltyStateX": [penalty_x], "penaltySafetyX": [penalty_xs],
+        "pathToNetwork": "network.json", "pathToScenarioTree": "scenarioTree.json",
+        "pathToForecaster": "forecastor.json", "algorithmName": "proximalAlgorithm", "lbfgsBufferSize": [5],
+    }
+    if step_size is None:
+        step_size = 0.95 / lipschitz_estimate(network, tree, config)
+    config["stepSize"] = [float(step_size)]
+    forecast = {"N": [N], "simHorizon": [sim_horizon], "dimDemand": [nd], "dimPrices": [nu]}
+    for t in range(sim_horizon):  # Forecaster reads members 4+2t / 5+2t in file order (Forecaster.cu:94,108)
+        forecast["timeIdDemand%d" % t] = dhat_all[t:t + N].ravel().tolist()
+        forecast["timeIdPrice%d" % t] = ahat_all[t:t + N].ravel().tolist()
+    return {"network": network, "tree": tree, "config": config, "forecast": forecast}
+
+
+def forecast_at(forecast, sim_time):
+    """Forecaster::predictDemand/predictPrices member-order rule (Forecaster.cu:93-119)."""
+    keys = list(forecast.keys())
+    return (np.asarray(forecast[keys[4 + 2 * sim_time]], float), np.asarray(forecast[keys[5 + 2 * sim_time]], float))
+
+
+def write_problem(problem, directory):
+    """Write the four JSON files the reference's loaders read; config paths are made absolute."""
+    os.makedirs(directory, exist_ok=True)
+    cfg = dict(problem["config"])
+    cfg["pathToNetwork"] = os.path.join(directory, "network.json")
+    cfg["pathToScenarioTree"] = os.path.join(directory, "scenarioTree.json")
+    cfg["pathToForecaster"] = os.path.join(directory, "forecastor.json")
+    for fname, d in (("network.json", problem["network"]), ("scenarioTree.json", problem["tree"]),
+                     ("forecastor.json", problem["forecast"]), ("controllerConfig.json", cfg)):
+        with open(os.path.join(directory, fname), "w") as f:
+            json.dump(d, f)
+    return os.path.join(directory, "controllerConfig.json")
