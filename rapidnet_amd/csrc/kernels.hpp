@@ -17,8 +17,6 @@
 namespace rn {
 
 constexpr int RPL = 4;          // rows of A per lane (16 B fp32 / 32 B fp64 per lane per column)
-constexpr int BWD_THREADS = 256;
-constexpr int BWD_WAVES = BWD_THREADS / 64;
 constexpr int ELT_THREADS = 256;
 constexpr int ELT_MAX_BLOCKS = 1024;
 
@@ -39,15 +37,22 @@ struct TreeDev {
 template <typename T>
 struct SweepArgs {
     TreeDev<T> tr;
-    int nx, nu, nv, ny, LD;
+    int nx, nu, nv, ny, LD, N, nodes;
+    int chainStage;   // c*: first stage from which the tree is K parallel chains (no branching at or after it)
+    int K;            // nodes per stage in the chain region
     const T *A;
-    const T *Rinv, *Bbt, *L, *B;
+    const T *RT;      // [Rinv | Rinv*Bbt]  nv x (nv+nx)
+    const T *L, *B;   // nu x nv, nx x nu
     const T *beta, *uhat, *e;
     const T *curX, *prevU, *prevUhat;
     const T *w;       // accelerated dual the sweep is evaluated at, [node][ny]
-    T *v, *rt, *q;    // rt_i = r_i + Bbt q_i (what the parent consumes), q_i
+    T *my;            // [node][2nv]  m1_i = Phi xi + Psi psi ; m2_i = D xi + Ftil psi
+    T *qa;            // [node][nx]   a_i = F_i' xi_i
+    T *sk;            // [node][nv+nx] s_i = beta_i + sum_children rho_c ; kappa_i
+    T *rkq;           // [node][nv+2nx] rho_i, kappa_i, q_i (kept for chain tops and crown nodes)
+    T *v, *lv, *z;    // [node][nv], [node][nu] L v_i, [node][nx] e_i + B u_i
     T *x, *u, *hx;
-    const T *cutSums; // multi-GPU: [cutParents][nv+nx] all-reduced children sums, or nullptr
+    const T *cutSums; // multi-GPU: [cutParents][nv+2nx] all-reduced children sums, or nullptr
     int cutStage;     // stage whose parents take cutSums instead of summing their local children (-1: none)
 };
 
@@ -107,159 +112,427 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Backward sweep, one stage (SmpcController.cu:593-673 + solveSumChildren Utilities.cu:168-201), one
-// workgroup per node i of the stage:
-//   q_i  = F_i' xi_i + sum_children q_c                                  (:651/656, :665)
-//   s_i  = beta_i + sum_children rt_c        ( = sigma_i + Gtil q_in,   :599, :644, :667 )
-//   [m1; m2] = A_i y_i                       ( = Phi xi + Psi psi ; D xi + Ftil psi,  :617-638 )
-//   v_i  = -1/(2 p_i) Rinv s_i + m1          ( = -1/2 Omega sigma + Theta q_in + ...,  :604-623 )
-//   rt_i = s_i + m2 + Bbt q_i                ( r_i of the reference plus the Gtil q term its parent adds )
-// HBM traffic per node: LD*ny*sizeof(T) for A_i (read once, non-temporal) + O(ny + nv + nx) vectors.
+// The dominant kernel.  Batched per-node mat-vec  [m1_i; m2_i] = A_i y_i  for ALL nodes of the tree in one
+// launch (SmpcController.cu:617-638 issues these as 4 cublasSgemmBatched per stage inside the sequential sweep;
+// they do not depend on the recursion, only the vector sums do -- see k_up_*).  One workgroup per node,
+// STREAM_THREADS/64 waves; wave w owns column phase cp = w / nRB of row block rb = w % nRB; lane l owns rows
+// rb*256 + 4l .. 4l+3 of every column of its phase (16 B fp32 / 32 B fp64 per lane per column, the whole wave
+// reads one contiguous LD*sizeof(T) column).  Loads are non-temporal (A is read once per iteration and is far
+// larger than the 256 MiB Infinity Cache) and double-buffered in groups of G columns so that ~2G columns per
+// wave are always in flight.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
+// HBM bytes per node: LD*ny*sizeof(T) + (ny + 2nv + nx)*sizeof(T).
+constexpr int STREAM_THREADS = 256;
+constexpr int STREAM_WAVES = STREAM_THREADS / 64;
+constexpr int STREAM_G = 5;   // columns per pipeline stage
+
 template <typename T>
-__global__ void __launch_bounds__(BWD_THREADS) k_backward_stage(SweepArgs<T> a, int stage) {
+__global__ void __launch_bounds__(STREAM_THREADS, 3) k_stream_gemv(SweepArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny
-    T *sh_s = sh_y + ((a.ny + 3) & ~3);                 // nv
-    T *sh_q = sh_s + ((a.nv + 3) & ~3);                 // nx
-    T *sh_g = sh_q + ((a.nx + 3) & ~3);                 // nv   (Rinv s, then reused for Bbt q)
-    T *sh_red = sh_g + ((a.nv + 3) & ~3);               // max(BWD_WAVES*LDp, BWD_THREADS) scratch
+    T *sh_red = sh_y + ((a.ny + 3) & ~3);               // nCP * LDp
     const int tid = threadIdx.x;
-    const int node = a.tr.stageCum[stage] + blockIdx.x;
-    const int nx = a.nx, nu = a.nu, nv = a.nv, ny = a.ny, LD = a.LD;
-    const T *dy = a.tr.dy + (size_t)stage * ny;
-    const T sp = a.tr.sqrtp[node];
-    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
-    const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
-
-    for (int c = tid; c < ny; c += BWD_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
-    __syncthreads();
-    for (int t = tid; t < nx; t += BWD_THREADS) {
-        T qv = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
-        if (presummed) qv += a.cutSums[(size_t)blockIdx.x * (nv + nx) + nv + t];
-        else for (int c = 0; c < nc; c++) qv += a.q[(size_t)(c0 + c) * nx + t];
-        sh_q[t] = qv;
-        a.q[(size_t)node * nx + t] = qv;
-    }
-    for (int t = tid; t < nv; t += BWD_THREADS) {
-        T s = a.beta[(size_t)node * nv + t];
-        if (presummed) s += a.cutSums[(size_t)blockIdx.x * (nv + nx) + t];
-        else for (int c = 0; c < nc; c++) s += a.rt[(size_t)(c0 + c) * nv + t];
-        sh_s[t] = s;
-    }
-    __syncthreads();
-
-    // ---- stream A_i: wave w takes (row block rb, column phase cp); lane l owns rows rb*256 + 4l .. +3
+    const int node = blockIdx.x;
+    const int nx = a.nx, nv = a.nv, ny = a.ny, LD = a.LD;
     const int wave = tid >> 6, lane = tid & 63;
-    const int nRB = (LD + 64 * RPL - 1) / (64 * RPL);     // row blocks of 256 rows
-    const int nCP = BWD_WAVES / nRB > 0 ? BWD_WAVES / nRB : 1;
-    for (int rb0 = 0; rb0 < nRB; rb0 += BWD_WAVES) {       // nRB > BWD_WAVES only for very large nv
-        const int rb = rb0 + (wave % (nRB < BWD_WAVES ? nRB : BWD_WAVES));
-        const int cp = wave / (nRB < BWD_WAVES ? nRB : BWD_WAVES);
+    const int nRB = (LD + 64 * RPL - 1) / (64 * RPL);                       // row blocks of 256 rows
+    const int nRBw = nRB < STREAM_WAVES ? nRB : STREAM_WAVES;
+    const int nCP = STREAM_WAVES / nRBw;                                     // column phases
+    const int LDp = (LD + 3) & ~3;
+    for (int c = tid; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
+    __syncthreads();
+    {   // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
+        const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+        const T sp = a.tr.sqrtp[node];
+        for (int t = tid; t < nx; t += STREAM_THREADS) a.qa[(size_t)node * nx + t] = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
+    }
+    for (int rb0 = 0; rb0 < nRB; rb0 += nRBw) {
+        const int rb = rb0 + wave % nRBw, cp = wave / nRBw;
         const int row = rb * 64 * RPL + lane * RPL;
+        const bool active = rb < nRB && cp < nCP && row < LD;
         T part[RPL] = {0, 0, 0, 0};
-        if (rb < nRB && cp < nCP && row < LD) {
+        if (active) {
             const T *Ab = a.A + (size_t)node * ny * LD + row;
-            int c = cp;
-            for (; c + 7 * nCP < ny; c += 8 * nCP) {     // 8 columns in flight per lane
-                T m[8][RPL];
-#pragma unroll
-                for (int k = 0; k < 8; k++) load_rows<T>(Ab + (size_t)(c + k * nCP) * LD, m[k]);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const T yc = sh_y[c + k * nCP];
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) part[r] += m[k][r] * yc;
+            const int ncol = (ny - cp + nCP - 1) / nCP;            // columns of this phase: cp, cp+nCP, ...
+            const int nG = ncol / STREAM_G;
+            T bufA[STREAM_G][RPL], bufB[STREAM_G][RPL];
+#define RN_LOADG(buf, g_)                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) load_rows<T>(Ab + (size_t)(cp + ((g_) * STREAM_G + k) * nCP) * LD, buf[k]);
+#define RN_USEG(buf, g_)                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) {                                                             \
+        const T yc = sh_y[cp + ((g_) * STREAM_G + k) * nCP];                                                           \
+        _Pragma("unroll") for (int r = 0; r < RPL; r++) part[r] += buf[k][r] * yc;                                     \
+    }
+            if (nG > 0) {
+                int g = 0;
+                RN_LOADG(bufA, 0)
+                // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is
+                // consumed, group g+1 (and then g+2) is in flight
+                for (; g + 2 < nG; g += 2) {
+                    RN_LOADG(bufB, g + 1)
+                    RN_USEG(bufA, g)
+                    RN_LOADG(bufA, g + 2)
+                    RN_USEG(bufB, g + 1)
+                }
+                if (g + 1 < nG) {
+                    RN_LOADG(bufB, g + 1)
+                    RN_USEG(bufA, g)
+                    RN_USEG(bufB, g + 1)
+                } else {
+                    RN_USEG(bufA, g)
                 }
             }
-            for (; c < ny; c += nCP) {
+#undef RN_LOADG
+#undef RN_USEG
+            for (int j = nG * STREAM_G; j < ncol; j++) {           // remainder columns
+                const int c = cp + j * nCP;
                 T m[RPL];
                 load_rows<T>(Ab + (size_t)c * LD, m);
                 const T yc = sh_y[c];
 #pragma unroll
                 for (int r = 0; r < RPL; r++) part[r] += m[r] * yc;
             }
-        }
-        // combine the column phases of this row block through LDS: sh_red[cp][row]
-        const int LDp = (LD + 3) & ~3;
-        if (rb < nRB && cp < nCP && row < LD) {
 #pragma unroll
             for (int r = 0; r < RPL; r++) sh_red[(size_t)cp * LDp + row + r] = part[r];
         }
     }
     __syncthreads();
-    // sh_red now holds nCP partial copies of A_i y_i; fold them into copy 0
-    {
-        const int LDp = (LD + 3) & ~3;
-        for (int r = tid; r < 2 * nv; r += BWD_THREADS) {
-            T s = sh_red[r];
-            for (int k = 1; k < nCP; k++) s += sh_red[(size_t)k * LDp + r];
-            sh_red[r] = s;
-        }
-    }
-    __syncthreads();
-    T *sh_scr = sh_red + BWD_WAVES * ((LD + 3) & ~3);      // scratch for block_gemv_shared
-    // g = Rinv s
-    block_gemv_shared<T>(a.Rinv, nv, nv, sh_s, sh_g, sh_scr, BWD_THREADS);
-    const T invp2 = (T)(-0.5) / a.tr.prob[node];
-    for (int t = tid; t < nv; t += BWD_THREADS) a.v[(size_t)node * nv + t] = invp2 * sh_g[t] + sh_red[t];
-    __syncthreads();
-    // g = Bbt q_i
-    block_gemv_shared<T>(a.Bbt, nv, nx, sh_q, sh_g, sh_scr, BWD_THREADS);
-    for (int t = tid; t < nv; t += BWD_THREADS) a.rt[(size_t)node * nv + t] = sh_s[t] + sh_red[nv + t] + sh_g[t];
-}
-
-// multi-GPU: partial children sums of the cut parents, [parent][rt(nv) | q(nx)] (the vector that is all-reduced)
-template <typename T>
-__global__ void k_cut_partial_sums(SweepArgs<T> a, T *out) {
-    const int parentStage = a.cutStage - 1;
-    const int node = a.tr.stageCum[parentStage] + blockIdx.x;
-    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
-    for (int t = threadIdx.x; t < a.nv + a.nx; t += blockDim.x) {
-        T s = 0;
-        if (t < a.nv) for (int c = 0; c < nc; c++) s += a.rt[(size_t)(c0 + c) * a.nv + t];
-        else for (int c = 0; c < nc; c++) s += a.q[(size_t)(c0 + c) * a.nx + (t - a.nv)];
-        out[(size_t)blockIdx.x * (a.nv + a.nx) + t] = s;
+    for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {
+        T s = sh_red[r];
+        for (int k = 1; k < nCP; k++) s += sh_red[(size_t)k * LDp + r];
+        a.my[(size_t)node * 2 * nv + r] = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Forward sweep, one stage (SmpcController.cu:676-741 + solveChildNodesUpdate Utilities.cu:142-155) and the
-// Hx products (:744-747, F_i and G_i are diagonal), one workgroup per node:
-//   u_i = uhat_i + L v_i + (u_anc - uhat_anc)        root: (prevU - prevUhat)
-//   x_i = x_anc + e_i + B u_i                        root: currentX
-//   Hx_i = sqrt(p_i) [d_x o x_i ; d_xs o x_i ; d_u o u_i]
-constexpr int FWD_THREADS = 128;
+// Leaf-to-root recursion of the backward sweep (SmpcController.cu:593-673 + solveSumChildren
+// Utilities.cu:168-201), re-associated so that no matrix product sits on the sequential path:
+//   rho_i   = beta_i + m2_i + sum_c rho_c        kappa_i = sum_c (kappa_c + q_c)        q_i = a_i + sum_c q_c
+// with r_i = rho_i + Bbt kappa_i  (the reference's r_j of :629-646; Bbt = Gtil) and
+//   s_i = beta_i + sum_c rho_c  so that  sigma_i + Gtil q_in = s_i + Bbt kappa_i     (:599, :644)
+// The products with the shared Rinv and Rinv*Bbt are applied afterwards to all nodes at once (k_gemm_shared).
+// Chain region (stages >= c*, every node has exactly one child at the same position): one workgroup per
+// scenario chain, thread t owns one component and walks from the leaf to the chain top.
+constexpr int CHAIN_THREADS = 256;
+constexpr int CHAIN_PF = 8;   // stages prefetched per round trip (the recursion itself is a running sum)
 template <typename T>
-__global__ void __launch_bounds__(FWD_THREADS) k_forward_stage(SweepArgs<T> a, int stage) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *sh_v = reinterpret_cast<T *>(smem_raw);     // nv
-    T *sh_u = sh_v + ((a.nv + 3) & ~3);            // nu
-    T *sh_o = sh_u + ((a.nu + 3) & ~3);            // max(nu, nx)
-    T *sh_scr = sh_o + ((max(a.nu, a.nx) + 3) & ~3);
-    const int tid = threadIdx.x;
-    const int node = a.tr.stageCum[stage] + blockIdx.x;
-    const int nx = a.nx, nu = a.nu, nv = a.nv, ny = a.ny;
-    const int par = a.tr.parent[node];
-    const T *dy = a.tr.dy + (size_t)stage * ny;
-    const T sp = a.tr.sqrtp[node];
-    for (int t = tid; t < nv; t += FWD_THREADS) sh_v[t] = a.v[(size_t)node * nv + t];
-    __syncthreads();
-    block_gemv_shared<T>(a.L, nu, nv, sh_v, sh_o, sh_scr, FWD_THREADS);
-    for (int t = tid; t < nu; t += FWD_THREADS) {
-        const T wanc = (par < 0) ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-        const T uv = a.uhat[(size_t)node * nu + t] + wanc + sh_o[t];
-        sh_u[t] = uv;
-        a.u[(size_t)node * nu + t] = uv;
-        a.hx[(size_t)node * ny + 2 * nx + t] = sp * dy[2 * nx + t] * uv;
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a) {
+    const int s = blockIdx.x;                      // chain = position within the stage
+    const int nv = a.nv, nx = a.nx;
+    const int top = a.chainStage;
+    const T *__restrict__ beta = a.beta;
+    const T *__restrict__ my = a.my;
+    const T *__restrict__ qa = a.qa;
+    const int *__restrict__ cum = a.tr.stageCum;
+    for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
+        if (t < nv) {
+            T rho = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T b[CHAIN_PF], m[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    const size_t node = (size_t)cum[kk] + s;
+                    b[j] = beta[node * nv + t];
+                    m[j] = my[node * 2 * nv + nv + t];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        const T sv = b[j] + rho;                   // s_i
+                        a.sk[node * (nv + nx) + t] = sv;
+                        rho = sv + m[j];
+                    }
+                }
+            }
+            a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T av[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        kap += q;                                  // kappa_i = kappa_c + q_c
+                        a.sk[node * (nv + nx) + nv + j0] = kap;
+                        q += av[j];                                // q_i = a_i + q_c
+                    }
+                }
+            }
+            const size_t ntop = (size_t)cum[top] + s;
+            a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
+            a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
+        }
     }
-    __syncthreads();
-    block_gemv_shared<T>(a.B, nx, nu, sh_u, sh_o, sh_scr, FWD_THREADS);
-    for (int t = tid; t < nx; t += FWD_THREADS) {
-        const T xanc = (par < 0) ? a.curX[t] : a.x[(size_t)par * nx + t];
-        const T xv = xanc + a.e[(size_t)node * nx + t] + sh_o[t];
-        a.x[(size_t)node * nx + t] = xv;
-        a.hx[(size_t)node * ny + t] = sp * dy[t] * xv;
-        a.hx[(size_t)node * ny + nx + t] = sp * dy[nx + t] * xv;
+}
+// Crown region (stages < c*), one node: children are summed explicitly (loads batched CHAIN_PF at a time).
+template <typename T>
+__device__ __forceinline__ void up_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads) {
+    const int node = a.tr.stageCum[stage] + pos;
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
+    const T *rk = a.rkq;
+    for (int t = tid; t < nv + nx; t += nthreads) {
+        if (t < nv) {
+            T sum = 0;
+            if (presummed) sum = a.cutSums[(size_t)pos * w + t];
+            else for (int c = 0; c < nc; c += CHAIN_PF) {
+                T r[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) r[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * w + t] : (T)0;
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) sum += r[j];
+            }
+            const T sv = a.beta[(size_t)node * nv + t] + sum;
+            a.sk[(size_t)node * (nv + nx) + t] = sv;
+            a.rkq[(size_t)node * w + t] = sv + a.my[(size_t)node * 2 * nv + nv + t];
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            if (presummed) { kap = a.cutSums[(size_t)pos * w + nv + j0]; q = a.cutSums[(size_t)pos * w + nv + nx + j0]; kap += q; }
+            else for (int c = 0; c < nc; c += CHAIN_PF) {
+                T kc[CHAIN_PF], qc[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    kc[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * w + nv + j0] : (T)0;
+                    qc[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * w + nv + nx + j0] : (T)0;
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) { kap += kc[j] + qc[j]; q += qc[j]; }
+            }
+            a.sk[(size_t)node * (nv + nx) + nv + j0] = kap;
+            a.rkq[(size_t)node * w + nv + j0] = kap;
+            a.rkq[(size_t)node * w + nv + nx + j0] = q + a.qa[(size_t)node * nx + j0];
+        }
+    }
+}
+// one launch per stage, one workgroup per node (large crowns)
+template <typename T>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_crown(SweepArgs<T> a, int stage) {
+    up_crown_node<T>(a, stage, blockIdx.x, threadIdx.x, CHAIN_THREADS);
+}
+// small crowns: ONE workgroup walks the stages [fromStage .. 0]; its own earlier stores are made visible to its
+// later loads by the barrier (same CU, same L1)
+constexpr int CROWN_THREADS = 1024;
+template <typename T>
+__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_all(SweepArgs<T> a, int fromStage) {
+    const int per = a.nv + a.nx;                         // work items per node
+    for (int k = fromStage; k >= 0; k--) {
+        const int nk = a.tr.stageCum[k + 1] - a.tr.stageCum[k];
+        const int lanesPerNode = per < CROWN_THREADS ? ((per + 63) / 64) * 64 : CROWN_THREADS;
+        const int nodesPerPass = CROWN_THREADS / lanesPerNode;
+        for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
+            const int pos = p0 + threadIdx.x / lanesPerNode;
+            if (pos < nk && threadIdx.x / lanesPerNode < nodesPerPass) up_crown_node<T>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+// multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload)
+template <typename T>
+__global__ void k_cut_partial_sums(SweepArgs<T> a, T *out) {
+    const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
+    const int w = a.nv + 2 * a.nx;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    for (int t = threadIdx.x; t < w; t += blockDim.x) {
+        T s = 0;
+        for (int c = 0; c < nc; c++) s += a.rkq[(size_t)(c0 + c) * w + t];
+        out[(size_t)blockIdx.x * w + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Batched product with a SHARED small matrix:  out_i = epi( M * in_i )  for all nodes i, as a tiled GEMM
+// [m x k] * [k x nodes] on the matrix cores (MFMA 16x16x4, one wave = 64 rows x 16 nodes, operands straight
+// from L2-resident M and the node-major vectors; these products are genuine dense contractions).
+// The reference issues these as per-stage cublasSgemm / per-node SgemmBatched calls on K identical copies of the
+// matrices (SmpcController.cu:604-611, :692-736).  Epilogues:
+//   EPI_V : v_i  = m1_i - acc / (2 p_i)        M = [Rinv | Rinv Bbt], in = [s_i; kappa_i]     (:604-623)
+//   EPI_LV: lv_i = acc                          M = L,  in = v_i                                (:692,:701,:727)
+//   EPI_Z : z_i  = e_i + acc                    M = B,  in = u_i                                (:695,:715,:736)
+enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2 };
+template <typename T>
+struct GemmArgs {
+    const T *M; int m, k;        // logical m x k; stored zero-padded, col-major, mp x kp with mp % 64 == 0, kp % 4 == 0
+    int mp, kp;
+    const T *in; int ldin;       // in_i = in + i*ldin (k entries)
+    T *out; int ldout;           // out_i = out + i*ldout (m entries)
+    const T *aux; int ldaux;     // EPI_V: my (m1 at aux + i*ldaux) ; EPI_Z: e
+    const T *prob;
+    int nodes;
+};
+// MFMA 16x16x4 wrappers.  fp64: v_mfma_f64_16x16x4_f64, C/D row = (lane>>4) + 4*reg;  fp32: v_mfma_f32_16x16x4_f32,
+// C/D row = 4*(lane>>4) + reg;  both: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15], col = lane&15.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma16<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_RT = 4;       // 16-row tiles per wave (64 output rows x 16 nodes per wave)
+template <typename T, int EPI>
+__global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rowGroups = (g.mp + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
+    const int nodeTiles = (g.nodes + 15) / 16;
+    const int unit = blockIdx.x * (GEMM_THREADS / 64) + wave;
+    if (unit >= rowGroups * nodeTiles) return;
+    const int nodeTile = unit / rowGroups, rg = unit % rowGroups;
+    const int r0 = rg * 16 * GEMM_RT;
+    const int col = lane & 15, kq = lane >> 4;
+    const int node = nodeTile * 16 + col;
+    const bool nodeOk = node < g.nodes;
+    // lanes of nodes past the end read a valid node's data and simply do not write the result
+    const T *__restrict__ inp = g.in + (size_t)(nodeOk ? node : g.nodes - 1) * g.ldin + kq;
+    const T *__restrict__ Mp = g.M + r0 + col + (size_t)kq * g.mp;   // mp % 64 == 0: all GEMM_RT tiles are in bounds
+    const size_t mstep = (size_t)4 * g.mp;
+    acc_t acc[GEMM_RT];
+#pragma unroll
+    for (int t = 0; t < GEMM_RT; t++) acc[t] = acc_t{0, 0, 0, 0};
+    const int kFull = g.k & ~7;
+    int k0 = 0;
+    for (; k0 < kFull; k0 += 8) {   // two k-steps per trip: 10 independent loads, then 8 MFMAs
+        const T b0 = inp[k0], b1 = inp[k0 + 4];
+        T a0[GEMM_RT], a1[GEMM_RT];
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++) { a0[t] = Mp[t * 16]; a1[t] = Mp[t * 16 + mstep]; }
+        Mp += 2 * mstep;
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(a0[t], b0, acc[t]);
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(a1[t], b1, acc[t]);
+    }
+    for (; k0 < g.k; k0 += 4) {     // K tail: M is zero-padded in k, the input vector is not
+        const T b = (k0 + kq < g.k) ? inp[k0] : (T)0;
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(Mp[t * 16], b, acc[t]);
+        Mp += mstep;
+    }
+    if (!nodeOk) return;
+    T scale = 0;
+    if (EPI == EPI_V) scale = (T)(-0.5) / g.prob[node];
+#pragma unroll
+    for (int t = 0; t < GEMM_RT; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int gr = r0 + t * 16 + Mfma16<T>::row(lane, reg);
+            if (gr >= g.m) continue;
+            T r = acc[t][reg];
+            if (EPI == EPI_V) r = g.aux[(size_t)node * g.ldaux + gr] + scale * r;
+            if (EPI == EPI_Z) r = g.aux[(size_t)node * g.ldaux + gr] + r;
+            g.out[(size_t)node * g.ldout + gr] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
+// Utilities.cu:142-155) and the diagonal Hx products (:744-747):
+//   pass U:  u_i = uhat_i + (u_anc - uhat_anc) + L v_i        root: (prevU - prevUhat)
+//   pass X:  x_i = x_anc + (e_i + B u_i)                       root: currentX
+//   Hx_i = sqrt(p_i) [d_x o x_i ; d_xs o x_i ; d_u o u_i]
+template <typename T, bool PASS_X>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a) {
+    const int s = blockIdx.x;
+    const int nx = a.nx, nu = a.nu, ny = a.ny;
+    const int top = a.chainStage;
+    const int dim = PASS_X ? nx : nu;
+    const int ntop = a.tr.stageCum[top] + s;
+    const int par = a.tr.parent[ntop];
+    const T sp = a.tr.sqrtp[ntop];   // p is constant along a chain
+    const T *__restrict__ inc = PASS_X ? a.z : a.lv;
+    const T *__restrict__ uhat = a.uhat;
+    const T *__restrict__ dyAll = a.tr.dy;
+    const int *__restrict__ cum = a.tr.stageCum;
+    for (int t = threadIdx.x; t < dim; t += CHAIN_THREADS) {
+        T run;
+        if (PASS_X) run = par < 0 ? a.curX[t] : a.x[(size_t)par * nx + t];
+        else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+        for (int k = top; k < a.N; k += CHAIN_PF) {
+            T dv[CHAIN_PF], uh[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) {
+                const int kk = k + j < a.N ? k + j : a.N - 1;
+                const size_t node = (size_t)cum[kk] + s;
+                dv[j] = inc[node * dim + t];
+                if (PASS_X) { d0[j] = dyAll[(size_t)kk * ny + t]; d1[j] = dyAll[(size_t)kk * ny + nx + t]; uh[j] = 0; }
+                else { d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t]; d1[j] = 0; uh[j] = uhat[node * nu + t]; }
+            }
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) {
+                if (k + j < a.N) {
+                    const size_t node = (size_t)cum[k + j] + s;
+                    run += dv[j];
+                    if (PASS_X) {
+                        a.x[node * nx + t] = run;
+                        a.hx[node * ny + t] = sp * d0[j] * run;
+                        a.hx[node * ny + nx + t] = sp * d1[j] * run;
+                    } else {
+                        const T uv = uh[j] + run;
+                        a.u[node * nu + t] = uv;
+                        a.hx[node * ny + 2 * nx + t] = sp * d0[j] * uv;
+                    }
+                }
+            }
+        }
+    }
+}
+template <typename T, bool PASS_X>
+__device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads) {
+    const int node = a.tr.stageCum[stage] + pos;
+    const int nx = a.nx, nu = a.nu, ny = a.ny;
+    const int par = a.tr.parent[node];
+    const T sp = a.tr.sqrtp[node];
+    const T *dy = a.tr.dy + (size_t)stage * ny;
+    const int dim = PASS_X ? nx : nu;
+    for (int t = tid; t < dim; t += nthreads) {
+        if (PASS_X) {
+            const T xv = (par < 0 ? a.curX[t] : a.x[(size_t)par * nx + t]) + a.z[(size_t)node * nx + t];
+            a.x[(size_t)node * nx + t] = xv;
+            a.hx[(size_t)node * ny + t] = sp * dy[t] * xv;
+            a.hx[(size_t)node * ny + nx + t] = sp * dy[nx + t] * xv;
+        } else {
+            const T wanc = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+            const T uv = a.uhat[(size_t)node * nu + t] + wanc + a.lv[(size_t)node * nu + t];
+            a.u[(size_t)node * nu + t] = uv;
+            a.hx[(size_t)node * ny + 2 * nx + t] = sp * dy[2 * nx + t] * uv;
+        }
+    }
+}
+template <typename T, bool PASS_X>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_down_crown(SweepArgs<T> a, int stage) {
+    down_crown_node<T, PASS_X>(a, stage, blockIdx.x, threadIdx.x, CHAIN_THREADS);
+}
+template <typename T, bool PASS_X>
+__global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a, int nStages) {
+    const int per = PASS_X ? a.nx : a.nu;
+    for (int k = 0; k < nStages; k++) {
+        const int nk = a.tr.stageCum[k + 1] - a.tr.stageCum[k];
+        const int lanesPerNode = per < CROWN_THREADS ? ((per + 63) / 64) * 64 : CROWN_THREADS;
+        const int nodesPerPass = CROWN_THREADS / lanesPerNode;
+        for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
+            const int pos = p0 + threadIdx.x / lanesPerNode;
+            if (pos < nk && threadIdx.x / lanesPerNode < nodesPerPass) down_crown_node<T, PASS_X>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
+        }
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -302,8 +575,29 @@ __device__ __forceinline__ void better(double &a, double &v, long long &i, doubl
     if (a2 > a || (a2 == a && i2 < i)) { a = a2; v = v2; i = i2; }
 }
 
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { typedef nat_d2 type; static constexpr int N = 2; };
+template <> struct VecOf<float> { typedef nat_f4 type; static constexpr int N = 4; };
+
+template <typename T> struct DualOut { T yn, wn, z, res, diff; };
+template <typename T, bool FIXUP>
+__device__ __forceinline__ DualOut<T> dual_elem(T hx, T w, T lo, T hi, T yp, T lambda, T invLambda, T ln, T sc) {
+    DualOut<T> o;
+    const T t = hx + invLambda * w;
+    T z = t < lo ? lo : (t > hi ? hi : t);
+    o.diff = t - z;
+    if (FIXUP) z += sc * o.diff;      // sc = 0 on the psi part and on halves that did not trip
+    o.z = z;
+    o.res = hx - z;
+    o.yn = w + lambda * o.res;
+    o.wn = ((T)1 + ln) * o.yn - ln * yp;
+    return o;
+}
+
 template <typename T, bool MATERIALIZE, bool FIXUP>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
     __shared__ Partial sh_p[ELT_THREADS / 64];
     T scX = 0, scS = 0;
     if (FIXUP) {
@@ -311,27 +605,56 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
         scX = (T)a.st->scaleX; scS = (T)a.st->scaleS;
     }
     const T ln = (T)a.lamNext[a.st->it + 1];
+    const T lambda = a.lambda, invLambda = a.invLambda;
     const int nx = a.nx, ny = a.ny;
     double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
     long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
     const long long stride = (long long)gridDim.x * ELT_THREADS;
-    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < a.n; i += stride) {
+    const long long gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    const long long nvec = a.n / VN;
+    // column index of the first element of this thread's vector, advanced incrementally (no division in the loop)
+    int c0 = (int)((gid * VN) % ny);
+    const int cstep = (int)((stride * VN) % ny);
+    for (long long iv = gid; iv < nvec; iv += stride) {   // 16 bytes per lane per stream
+        const VT hx = reinterpret_cast<const VT *>(a.hx)[iv], w = reinterpret_cast<const VT *>(a.w)[iv];
+        const VT lo = reinterpret_cast<const VT *>(a.lo)[iv], hi = reinterpret_cast<const VT *>(a.hi)[iv];
+        const VT yp = reinterpret_cast<const VT *>(a.yprev)[iv];
+        VT yn, wn, z, res;
+        int c = c0;
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+            const bool isBox = c < nx, isXi = c < 2 * nx;
+            const T sc = FIXUP ? (isBox ? scX : (isXi ? scS : (T)0)) : (T)0;
+            const DualOut<T> o = dual_elem<T, FIXUP>(hx[e], w[e], lo[e], hi[e], yp[e], lambda, invLambda, ln, sc);
+            yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
+            const long long i = iv * VN + e;
+            const double dd = (a.countCrown || i >= a.crownElems) ? (double)o.diff * (double)o.diff : 0.0;
+            d2x += isBox ? dd : 0.0;
+            d2s += (isXi && !isBox) ? dd : 0.0;
+            const double ar = fabs((double)o.res);
+            if (isXi) { if (ar > absXi) { absXi = ar; valXi = (double)o.res; idxXi = i; } }
+            else { if (ar > absPsi) { absPsi = ar; valPsi = (double)o.res; idxPsi = i; } }
+            if (++c == ny) c = 0;
+        }
+        reinterpret_cast<VT *>(a.ynew)[iv] = yn;
+        reinterpret_cast<VT *>(a.wnext)[iv] = wn;
+        if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[iv] = z; reinterpret_cast<VT *>(a.res)[iv] = res; }
+        c0 += cstep;
+        if (c0 >= ny) c0 -= ny;
+    }
+    for (long long i = nvec * VN + gid; i < a.n; i += stride) {   // at most VN-1 tail elements
         const int c = (int)(i % ny);
-        const T hx = a.hx[i], w = a.w[i], lo = a.lo[i], hi = a.hi[i], yp = a.yprev[i];
-        const T t = hx + a.invLambda * w;
-        T z = t < lo ? lo : (t > hi ? hi : t);
-        const T diff = t - z;
-        const bool counted = a.countCrown || i >= a.crownElems;
-        if (c < nx) { if (counted) d2x += (double)diff * (double)diff; if (FIXUP) z += scX * diff; }
-        else if (c < 2 * nx) { if (counted) d2s += (double)diff * (double)diff; if (FIXUP) z += scS * diff; }
-        const T res = hx - z;
-        const T yn = w + a.lambda * res;
-        a.ynew[i] = yn;
-        a.wnext[i] = ((T)1 + ln) * yn - ln * yp;
-        if (MATERIALIZE) { a.z[i] = z; a.res[i] = res; }
-        const double ar = fabs((double)res);
-        if (c < 2 * nx) better(absXi, valXi, idxXi, ar, (double)res, i);
-        else better(absPsi, valPsi, idxPsi, ar, (double)res, i);
+        const bool isBox = c < nx, isXi = c < 2 * nx;
+        const T sc = FIXUP ? (isBox ? scX : (isXi ? scS : (T)0)) : (T)0;
+        const DualOut<T> o = dual_elem<T, FIXUP>(a.hx[i], a.w[i], a.lo[i], a.hi[i], a.yprev[i], lambda, invLambda, ln, sc);
+        a.ynew[i] = o.yn; a.wnext[i] = o.wn;
+        if (MATERIALIZE) { a.z[i] = o.z; a.res[i] = o.res; }
+        const double dd = (a.countCrown || i >= a.crownElems) ? (double)o.diff * (double)o.diff : 0.0;
+        d2x += isBox ? dd : 0.0;
+        d2s += (isXi && !isBox) ? dd : 0.0;
+        const double ar = fabs((double)o.res);
+        if (isXi) { if (ar > absXi) { absXi = ar; valXi = (double)o.res; idxXi = i; } }
+        else { if (ar > absPsi) { absPsi = ar; valPsi = (double)o.res; idxPsi = i; } }
     }
     // wave reduction (64 lanes), then across the block's waves
     for (int off = 32; off > 0; off >>= 1) {

@@ -145,7 +145,10 @@ struct Ctx : CtxBase {
     T *d_errD = nullptr, *d_errP = nullptr, *d_dhat = nullptr, *d_ahat = nullptr;
     T *d_curX = nullptr, *d_prevU = nullptr, *d_prevUhat = nullptr, *d_prevD = nullptr;
     T *d_beta = nullptr, *d_uhat = nullptr, *d_e = nullptr, *d_alpha = nullptr;
-    T *d_x = nullptr, *d_u = nullptr, *d_v = nullptr, *d_rt = nullptr, *d_q = nullptr, *d_hx = nullptr;
+    T *d_x = nullptr, *d_u = nullptr, *d_v = nullptr, *d_hx = nullptr;
+    T *d_my = nullptr, *d_qa = nullptr, *d_sk = nullptr, *d_rkq = nullptr, *d_lv = nullptr, *d_zz = nullptr;
+    T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
+    int chainStage = 0;
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
     T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
     T *d_tmp = nullptr;  // nodes*max(2nx,nu) staging for reference-layout get/set
@@ -210,16 +213,27 @@ struct Ctx : CtxBase {
         return RN_OK;
     }
 
+    static int pad16(int v) { return (v + 63) / 64 * 64; }   // rows padded to one wave tile (GEMM_RT * 16)
+    static int pad4(int v) { return (v + 3) / 4 * 4; }
+    int upload_padded(T *dst, const double *src, int m, int k) {   // col-major m x k -> zero-padded pad16(m) x pad4(k)
+        const int mp = pad16(m), kp = pad4(k);
+        std::vector<double> tmp((size_t)mp * kp, 0.0);
+        for (int j = 0; j < k; j++) for (int i = 0; i < m; i++) tmp[i + (size_t)j * mp] = src[i + (size_t)j * m];
+        return upload(dst, tmp.data(), tmp.size());
+    }
     TreeDev<T> tree_dev() const { return TreeDev<T>{d_stageCum, d_parent, d_childStart, d_childCount, d_stageOf, d_sqrtp, d_prob, d_dy}; }
     SweepArgs<T> sweep_args() const {
         SweepArgs<T> a{};
         a.tr = tree_dev();
-        a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD;
-        a.A = d_A; a.Rinv = d_Rinv; a.Bbt = d_Bbt; a.L = d_L; a.B = d_B;
-        a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
-        a.w = p_acc; a.v = d_v; a.rt = d_rt; a.q = d_q; a.x = d_x; a.u = d_u; a.hx = d_hx;
+        a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD; a.N = d.N; a.nodes = d.nodes;
         a.cutSums = (nranks > 1 && cutStage > 0) ? d_cut : nullptr;
         a.cutStage = cutStage;
+        a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
+        a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
+        a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B;
+        a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
+        a.w = p_acc; a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lv = d_lv; a.z = d_zz;
+        a.x = d_x; a.u = d_u; a.hx = d_hx;
         return a;
     }
     long long ntot() const { return (long long)d.nodes * ny; }
@@ -263,6 +277,15 @@ struct Ctx : CtxBase {
         for (int i = 0; i < nodes; i++) (h_childCount[i] == 0 ? leaves : nonleaf)++;
         RN_CHECK(nonleaf == d.nNonLeafNodes, RN_E_ARG, "rn_create: nNonLeafNodes inconsistent with ancestor[]");
         (void)leaves;
+        // c*: first stage from which the tree is K parallel chains (every node has exactly one child, same position)
+        chainStage = N - 1;
+        while (chainStage > 0) {
+            const int k = chainStage - 1;
+            bool chain = (h_stageCum[k + 1] - h_stageCum[k]) == (h_stageCum[k + 2] - h_stageCum[k + 1]);
+            for (int i = h_stageCum[k]; chain && i < h_stageCum[k + 1]; i++) chain = (h_childCount[i] == 1);
+            if (!chain) break;
+            chainStage--;
+        }
         if (int rc = dalloc(&d_stageCum, N + 1)) return rc;
         if (int rc = dalloc(&d_parent, nodes)) return rc;
         if (int rc = dalloc(&d_childStart, nodes)) return rc;
@@ -283,11 +306,13 @@ struct Ctx : CtxBase {
         DA(d_errD, n * nd) DA(d_errP, n * nu) DA(d_dhat, (size_t)N * nd) DA(d_ahat, (size_t)N * nu)
         DA(d_curX, nx) DA(d_prevU, nu) DA(d_prevUhat, nu) DA(d_prevD, nd)
         DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
-        DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_rt, n * nv) DA(d_q, n * nx) DA(d_hx, n * ny)
+        DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_hx, n * ny)
+        DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lv, n * nu) DA(d_zz, n * nx)
+        DA(d_RTp, (size_t)pad16(nv) * pad4(nv + nx)) DA(d_Lp, (size_t)pad16(nu) * pad4(nv)) DA(d_Bp, (size_t)pad16(nx) * pad4(nu))
         DA(d_lo, n * ny) DA(d_hi, n * ny) DA(d_z, n * ny) DA(d_res, n * ny)
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
-        DA(d_cut, (size_t)nodes * (nv + nx))  // upper bound on cut parents
+        DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
         DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS)
 #undef DA
         std::vector<double> sq(nodes);
@@ -339,6 +364,12 @@ struct Ctx : CtxBase {
         for (int t = 0; t < nx; t++) { blo[t] = s->vecXmin[t]; bhi[t] = s->vecXmax[t]; blo[nx + t] = s->vecXsafe[t]; bhi[nx + t] = (double)big; }
         for (int t = 0; t < nu; t++) { blo[2 * nx + t] = s->vecUmin[t]; bhi[2 * nx + t] = s->vecUmax[t]; }
 #define UP(dst, src, cnt) if (int rc = upload(dst, src, (size_t)(cnt))) return rc;
+        std::vector<double> RTm((size_t)nv * (nv + nx));
+        std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
+        std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
+        if (int rc = upload_padded(d_RTp, RTm.data(), nv, nv + nx)) return rc;
+        if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
+        if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
         UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
         UP(d_Lt, Lt.data(), nv * nu) UP(d_WLt, WLt.data(), nv * nu) UP(d_T1, T1.data(), nv * nx) UP(d_T2, T2.data(), nv * nu)
         UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu)
@@ -431,9 +462,9 @@ struct Ctx : CtxBase {
         return rc;
     }
     int algorithmic_bytes(double *bwd, double *dual) const override {
-        // backward sweep: A_i once + read w, beta, children rt/q; write v, rt, q   (all stages of one sweep)
+        // k_stream_gemv, one launch = the whole tree: A_i (2nv x ny, unpadded) read once + y_i read + m1,m2,a_i written
         const double s = sizeof(T), n = d.nodes;
-        if (bwd) *bwd = n * ((double)2 * d.nv * ny + ny + 3.0 * d.nv + 2.0 * d.nx + (d.nv + d.nx)) * s;
+        if (bwd) *bwd = n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
         if (dual) *dual = 7.0 * (double)ntot() * s;
         return RN_OK;
     }
@@ -441,35 +472,58 @@ struct Ctx : CtxBase {
     void *stream_handle() override { return (void *)stream; }
 
     // ---- the sweep ---------------------------------------------------------------------------------------
-    size_t bwd_lds() const {
+    size_t stream_lds() const {
         const int LDp = (LD + 3) & ~3;
-        return (size_t)(((ny + 3) & ~3) + 2 * ((d.nv + 3) & ~3) + ((d.nx + 3) & ~3) + BWD_WAVES * LDp + BWD_THREADS) * sizeof(T);
+        const int nRB = (LD + 64 * RPL - 1) / (64 * RPL);
+        const int nCP = STREAM_WAVES / std::min(nRB, STREAM_WAVES);
+        return (size_t)(((ny + 3) & ~3) + (size_t)nCP * LDp) * sizeof(T);
     }
-    size_t fwd_lds() const {
-        return (size_t)(((d.nv + 3) & ~3) + ((d.nu + 3) & ~3) + ((std::max(d.nu, d.nx) + 3) & ~3) + FWD_THREADS) * sizeof(T);
+    template <int EPI>
+    void launch_gemm(const T *Mp, int m, int k, const T *in, int ldin, T *out, int ldout, const T *aux, int ldaux) {
+        GemmArgs<T> g{Mp, m, k, pad16(m), pad4(k), in, ldin, out, ldout, aux, ldaux, d_prob, d.nodes};
+        const int units = ((g.mp + 16 * GEMM_RT - 1) / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);
+        hipLaunchKernelGGL((k_gemm_shared<T, EPI>), dim3((units + 3) / 4), dim3(GEMM_THREADS), 0, stream, g);
     }
     int launch_sweep() {
         SweepArgs<T> a = sweep_args();
-        const size_t lb = bwd_lds(), lf = fwd_lds();
-        for (int k = d.N - 1; k >= 0; k--) {
-            const int nk = h_stageCum[k + 1] - h_stageCum[k];
-            if (a.cutSums && k == cutStage - 1) {   // multi-GPU: all-reduce the children sums of the cut parents
-                const hipEvent_t *ec = prof_begin(3);
-                hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk), dim3(128), 0, stream, a, d_cut);
-                const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk * (d.nv + d.nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
-                                                0 /*ncclSum*/, comm, stream);
-                prof_end(ec);
-                RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
-            }
-            const hipEvent_t *e0 = prof_begin(0);
-            hipLaunchKernelGGL(k_backward_stage<T>, dim3(nk), dim3(BWD_THREADS), lb, stream, a, k);
-            prof_end(e0);
-        }
+        const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
+        auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
+        // (1) all per-node mat-vecs of the backward sweep in one streaming launch
+        const hipEvent_t *e0 = prof_begin(0);
+        hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
+        prof_end(e0);
         const hipEvent_t *e1 = prof_begin(1);
-        for (int k = 0; k < d.N; k++) {
-            const int nk = h_stageCum[k + 1] - h_stageCum[k];
-            hipLaunchKernelGGL(k_forward_stage<T>, dim3(nk), dim3(FWD_THREADS), lf, stream, a, k);
+        // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
+        hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
+        const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64 && (!a.cutSums || cutStage == cs);
+        auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
+            hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k)), dim3(128), 0, stream, a, d_cut);
+            const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk(k) * (nv + 2 * nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
+                                            0 /*ncclSum*/, comm, stream);
+            RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+            return RN_OK;
+        };
+        if (fusedCrown) {
+            if (a.cutSums) if (int rc = all_reduce_cut(cs - 1)) return rc;
+            hipLaunchKernelGGL(k_up_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs - 1);
+        } else {
+            for (int k = cs - 1; k >= 0; k--) {
+                if (a.cutSums && k == cutStage - 1) if (int rc = all_reduce_cut(k)) return rc;
+                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+            }
         }
+        // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
+        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
+        launch_gemm<EPI_LV>(d_Lp, nu, nv, d_v, nv, d_lv, nu, nullptr, 0);
+        // (4) root-to-leaf: u, then z_i = e_i + B u_i, then x and Hx
+        if (fusedCrown) hipLaunchKernelGGL((k_down_crown_all<T, false>), dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
+        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL((k_down_crown<T, false>), dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+        hipLaunchKernelGGL((k_down_chain<T, false>), dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        launch_gemm<EPI_Z>(d_Bp, nx, nu, d_u, nu, d_zz, nx, d_e, nx);
+        if (fusedCrown) hipLaunchKernelGGL((k_down_crown_all<T, true>), dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
+        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL((k_down_crown<T, true>), dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+        hipLaunchKernelGGL((k_down_chain<T, true>), dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
