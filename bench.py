@@ -143,10 +143,10 @@ def main():
         ms, n = s.profileRead()
         s.profileEnable(0)
         bwd_bytes, dual_bytes = s.algorithmicBytes()
-        names = ("backward_sweep", "forward_sweep", "dual_update", "bookkeeping")
+        names = ("backward_sweep", "forward_sweep", "dual_update", "bookkeeping")  # 0 = k_stream_gemv, 1 = recursion + shared GEMMs
         for i, nm in enumerate(names):
             classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
-        launches_per_sweep = s.N
+        launches_per_sweep = 1          # k_stream_gemv covers the whole tree in one launch
         avg_s = 1e-3 * ms[0] / max(n[0], 1)
         bytes_per_launch = bwd_bytes / launches_per_sweep
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -154,10 +154,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_backward_stage_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_stream_gemv_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_backward_stage", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+        roofline = {"kernel": "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_s,
                     "launches_per_step": launches_per_sweep,

@@ -17,16 +17,20 @@ def _stale(out, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def build_hip(force=False, verbose=False):
-    """librapidnet_hip.so: the C-ABI (include/rapidnet.h) + every HIP kernel, for gfx950 only."""
+def build_hip(force=False, verbose=False, defines=(), out=None):
+    """librapidnet_hip.so: the C-ABI (include/rapidnet.h) + every HIP kernel, for gfx950 only.
+
+    `defines` / `out` build tuning variants (e.g. RN_STREAM_G=6) next to the default library; capi.load() picks the
+    library named by $RAPIDNET_LIB when set."""
+    out = out or LIB_HIP
     srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "rapidnet.h")]
-    if force or _stale(LIB_HIP, srcs):
+    if force or _stale(out, srcs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               "-o", LIB_HIP, srcs[0], "-ldl"]
+               "-Wno-pass-failed"] + ["-D" + d for d in defines] + ["-o", out, srcs[0], "-ldl"]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)
-    return LIB_HIP
+    return out
 
 
 if __name__ == "__main__":

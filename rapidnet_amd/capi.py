@@ -45,7 +45,7 @@ _LIB = None
 
 
 def lib_path():
-    return _build.LIB_HIP
+    return os.environ.get("RAPIDNET_LIB") or _build.LIB_HIP
 
 
 def load():

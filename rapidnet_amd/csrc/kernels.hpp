@@ -121,12 +121,21 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 // larger than the 256 MiB Infinity Cache) and double-buffered in groups of G columns so that ~2G columns per
 // wave are always in flight.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
 // HBM bytes per node: LD*ny*sizeof(T) + (ny + 2nv + nx)*sizeof(T).
-constexpr int STREAM_THREADS = 256;
+#ifndef RN_STREAM_THREADS
+#define RN_STREAM_THREADS 512
+#endif
+#ifndef RN_STREAM_G
+#define RN_STREAM_G 3
+#endif
+#ifndef RN_STREAM_MINW
+#define RN_STREAM_MINW 2
+#endif
+constexpr int STREAM_THREADS = RN_STREAM_THREADS;
 constexpr int STREAM_WAVES = STREAM_THREADS / 64;
-constexpr int STREAM_G = 5;   // columns per pipeline stage
+constexpr int STREAM_G = RN_STREAM_G;   // columns per pipeline stage
 
 template <typename T>
-__global__ void __launch_bounds__(STREAM_THREADS, 3) k_stream_gemv(SweepArgs<T> a) {
+__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // nCP * LDp
@@ -138,25 +147,28 @@ __global__ void __launch_bounds__(STREAM_THREADS, 3) k_stream_gemv(SweepArgs<T> 
     const int nRBw = nRB < STREAM_WAVES ? nRB : STREAM_WAVES;
     const int nCP = STREAM_WAVES / nRBw;                                     // column phases
     const int LDp = (LD + 3) & ~3;
-    for (int c = tid; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
-    __syncthreads();
-    {   // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
-        const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
-        const T sp = a.tr.sqrtp[node];
-        for (int t = tid; t < nx; t += STREAM_THREADS) a.qa[(size_t)node * nx + t] = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
-    }
     for (int rb0 = 0; rb0 < nRB; rb0 += nRBw) {
         const int rb = rb0 + wave % nRBw, cp = wave / nRBw;
         const int row = rb * 64 * RPL + lane * RPL;
         const bool active = rb < nRB && cp < nCP && row < LD;
         T part[RPL] = {0, 0, 0, 0};
-        if (active) {
-            const T *Ab = a.A + (size_t)node * ny * LD + row;
-            const int ncol = (ny - cp + nCP - 1) / nCP;            // columns of this phase: cp, cp+nCP, ...
-            const int nG = ncol / STREAM_G;
-            T bufA[STREAM_G][RPL], bufB[STREAM_G][RPL];
+        const T *Ab = a.A + (size_t)node * ny * LD + (active ? row : 0);
+        const int ncol = (ny - cp + nCP - 1) / nCP;            // columns of this phase: cp, cp+nCP, ...
+        const int nG = active ? ncol / STREAM_G : 0;
+        T bufA[STREAM_G][RPL], bufB[STREAM_G][RPL];
 #define RN_LOADG(buf, g_)                                                                                              \
     _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) load_rows<T>(Ab + (size_t)(cp + ((g_) * STREAM_G + k) * nCP) * LD, buf[k]);
+        // the first group of A does not depend on y: put it in flight before the prologue
+        if (nG > 0) { RN_LOADG(bufA, 0) }
+        if (rb0 == 0) {
+            for (int c = tid; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
+            __syncthreads();
+            // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
+            const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+            const T sp = a.tr.sqrtp[node];
+            for (int t = tid; t < nx; t += STREAM_THREADS) a.qa[(size_t)node * nx + t] = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
+        }
+        if (active) {
 #define RN_USEG(buf, g_)                                                                                               \
     _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) {                                                             \
         const T yc = sh_y[cp + ((g_) * STREAM_G + k) * nCP];                                                           \
@@ -164,7 +176,6 @@ __global__ void __launch_bounds__(STREAM_THREADS, 3) k_stream_gemv(SweepArgs<T> 
     }
             if (nG > 0) {
                 int g = 0;
-                RN_LOADG(bufA, 0)
                 // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is
                 // consumed, group g+1 (and then g+2) is in flight
                 for (; g + 2 < nG; g += 2) {
@@ -213,7 +224,8 @@ __global__ void __launch_bounds__(STREAM_THREADS, 3) k_stream_gemv(SweepArgs<T> 
 // Chain region (stages >= c*, every node has exactly one child at the same position): one workgroup per
 // scenario chain, thread t owns one component and walks from the leaf to the chain top.
 constexpr int CHAIN_THREADS = 256;
-constexpr int CHAIN_PF = 8;   // stages prefetched per round trip (the recursion itself is a running sum)
+constexpr int CHAIN_PF = 12;
+constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the recursion itself is a running sum)
 template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a) {
     const int s = blockIdx.x;                      // chain = position within the stage
@@ -314,14 +326,56 @@ __device__ __forceinline__ void up_crown_node(const SweepArgs<T> &a, int stage, 
         }
     }
 }
-// one launch per stage, one workgroup per node (large crowns)
+// one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
+// loads of a node are in flight at once, partial sums are folded through LDS
 template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_up_crown(SweepArgs<T> a, int stage) {
-    up_crown_node<T>(a, stage, blockIdx.x, threadIdx.x, CHAIN_THREADS);
+__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sh = reinterpret_cast<T *>(smem_raw);            // parts x w
+    const int pos = blockIdx.x;
+    const int node = a.tr.stageCum[stage] + pos;
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
+    const int wp = (w + 63) / 64 * 64;
+    const int parts = CROWN_THREADS / wp > 0 ? CROWN_THREADS / wp : 1;
+    const int part = threadIdx.x / wp, t = threadIdx.x % wp;
+    if (part < parts && t < w) {
+        T sum = 0;
+        if (!presummed) {
+            const T *rk = a.rkq;
+            for (int c = part; c < nc; c += parts * CHAIN_PF) {
+                T r[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) r[j] = (c + j * parts < nc) ? rk[(size_t)(c0 + c + j * parts) * w + t] : (T)0;
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) sum += r[j];
+            }
+        } else if (part == 0) sum = a.cutSums[(size_t)pos * w + t];
+        sh[part * w + t] = sum;
+    }
+    __syncthreads();
+    // fold: rhoSum (nv) | kappaSum (nx) | qSum (nx)
+    for (int tt = threadIdx.x; tt < nv + nx; tt += CROWN_THREADS) {
+        if (tt < nv) {
+            T sum = 0;
+            for (int p = 0; p < parts; p++) sum += sh[p * w + tt];
+            const T sv = a.beta[(size_t)node * nv + tt] + sum;
+            a.sk[(size_t)node * (nv + nx) + tt] = sv;
+            a.rkq[(size_t)node * w + tt] = sv + a.my[(size_t)node * 2 * nv + nv + tt];
+        } else {
+            const int j0 = tt - nv;
+            T ks = 0, qs = 0;
+            for (int p = 0; p < parts; p++) { ks += sh[p * w + nv + j0]; qs += sh[p * w + nv + nx + j0]; }
+            const T kap = ks + qs;                                   // kappa_i = sum_c (kappa_c + q_c)
+            a.sk[(size_t)node * (nv + nx) + nv + j0] = kap;
+            a.rkq[(size_t)node * w + nv + j0] = kap;
+            a.rkq[(size_t)node * w + nv + nx + j0] = qs + a.qa[(size_t)node * nx + j0];
+        }
+    }
 }
 // small crowns: ONE workgroup walks the stages [fromStage .. 0]; its own earlier stores are made visible to its
 // later loads by the barrier (same CU, same L1)
-constexpr int CROWN_THREADS = 1024;
 template <typename T>
 __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_all(SweepArgs<T> a, int fromStage) {
     const int per = a.nv + a.nx;                         // work items per node
@@ -384,31 +438,38 @@ template <> struct Mfma16<float> {
     static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_RT = 4;       // 16-row tiles per wave (64 output rows x 16 nodes per wave)
+constexpr int GEMM_WAVES = GEMM_THREADS / 64;
+constexpr int GEMM_RT = 4;       // 16-row tiles per workgroup tile (64 output rows x 16 nodes)
+// One workgroup = one 64 x 16 output tile; its 4 waves split K (contiguous quarters, multiples of 4) so that 4x more
+// waves are in flight (the loop is latency-, not MFMA-bound), partial tiles are summed through LDS by wave 0.
 template <typename T, int EPI>
 __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
     typedef typename Mfma16<T>::acc_t acc_t;
+    __shared__ T sh_acc[GEMM_WAVES - 1][GEMM_RT * 4][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rowGroups = (g.mp + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
-    const int nodeTiles = (g.nodes + 15) / 16;
-    const int unit = blockIdx.x * (GEMM_THREADS / 64) + wave;
-    if (unit >= rowGroups * nodeTiles) return;
+    const int rowGroups = g.mp / (16 * GEMM_RT);
+    const int unit = blockIdx.x;
     const int nodeTile = unit / rowGroups, rg = unit % rowGroups;
     const int r0 = rg * 16 * GEMM_RT;
     const int col = lane & 15, kq = lane >> 4;
     const int node = nodeTile * 16 + col;
     const bool nodeOk = node < g.nodes;
+    // K range of this wave
+    const int ksteps = g.kp / 4;
+    const int per = (ksteps + GEMM_WAVES - 1) / GEMM_WAVES;
+    const int kBeg = 4 * (wave * per < ksteps ? wave * per : ksteps);
+    const int kEnd = 4 * ((wave + 1) * per < ksteps ? (wave + 1) * per : ksteps);
+    const int kLim = kEnd < g.k ? kEnd : g.k;              // the input vector has only g.k entries
     // lanes of nodes past the end read a valid node's data and simply do not write the result
     const T *__restrict__ inp = g.in + (size_t)(nodeOk ? node : g.nodes - 1) * g.ldin + kq;
-    const T *__restrict__ Mp = g.M + r0 + col + (size_t)kq * g.mp;   // mp % 64 == 0: all GEMM_RT tiles are in bounds
+    const T *__restrict__ Mp = g.M + r0 + col + (size_t)(kBeg + kq) * g.mp;   // mp % 64 == 0: all tiles in bounds
     const size_t mstep = (size_t)4 * g.mp;
     acc_t acc[GEMM_RT];
 #pragma unroll
     for (int t = 0; t < GEMM_RT; t++) acc[t] = acc_t{0, 0, 0, 0};
-    const int kFull = g.k & ~7;
-    int k0 = 0;
-    for (; k0 < kFull; k0 += 8) {   // two k-steps per trip: 10 independent loads, then 8 MFMAs
+    int k0 = kBeg;
+    for (; k0 + 8 <= kLim; k0 += 8) {   // two k-steps per trip: 10 independent loads, then 8 MFMAs
         const T b0 = inp[k0], b1 = inp[k0 + 4];
         T a0[GEMM_RT], a1[GEMM_RT];
 #pragma unroll
@@ -419,12 +480,26 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
 #pragma unroll
         for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(a1[t], b1, acc[t]);
     }
-    for (; k0 < g.k; k0 += 4) {     // K tail: M is zero-padded in k, the input vector is not
+    for (; k0 < kLim; k0 += 4) {        // tail: M is zero-padded in k, the input vector is not
         const T b = (k0 + kq < g.k) ? inp[k0] : (T)0;
 #pragma unroll
         for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(Mp[t * 16], b, acc[t]);
         Mp += mstep;
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sh_acc[wave - 1][t * 4 + reg][lane] = acc[t][reg];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < GEMM_WAVES - 1; w++)
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) acc[t][reg] += sh_acc[w][t * 4 + reg][lane];
     if (!nodeOk) return;
     T scale = 0;
     if (EPI == EPI_V) scale = (T)(-0.5) / g.prob[node];

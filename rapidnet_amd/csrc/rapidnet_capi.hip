@@ -481,8 +481,8 @@ struct Ctx : CtxBase {
     template <int EPI>
     void launch_gemm(const T *Mp, int m, int k, const T *in, int ldin, T *out, int ldout, const T *aux, int ldaux) {
         GemmArgs<T> g{Mp, m, k, pad16(m), pad4(k), in, ldin, out, ldout, aux, ldaux, d_prob, d.nodes};
-        const int units = ((g.mp + 16 * GEMM_RT - 1) / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);
-        hipLaunchKernelGGL((k_gemm_shared<T, EPI>), dim3((units + 3) / 4), dim3(GEMM_THREADS), 0, stream, g);
+        const int units = (g.mp / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);   // one 64 x 16 output tile per workgroup
+        hipLaunchKernelGGL((k_gemm_shared<T, EPI>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
     }
     int launch_sweep() {
         SweepArgs<T> a = sweep_args();
@@ -496,7 +496,7 @@ struct Ctx : CtxBase {
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
         hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
-        const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64 && (!a.cutSums || cutStage == cs);
+        const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
         auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k)), dim3(128), 0, stream, a, d_cut);
             const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk(k) * (nv + 2 * nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
@@ -504,13 +504,12 @@ struct Ctx : CtxBase {
             RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
             return RN_OK;
         };
-        if (fusedCrown) {
-            if (a.cutSums) if (int rc = all_reduce_cut(cs - 1)) return rc;
-            hipLaunchKernelGGL(k_up_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs - 1);
-        } else {
+        {
+            const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
+            const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
             for (int k = cs - 1; k >= 0; k--) {
                 if (a.cutSums && k == cutStage - 1) if (int rc = all_reduce_cut(k)) return rc;
-                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
