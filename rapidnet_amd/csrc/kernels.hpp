@@ -503,16 +503,26 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
     if (!nodeOk) return;
     T scale = 0;
     if (EPI == EPI_V) scale = (T)(-0.5) / g.prob[node];
+    // epilogue: all auxiliary loads first (independent, clamped in-bounds), then the stores
+    T auxv[GEMM_RT][4];
+    if (EPI != EPI_LV) {
+#pragma unroll
+        for (int t = 0; t < GEMM_RT; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = r0 + t * 16 + Mfma16<T>::row(lane, reg);
+                auxv[t][reg] = g.aux[(size_t)node * g.ldaux + (gr < g.m ? gr : g.m - 1)];
+            }
+    }
 #pragma unroll
     for (int t = 0; t < GEMM_RT; t++) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int gr = r0 + t * 16 + Mfma16<T>::row(lane, reg);
-            if (gr >= g.m) continue;
             T r = acc[t][reg];
-            if (EPI == EPI_V) r = g.aux[(size_t)node * g.ldaux + gr] + scale * r;
-            if (EPI == EPI_Z) r = g.aux[(size_t)node * g.ldaux + gr] + r;
-            g.out[(size_t)node * g.ldout + gr] = r;
+            if (EPI == EPI_V) r = auxv[t][reg] + scale * r;
+            if (EPI == EPI_Z) r = auxv[t][reg] + r;
+            if (gr < g.m) g.out[(size_t)node * g.ldout + gr] = r;
         }
     }
 }
