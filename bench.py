@@ -108,7 +108,7 @@ def main():
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         s.commInit(rank, world, uid[0])
-        s.setCutStage(cut_stage)
+        s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
     s.initialiseSmpcController(dh, ah)
     s.apgReset()
 

@@ -176,9 +176,19 @@ int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
 /* stage c of the (rank-local) tree whose nodes are the roots of the sharded subtrees: the children sums of the
  * stage c-1 nodes (replicated on every rank) are all-reduced once per iteration; -1 switches sharding off. */
 int rn_set_cut_stage(rn_ctx *ctx, int stage);
+/* static tree data a shard cannot derive from its local children: for every cut parent i (stage-1 nodes of the cut, in
+ * stage order) E_i = sum over ALL children c of p_c * errorDemand_c (nd reals) and P_i = sum_c p_c.  They replace the
+ * children loop of calculateZeta (Utilities.cu:100-131) for those nodes: sum_c p_c uhat_c = Lhat (E_i + P_i dhat). */
+int rn_set_cut_children_moments(rn_ctx *ctx, const double *E /* parents*nd */, const double *P /* parents */, size_t nParents);
 /* per-iteration {max|res_xi|, signed entry, max|res_psi|, signed entry} for iterations [first, first+n), so that
  * ranks can combine their local arg-max into the tree-global vecPrimalInfs (SmpcController.cu:1480-1496) */
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out /* 4*n */);
+/* Test hooks for the sharded sweep: run rn_solve_step in two halves around the exchange -- phase 1 stops after the
+ * cut parents' LOCAL children sums are in the exchange buffer, phase 2 resumes from a buffer the caller has summed
+ * over the shards (rn_debug_cut_buffer reads / writes it: cutParents * (nv + 2 nx) reals).  rn_comm_init with
+ * id128 == NULL records rank / nranks without creating an RCCL communicator. */
+int rn_debug_sweep_phase(rn_ctx *ctx, int phase);
+int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n);
 
 #ifdef __cplusplus
 }

@@ -172,6 +172,11 @@ static int lu_inverse(int n, real *A, real *Ainv) {
     return 0;
 }
 
+/* Tests of rank-local (sharded) trees switch the reference's Omega/Theta aliasing off: a local tree may keep branching
+ * probabilities that its own shape no longer shows, so every node gets its own (p_i Rbar)^-1. */
+static int g_alias_operators = 1;
+void oracle_config_aliasing(int on) { g_alias_operators = on; }
+
 oracle_t *oracle_create(int nx, int nu, int nv, int nd, int N, int K, int nodes, int nNonLeaf,
                         const int *stages, const int *nodesPerStage, const int *nodesPerStageCumul,
                         const int *ancestor, const int *nChildren, const int *nChildrenCumul, const double *prob) {
@@ -189,6 +194,7 @@ oracle_t *oracle_create(int nx, int nu, int nv, int nd, int N, int K, int nodes,
     o->finalBranchNode = 0;
     for (int i = 0; i < N - 1; i++)
         if (nodesPerStage[i] == nodesPerStage[i + 1]) { o->finalBranchNode = nodesPerStageCumul[i + 1]; break; }
+    if (!g_alias_operators) o->finalBranchNode = nodes;
     int fb = o->finalBranchNode;
     /* operator aliasing, Engine.cu:210-221 */
     o->opIdx = (int *)malloc(nodes * sizeof(int));
@@ -427,13 +433,11 @@ static void sum_children(const oracle_t *o, const real *src, real *dst, int stag
     }
 }
 
-/* SmpcController::solveStep, SmpcController.cu:563-755 */
-void oracle_solve_step(oracle_t *o) {
-    int nx = o->nx, nu = o->nu, nv = o->nv, N = o->N, nodes = o->nodes, K = o->K;
-    real *tmpQ = ralloc((size_t)K * nx), *tmpR = ralloc((size_t)K * nv), *Lv = ralloc((size_t)K * nu);
-    memcpy(o->sigma, o->beta, (size_t)nodes * nv * sizeof(real));
-    /* backward substitution */
-    for (int k = N - 1; k > -1; k--) {
+/* backward substitution of SmpcController::solveStep (SmpcController.cu:593-673) for stages kHi .. kLo */
+void oracle_backward_range(oracle_t *o, int kHi, int kLo) {
+    int nx = o->nx, nu = o->nu, nv = o->nv, N = o->N, K = o->K;
+    real *tmpQ = ralloc((size_t)K * nx), *tmpR = ralloc((size_t)K * nv);
+    for (int k = kHi; k >= kLo; k--) {
         int cum = o->nodesPerStageCumul[k], nk = o->nodesPerStage[k];
         for (int j = 0; j < nk; j++) {
             int i = cum + j;
@@ -467,6 +471,33 @@ void oracle_solve_step(oracle_t *o) {
             }
         }
     }
+    free(tmpQ); free(tmpR);
+}
+
+void oracle_forward(oracle_t *o);
+
+/* SmpcController::solveStep, SmpcController.cu:563-755 */
+void oracle_solve_step(oracle_t *o) {
+    memcpy(o->sigma, o->beta, (size_t)o->nodes * o->nv * sizeof(real));                          /* :587 */
+    oracle_backward_range(o, o->N - 1, 0);
+    oracle_forward(o);
+}
+/* multi-GPU emulation (tests only): phase 0 runs the backward sweep down to the cut stage and leaves, in q/r, the
+ * sums over the LOCAL children of every cut parent; the caller all-reduces them over the ranks; phase 1 finishes. */
+void oracle_solve_step_phase(oracle_t *o, int phase, int cutStage) {
+    if (phase == 0) {
+        memcpy(o->sigma, o->beta, (size_t)o->nodes * o->nv * sizeof(real));
+        oracle_backward_range(o, o->N - 1, cutStage);
+    } else {
+        oracle_backward_range(o, cutStage - 1, 0);
+        oracle_forward(o);
+    }
+}
+
+/* forward substitution and Hx of SmpcController::solveStep (SmpcController.cu:676-747) */
+void oracle_forward(oracle_t *o) {
+    int nx = o->nx, nu = o->nu, nv = o->nv, N = o->N, nodes = o->nodes, K = o->K;
+    real *Lv = ralloc((size_t)K * nu);
     /* forward substitution */
     memcpy(o->u, o->uhat, (size_t)nodes * nu * sizeof(real));
     for (int k = 0; k < N; k++) {
@@ -517,7 +548,7 @@ void oracle_solve_step(oracle_t *o) {
         }
         for (int t = 0; t < nu; t++) o->primalPsi[(size_t)i * nu + t] = G[(size_t)nu * t + t] * o->u[(size_t)i * nu + t];
     }
-    free(tmpQ); free(tmpR); free(Lv);
+    free(Lv);
 }
 
 /* SmpcController::proximalFunG, SmpcController.cu:759-835.  proxW* is the vector ptrProximalXi/Psi points
@@ -634,7 +665,7 @@ real *oracle_buffer(oracle_t *o, const char *name, long *count) {
     BUF("dualXi", o->dualXi, n * 2 * nx) BUF("dualPsi", o->dualPsi, n * nu)
     BUF("resXi", o->resXi, n * 2 * nx) BUF("resPsi", o->resPsi, n * nu)
     BUF("uhat", o->uhat, n * nu) BUF("e", o->e, n * nx) BUF("beta", o->beta, n * nv) BUF("alpha", o->alpha, n * nu)
-    BUF("sigma", o->sigma, n * nv)
+    BUF("sigma", o->sigma, n * nv) BUF("q", o->q, (size_t)o->K * nx) BUF("r", o->r, (size_t)o->K * nv)
     BUF("sysF", o->sysF, n * 2 * nx * nx) BUF("sysG", o->sysG, n * nu * nu)
     BUF("xmin", o->xmin, n * nx) BUF("xmax", o->xmax, n * nx) BUF("xs", o->xs, n * nx)
     BUF("umin", o->umin, n * nu) BUF("umax", o->umax, n * nu)

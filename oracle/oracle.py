@@ -60,6 +60,7 @@ def _lib(precision):
         for fn in ("oracle_apg_reset", "oracle_solve_step", "oracle_prox", "oracle_residual", "oracle_dual_update"):
             getattr(lib, fn).argtypes = [C.c_void_p]
         lib.oracle_extrapolate.argtypes = [C.c_void_p, C.c_double]
+        lib.oracle_solve_step_phase.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.oracle_primal_infeasibility.restype = C.c_double
         lib.oracle_primal_infeasibility.argtypes = [C.c_void_p]
         lib.oracle_apg.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -100,8 +101,9 @@ def forecast_at(forecast, sim_time):
 class Oracle:
     """CPU oracle for one (network, tree, config) triple."""
 
-    def __init__(self, network, tree, config, precision="f64"):
+    def __init__(self, network, tree, config, precision="f64", alias_operators=True):
         self.lib = _lib(precision)
+        self.lib.oracle_config_aliasing(1 if alias_operators else 0)
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.network, self.tree, self.config = network, tree, config
         self.nx, self.nu, self.nd = (int(_scalar(network, k)) for k in ("nx", "nu", "nd"))
@@ -167,6 +169,10 @@ class Oracle:
 
     def solve_step(self):
         self.lib.oracle_solve_step(self.h)
+
+    def solve_step_phase(self, phase, cut_stage):
+        """tests only: backward sweep down to the cut (phase 0) / the rest (phase 1); see oracle_solve_step_phase."""
+        self.lib.oracle_solve_step_phase(self.h, int(phase), int(cut_stage))
 
     def prox(self):
         self.lib.oracle_prox(self.h)

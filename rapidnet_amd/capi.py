@@ -23,7 +23,8 @@ SYMBOLS = [
     "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
-    "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts",
+    "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
+    "rn_debug_cut_buffer", "rn_set_cut_children_moments",
 ]
 
 
@@ -93,6 +94,9 @@ def load():
     lib.rn_comm_init.argtypes = [vp, ip, ip, dp]
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
+    lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
+    lib.rn_debug_sweep_phase.argtypes = [vp, ip]
+    lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
     _LIB = lib
     return lib
 
@@ -284,11 +288,27 @@ class Solver:
 
     # ---- multi-GPU ------------------------------------------------------------------------------------------
     def commInit(self, rank, nranks, unique_id_bytes):
+        """unique_id_bytes None: record rank / nranks only (tests emulate the exchange with debugCutBuffer)."""
+        if unique_id_bytes is None:
+            self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), None))
+            return
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
         self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
 
-    def setCutStage(self, stage):
+    def debugSweepPhase(self, phase):
+        self._check(self.lib.rn_debug_sweep_phase(self.h, int(phase)))
+
+    def debugCutBuffer(self, n, values=None):
+        buf = np.zeros(n) if values is None else _f64(values)
+        self._check(self.lib.rn_debug_cut_buffer(self.h, 0 if values is None else 1, buf.ctypes.data, buf.size))
+        return buf
+
+    def setCutStage(self, stage, moments=None):
+        """moments = partition.cut_children_moments(full_tree, stage), required when nranks > 1."""
         self._check(self.lib.rn_set_cut_stage(self.h, int(stage)))
+        if moments is not None:
+            E, P = _f64(moments[0]), _f64(moments[1])
+            self._check(self.lib.rn_set_cut_children_moments(self.h, E.ctypes.data, P.ctypes.data, P.size))
 
     def historyParts(self, first, n):
         out = np.zeros(4 * n)

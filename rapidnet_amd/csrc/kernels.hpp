@@ -788,6 +788,28 @@ __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials,
     }
 }
 
+// multi-GPU variant of k_decide: fold the local partials to (d2x, d2s), all-reduce those two numbers, then decide
+__global__ void __launch_bounds__(ELT_THREADS) k_reduce_dist(const Partial *partials, int nblocks, double *out2) {
+    __shared__ double sx[ELT_THREADS], ss[ELT_THREADS];
+    double d2x = 0, d2s = 0;
+    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) { d2x += partials[b].d2x; d2s += partials[b].d2s; }
+    sx[threadIdx.x] = d2x; ss[threadIdx.x] = d2s;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { sx[threadIdx.x] += sx[threadIdx.x + off]; ss[threadIdx.x] += ss[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = sx[0]; out2[1] = ss[0]; }
+}
+__global__ void k_decide_from(const double *d2, IterState *st, double thrX, double thrS) {
+    const double dX = sqrt(d2[0]), dS = sqrt(d2[1]);
+    st->distX = dX; st->distS = dS;
+    const bool tx = dX > thrX, ts = dS > thrS;
+    st->tripped = (tx || ts) ? 1 : 0;
+    st->scaleX = tx ? 1.0 - thrX / dX : 0.0;
+    st->scaleS = ts ? 1.0 - thrS / dS : 0.0;
+}
+
 // one workgroup: primal infeasibility of this iteration (max of the signed entries at the two arg-max |.|
 // positions -- the reference's quirk) into hist[it]; advance the iteration counter.
 __global__ void __launch_bounds__(ELT_THREADS) k_finalize(const Partial *partials, int nblocks, IterState *st, double *hist,
@@ -964,6 +986,8 @@ struct AffineArgs {
     const T *errD, *errP, *dhat, *ahat, *alpha1, *prevUhat;
     T wEco; int useErrD, useErrP;
     T *e, *uhat, *alpha, *beta;
+    // multi-GPU: children moments of the cut parents (whole tree): momE [parents][nd] = sum_c p_c errD_c, momP = sum_c p_c
+    const T *momE, *momP; int cutStage;
 };
 constexpr int AFF_THREADS = 128;
 template <typename T>
@@ -992,18 +1016,30 @@ __global__ void __launch_bounds__(AFF_THREADS) k_affine_beta(AffineArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_z = reinterpret_cast<T *>(smem_raw);                 // nu  zeta
     T *sh_a = sh_z + ((a.nu + 3) & ~3);                        // nu  alpha
-    T *sh_o = sh_a + ((a.nu + 3) & ~3);                        // nv
-    T *sh_o2 = sh_o + ((a.nv + 3) & ~3);                       // nv
-    T *sh_scr = sh_o2 + ((a.nv + 3) & ~3);
+    T *sh_o = sh_a + ((a.nu + 3) & ~3);                        // max(nv, nu)
+    T *sh_o2 = sh_o + ((max(a.nv, a.nu) + 3) & ~3);            // nv
+    T *sh_d = sh_o2 + ((a.nv + 3) & ~3);                       // nd
+    T *sh_scr = sh_d + ((a.nd + 3) & ~3);
     const int node = blockIdx.x, tid = threadIdx.x, nu = a.nu;
     const int par = a.tr.parent[node];
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     const T p = a.tr.prob[node];
+    const int stage = a.tr.stageOf[node];
+    const bool presummed = a.momE != nullptr && stage == a.cutStage - 1;
+    if (presummed) {   // sum_c p_c uhat_c = Lhat (E_i + P_i dhat[stage+1]) over ALL children, local or not
+        const int pos = node - a.tr.stageCum[stage];
+        const T P = a.momP[pos];
+        for (int t = tid; t < a.nd; t += AFF_THREADS)
+            sh_d[t] = (a.useErrD ? a.momE[(size_t)pos * a.nd + t] : (T)0) + P * a.dhat[(size_t)(stage + 1) * a.nd + t];
+        __syncthreads();
+        block_gemv_shared<T>(a.Lhat, nu, a.nd, sh_d, sh_o, sh_scr, AFF_THREADS);
+    }
     for (int t = tid; t < nu; t += AFF_THREADS) {
         const T ui = a.uhat[(size_t)node * nu + t];
         const T ua = par < 0 ? a.prevUhat[t] : a.uhat[(size_t)par * nu + t];
         T z = p * (ui - ua);
-        for (int c = 0; c < nc; c++) z -= a.tr.prob[c0 + c] * (a.uhat[(size_t)(c0 + c) * nu + t] - ui);
+        if (presummed) z -= sh_o[t] - a.momP[node - a.tr.stageCum[stage]] * ui;
+        else for (int c = 0; c < nc; c++) z -= a.tr.prob[c0 + c] * (a.uhat[(size_t)(c0 + c) * nu + t] - ui);
         sh_z[t] = z;
         sh_a[t] = a.alpha[(size_t)node * nu + t];
     }

@@ -92,6 +92,9 @@ struct CtxBase {
     virtual int comm_init(int, int, const void *) = 0;
     virtual int set_cut_stage(int) = 0;
     virtual int hist_parts(int, int, double *) = 0;
+    virtual int sweep_phase(int) = 0;
+    virtual int set_cut_moments(const double *, const double *, size_t) = 0;
+    virtual int cut_buffer(int, double *, size_t) = 0;
 };
 
 // dense host helpers (fp64, column-major) ---------------------------------------------------------------
@@ -153,12 +156,14 @@ struct Ctx : CtxBase {
     T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
     T *d_tmp = nullptr;  // nodes*max(2nx,nu) staging for reference-layout get/set
     T *d_cut = nullptr;  // multi-GPU all-reduce payload
+    T *d_momE = nullptr, *d_momP = nullptr;  // multi-GPU: children moments of the cut parents (static tree data)
+    bool moments_set = false;
     // logical views (see DESIGN.md "iterate buffers")
     T *p_xi = nullptr, *p_upd = nullptr, *p_acc = nullptr, *p_acc_other = nullptr, *p_acc_view = nullptr;
     bool acc_ready = false;
     IterState *d_state = nullptr;
     Partial *d_partials = nullptr;
-    double *d_lam = nullptr, *d_hist = nullptr, *d_histParts = nullptr;
+    double *d_lam = nullptr, *d_hist = nullptr, *d_histParts = nullptr, *d_dist2 = nullptr;
     int lamCap = 0, histCap = 0;
     int h_it = 0;
     double theta0 = 1, theta1 = 1;
@@ -226,7 +231,7 @@ struct Ctx : CtxBase {
         SweepArgs<T> a{};
         a.tr = tree_dev();
         a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD; a.N = d.N; a.nodes = d.nodes;
-        a.cutSums = (nranks > 1 && cutStage > 0) ? d_cut : nullptr;
+        a.cutSums = (cutStage > 0) ? d_cut : nullptr;
         a.cutStage = cutStage;
         a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
         a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
@@ -313,7 +318,7 @@ struct Ctx : CtxBase {
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
         DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
-        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS)
+        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS) DA(d_dist2, 2)
 #undef DA
         std::vector<double> sq(nodes);
         for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
@@ -414,8 +419,10 @@ struct Ctx : CtxBase {
         a.Gd = d_Gd; a.Lhat = d_Lhat; a.WLt = d_WLt; a.Lt = d_Lt; a.errD = d_errD; a.errP = d_errP; a.dhat = d_dhat; a.ahat = d_ahat;
         a.alpha1 = d_alpha1; a.prevUhat = d_prevUhat; a.wEco = (T)wEco; a.useErrD = useErrD; a.useErrP = useErrP;
         a.e = d_e; a.uhat = d_uhat; a.alpha = d_alpha; a.beta = d_beta;
+        RN_CHECK(cutStage <= 0 || nranks == 1 || moments_set, RN_E_STATE, "sharded context: rn_set_cut_children_moments must be called before the affine terms");
+        a.momE = (cutStage > 0 && moments_set) ? d_momE : nullptr; a.momP = d_momP; a.cutStage = cutStage;
         const size_t sh1 = (size_t)(((d.nd + 3) & ~3) + ((std::max(d.nx, d.nu) + 3) & ~3) + AFF_THREADS) * sizeof(T);
-        const size_t sh2 = (size_t)(2 * ((d.nu + 3) & ~3) + 2 * ((d.nv + 3) & ~3) + AFF_THREADS) * sizeof(T);
+        const size_t sh2 = (size_t)(2 * ((d.nu + 3) & ~3) + ((std::max(d.nv, d.nu) + 3) & ~3) + ((d.nv + 3) & ~3) + ((d.nd + 3) & ~3) + AFF_THREADS) * sizeof(T);
         const hipEvent_t *e0 = prof_begin(3);
         hipLaunchKernelGGL(k_affine_demand<T>, dim3(d.nodes), dim3(AFF_THREADS), sh1, stream, a);
         hipLaunchKernelGGL(k_affine_beta<T>, dim3(d.nodes), dim3(AFF_THREADS), sh2, stream, a);
@@ -484,21 +491,29 @@ struct Ctx : CtxBase {
         const int units = (g.mp / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);   // one 64 x 16 output tile per workgroup
         hipLaunchKernelGGL((k_gemm_shared<T, EPI>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
     }
-    int launch_sweep() {
+    // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
+    // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
+    int launch_sweep(int phase = 0) {
         SweepArgs<T> a = sweep_args();
+        RN_CHECK(phase == 0 || a.cutSums, RN_E_STATE, "rn_debug_sweep_phase needs rn_set_cut_stage and nranks > 1");
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
         auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
         // (1) all per-node mat-vecs of the backward sweep in one streaming launch
-        const hipEvent_t *e0 = prof_begin(0);
-        hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
-        prof_end(e0);
-        const hipEvent_t *e1 = prof_begin(1);
+        const hipEvent_t *e0 = nullptr, *e1 = nullptr;
+        if (phase != 2) {
+            e0 = prof_begin(0);
+            hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
+            prof_end(e0);
+        }
+        e1 = prof_begin(1);
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
-        hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        if (phase != 2) hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
         const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
         auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
+            if (phase == 2) return RN_OK;              // payload already summed by the caller
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k)), dim3(128), 0, stream, a, d_cut);
+            if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
             const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk(k) * (nv + 2 * nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
                                             0 /*ncclSum*/, comm, stream);
             RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
@@ -508,7 +523,11 @@ struct Ctx : CtxBase {
             const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
             const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
             for (int k = cs - 1; k >= 0; k--) {
-                if (a.cutSums && k == cutStage - 1) if (int rc = all_reduce_cut(k)) return rc;
+                if (phase == 2 && k > cutStage - 1) continue;          // done in phase 1
+                if (a.cutSums && k == cutStage - 1) {
+                    if (int rc = all_reduce_cut(k)) return rc;
+                    if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
+                }
                 hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
@@ -536,7 +555,7 @@ struct Ctx : CtxBase {
         a.lamNext = d_lam; a.thrX = penX / stepSize; a.thrS = penXs / stepSize;
         a.st = d_state; a.partials = d_partials;
         a.crownElems = 0; a.countCrown = 1;
-        if (nranks > 1 && cutStage > 0) { a.crownElems = h_stageCum[cutStage] * ny; a.countCrown = (rank == 0); }
+        if (cutStage > 0) { a.crownElems = h_stageCum[cutStage] * ny; a.countCrown = (rank == 0); }
         return a;
     }
     int ensure_tables(int upto) {  // lambda table and history capacity for iterations [0, upto]
@@ -594,7 +613,12 @@ struct Ctx : CtxBase {
             else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             prof_end(e2);
             const hipEvent_t *e3 = prof_begin(3);
-            hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
+            if (comm && cutStage > 0) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
+                hipLaunchKernelGGL(k_reduce_dist, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
+                const int rc = g_nccl.AllReduce(d_dist2, d_dist2, 2, 8 /*ncclFloat64*/, 0 /*ncclSum*/, comm, stream);
+                RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist) failed");
+                hipLaunchKernelGGL(k_decide_from, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
+            } else hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
             if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
@@ -812,7 +836,7 @@ struct Ctx : CtxBase {
     int comm_init(int rk, int nr, const void *id) override {
         RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
         rank = rk; nranks = nr;
-        if (nr == 1) return RN_OK;
+        if (id == nullptr) return RN_OK;   // id == NULL: bookkeeping only (tests emulate the exchange)
         RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
         RN_HIP(hipSetDevice(device));
         typedef int (*init_t)(void **, int, UniqueId128, int);
@@ -822,9 +846,33 @@ struct Ctx : CtxBase {
         RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
     }
+    int sweep_phase(int phase) override {
+        RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_debug_sweep_phase before the factor step / affine terms");
+        RN_CHECK(phase == 1 || phase == 2, RN_E_ARG, "rn_debug_sweep_phase: phase must be 1 or 2");
+        RN_HIP(hipSetDevice(device));
+        p_acc_view = p_acc;
+        return launch_sweep(phase);
+    }
+    int cut_buffer(int write, double *host, size_t n) override {
+        RN_CHECK(cutStage > 0, RN_E_STATE, "rn_debug_cut_buffer: no cut stage set");
+        const size_t cnt = (size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx);
+        RN_CHECK(host && n == cnt, RN_E_ARG, "rn_debug_cut_buffer: size mismatch");
+        RN_HIP(hipSetDevice(device));
+        return write ? upload(d_cut, host, n) : download(host, d_cut, n);
+    }
+    int set_cut_moments(const double *E, const double *P, size_t nParents) override {
+        RN_CHECK(cutStage > 0, RN_E_STATE, "rn_set_cut_children_moments: set the cut stage first");
+        RN_CHECK(E && P && nParents == (size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]), RN_E_ARG, "rn_set_cut_children_moments: one row per cut parent expected");
+        RN_HIP(hipSetDevice(device));
+        if (!d_momE) { if (int rc = dalloc(&d_momE, nParents * d.nd)) return rc; if (int rc = dalloc(&d_momP, nParents)) return rc; }
+        if (int rc = upload(d_momE, E, nParents * d.nd)) return rc;
+        if (int rc = upload(d_momP, P, nParents)) return rc;
+        moments_set = true;
+        return RN_OK;
+    }
     int set_cut_stage(int c) override {
         RN_CHECK(c == -1 || (c >= 1 && c < d.N), RN_E_ARG, "rn_set_cut_stage: stage out of range");
-        cutStage = c;
+        cutStage = c; moments_set = false;
         return RN_OK;
     }
 };
@@ -889,5 +937,8 @@ int rn_comm_unique_id(void *id128) {
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128) { RN_GUARD(ctx); return ctx->impl->comm_init(rank, nranks, id128); }
 int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
+int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
+int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
+int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 
 }  // extern "C"

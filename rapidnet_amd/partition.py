@@ -65,6 +65,26 @@ def local_tree(tree, rank, world, cut_stage):
     return out, keep
 
 
+def cut_children_moments(tree, cut_stage):
+    """For every cut parent i (stage cut_stage-1 of the FULL tree): E_i = sum_c p_c errorDemand_c over ALL its
+    children and P_i = sum_c p_c.  A rank only holds its local children, but beta_i needs all of them
+    (calculateZeta, Utilities.cu:100-131: zeta_i = p_i dUhat_i - sum_c p_c (uhat_c - uhat_i) with
+    uhat_c = Lhat (errorDemand_c + dhat[stage+1])), and sum_c p_c uhat_c = Lhat (E_i + P_i dhat[stage+1])."""
+    nodes = int(tree["nodes"][0])
+    nd = int(tree["dimDemand"][0])
+    cum = np.asarray(tree["nodesPerStageCumul"], int)
+    anc = np.asarray(tree["ancestor"], int) - 1
+    p = np.asarray(tree["probNode"], float)
+    ed = np.asarray(tree["errorDemandNode"], float).reshape(nodes, nd)
+    first, n_par = cum[cut_stage - 1], cum[cut_stage] - cum[cut_stage - 1]
+    E = np.zeros((n_par, nd))
+    P = np.zeros(n_par)
+    for c in range(cum[cut_stage], cum[cut_stage + 1]):
+        E[anc[c] - first] += p[c] * ed[c]
+        P[anc[c] - first] += p[c]
+    return E, P
+
+
 def scatter_to_global(parts, global_ids, nodes, dim):
     """Reassemble a node-major vector of the full tree from per-rank local vectors (crown taken from rank 0)."""
     full = np.zeros((nodes, dim))
