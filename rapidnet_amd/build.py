@@ -33,5 +33,28 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+LIB_HOST = os.path.join(HERE, "librapidnet_host.so")
+BIN_DIR = os.path.join(HERE, "bin")
+TEST_HOST = os.path.join(BIN_DIR, "test_host")
+
+
+def build_host(force=False):
+    """librapidnet_host.so (the reference's C++ class surface over the C-ABI) and the C++ test driver."""
+    hdir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(hdir, f) for f in ("DataModel.cpp", "Engine.cpp", "SmpcController.cpp")]
+    deps = srcs + [os.path.join(hdir, f) for f in ("DataModel.hpp", "Engine.hpp", "SmpcController.hpp", "JsonLite.hpp", "Configuration.h")]
+    build_hip()
+    if force or _stale(LIB_HOST, deps + [LIB_HIP]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-fPIC", "-shared", "-o", LIB_HOST] + srcs +
+                              ["-L" + HERE, "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN"])
+    test_src = os.path.join(ROOT, "tests", "cpp", "test_host.cpp")
+    os.makedirs(BIN_DIR, exist_ok=True)
+    if force or _stale(TEST_HOST, [test_src, LIB_HOST]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-o", TEST_HOST, test_src, "-L" + HERE, "-lrapidnet_host",
+                               "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN/.."])
+    return LIB_HOST
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_host(force="--force" in sys.argv))

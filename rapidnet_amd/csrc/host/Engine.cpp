@@ -1,0 +1,72 @@
+// Engine.cpp -- see Engine.hpp.
+#include "Engine.hpp"
+
+void Engine::check(int rc, const char *what) {
+    if (rc != RN_OK) throw std::runtime_error(string(what) + ": " + rn_last_error(ctx));
+}
+
+Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device) : ctx(nullptr) {
+    ptrMySmpcConfig = smpcConfig;
+    ptrMyNetwork = new DwnNetwork(smpcConfig->getPathToNetwork());          // never deleted by the reference either
+    ptrMyScenarioTree = new ScenarioTree(smpcConfig->getPathToScenarioTree());
+    create(precision, device);
+}
+
+Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device) : ctx(nullptr) {
+    ptrMyNetwork = network; ptrMyScenarioTree = scenarioTree; ptrMySmpcConfig = smpcConfig;
+    create(precision, device);
+}
+
+void Engine::create(int precision, int device) {
+    priceUncertaintyFlag = true; demandUncertaintyFlag = true;
+    const string alg = ptrMySmpcConfig->getOptimisationAlgorithm();   // Engine.cu:151-163
+    globalFbeFlag = (alg == "globalFbeAlgorithm");
+    namaFlag = (alg == "namaAlgorithm");
+    apgFlag = !globalFbeFlag && !namaFlag;
+    _ASSERT(ptrMyNetwork->getNumTanks() == ptrMySmpcConfig->getNX() && ptrMyNetwork->getNumControls() == ptrMySmpcConfig->getNU());
+    _ASSERT(ptrMyNetwork->getNumDemands() == ptrMySmpcConfig->getND());
+    rn_dims d;
+    d.nx = ptrMyNetwork->getNumTanks(); d.nu = ptrMyNetwork->getNumControls(); d.nv = ptrMySmpcConfig->getNV();
+    d.nd = ptrMyNetwork->getNumDemands(); d.N = ptrMyScenarioTree->getPredHorizon(); d.K = ptrMyScenarioTree->getNumScenarios();
+    d.nodes = ptrMyScenarioTree->getNumNodes(); d.nNonLeafNodes = ptrMyScenarioTree->getNumNonleafNodes();
+    rn_tree t;
+    t.stages = ptrMyScenarioTree->getStageNodes(); t.nodesPerStage = ptrMyScenarioTree->getNodesPerStage();
+    t.nodesPerStageCumul = ptrMyScenarioTree->getNodesPerStageCumul(); t.ancestor = ptrMyScenarioTree->getAncestorArray();
+    t.nChildren = ptrMyScenarioTree->getNumChildren(); t.nChildrenCumul = ptrMyScenarioTree->getNumChildrenCumul();
+    t.probNode = ptrMyScenarioTree->getProbArray();
+    const int rc = rn_create(&d, &t, precision, device, &ctx);
+    if (rc != RN_OK) throw std::runtime_error(string("rn_create: ") + rn_last_error(nullptr));
+    check(rn_set_parameters(ctx, ptrMySmpcConfig->getStepSize(), ptrMySmpcConfig->getPenaltyState(), ptrMySmpcConfig->getPenaltySafety()),
+          "rn_set_parameters");
+    check(rn_set_tree_errors(ctx, ptrMyScenarioTree->getErrorDemandArray(), ptrMyScenarioTree->getErrorPriceArray()), "rn_set_tree_errors");
+}
+
+Engine::~Engine() { if (ctx) rn_destroy(ctx); }
+
+void Engine::factorStep() {
+    rn_system s;
+    s.matB = ptrMyNetwork->getMatB(); s.matGd = ptrMyNetwork->getMatGd();
+    s.matL = ptrMySmpcConfig->getMatL(); s.matLhat = ptrMySmpcConfig->getMatLhat();
+    s.costW = ptrMySmpcConfig->getCostW(); s.matDiagPrecnd = ptrMySmpcConfig->getMatPrcndDiag();
+    s.vecXmin = ptrMyNetwork->getXmin(); s.vecXmax = ptrMyNetwork->getXmax(); s.vecXsafe = ptrMyNetwork->getXsafe();
+    s.vecUmin = ptrMyNetwork->getUmin(); s.vecUmax = ptrMyNetwork->getUmax(); s.costAlpha1 = ptrMyNetwork->getAlpha();
+    check(rn_factor_step(ctx, &s), "rn_factor_step");
+}
+void Engine::updateStateControl(real_t *currentX, real_t *prevU, real_t *prevDemand) {
+    check(rn_update_state_control(ctx, currentX, prevU, prevDemand), "rn_update_state_control");
+}
+void Engine::eliminateInputDistubanceCoupling(real_t *nominalDemand, real_t *nominalPrices) {
+    check(rn_eliminate_input_disturbance_coupling(ctx, nominalDemand, nominalPrices), "rn_eliminate_input_disturbance_coupling");
+}
+void Engine::setPriceUncertaintyFlag(bool f) {
+    priceUncertaintyFlag = f;
+    check(rn_set_uncertainty(ctx, demandUncertaintyFlag, priceUncertaintyFlag, ptrMySmpcConfig->getWeightEconomical()), "rn_set_uncertainty");
+}
+void Engine::setDemandUncertaintyFlag(bool f) {
+    demandUncertaintyFlag = f;
+    check(rn_set_uncertainty(ctx, demandUncertaintyFlag, priceUncertaintyFlag, ptrMySmpcConfig->getWeightEconomical()), "rn_set_uncertainty");
+}
+size_t Engine::getBufferSize(int id) { return rn_buffer_size(ctx, id); }
+void Engine::getBuffer(int id, real_t *host) { check(rn_get(ctx, id, host, rn_buffer_size(ctx, id)), "rn_get"); }
+void Engine::setBuffer(int id, const real_t *host) { check(rn_set(ctx, id, host, rn_buffer_size(ctx, id)), "rn_set"); }
+void Engine::getOperator(int op, uint_t node, real_t *host, size_t n) { check(rn_get_operator(ctx, op, node, host, n), "rn_get_operator"); }

@@ -1,0 +1,104 @@
+// SmpcController.cpp -- see SmpcController.hpp.
+#include "SmpcController.hpp"
+
+void SmpcController::check(int rc, const char *what) {
+    if (rc != RN_OK) throw std::runtime_error(string(what) + ": " + rn_last_error(ptrMyEngine->getContext()));
+}
+
+SmpcController::SmpcController(Forecaster *f, Engine *e, SmpcConfiguration *c)
+    : ptrMyEngine(e), ptrMyForecaster(f), ptrMySmpcConfig(c), factorStepFlag(false), simulatorFlag(true), ownsObjects(false) {
+    stepSize = c->getStepSize();
+    vecPrimalInfs.assign(c->getMaxIterations() + 1, 0.0);
+    lastControl.assign(c->getNU(), 0.0);
+}
+
+SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
+    ptrMySmpcConfig = new SmpcConfiguration(pathToConfigFile);          // SmpcController.cu:78-81
+    ptrMyForecaster = new Forecaster(ptrMySmpcConfig->getPathToForecaster());
+    ptrMyEngine = new Engine(ptrMySmpcConfig);
+    stepSize = ptrMySmpcConfig->getStepSize();
+    vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
+    lastControl.assign(ptrMySmpcConfig->getNU(), 0.0);
+}
+
+// the reference never deletes the objects its path-constructor news (SmpcController.cu:2091-2102); callers that want
+// them gone delete them through the getters, exactly as the reference's tests do (Testing.cu:515-520)
+SmpcController::~SmpcController() {}
+
+void SmpcController::initialiseSmpcController() {
+    factorStepFlag = true;
+    ptrMyEngine->factorStep();
+    ptrMyEngine->updateStateControl(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(), ptrMySmpcConfig->getPrevDemand());
+    ptrMyEngine->eliminateInputDistubanceCoupling(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalPrices());
+}
+
+void SmpcController::controllerSmpc() {
+    if (!factorStepFlag) { ptrMyEngine->factorStep(); factorStepFlag = true; }
+    ptrMyEngine->updateStateControl(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(), ptrMySmpcConfig->getPrevDemand());
+    ptrMyEngine->eliminateInputDistubanceCoupling(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalPrices());
+    algorithmApg();
+}
+
+uint_t SmpcController::controlAction(real_t *u) {
+    if (!factorStepFlag) { ptrMyEngine->factorStep(); factorStepFlag = true; }
+    const int rc = rn_control_action(ptrMyEngine->getContext(), ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(),
+                                     ptrMySmpcConfig->getPrevDemand(), ptrMyForecaster->getNominalDemand(),
+                                     ptrMyForecaster->getNominalPrices(), ptrMySmpcConfig->getMaxIterations(), 0, u);
+    if (rc != RN_OK) { std::cerr << "controlAction: " << rn_last_error(ptrMyEngine->getContext()) << std::endl; return 0; }
+    for (uint_t i = 0; i < ptrMySmpcConfig->getNU(); i++) lastControl[i] = u[i];
+    return 1;
+}
+
+uint_t SmpcController::controlAction(std::fstream &out) {
+    if (!out.is_open()) return 0;
+    if (!factorStepFlag) { ptrMyEngine->factorStep(); factorStepFlag = true; }
+    const uint_t nu = ptrMySmpcConfig->getNU();
+    std::vector<real_t> u(nu);
+    const int rc = rn_control_action(ptrMyEngine->getContext(), ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(),
+                                     ptrMySmpcConfig->getPrevDemand(), ptrMyForecaster->getNominalDemand(),
+                                     ptrMyForecaster->getNominalPrices(), ptrMySmpcConfig->getMaxIterations(), 1 /* projectionBox :1649 */,
+                                     u.data());
+    if (rc != RN_OK) { std::cerr << "controlAction: " << rn_last_error(ptrMyEngine->getContext()) << std::endl; return 0; }
+    out << "\"control\" : [";                                   // same (not quite JSON) format as :1651-1658
+    for (uint_t i = 0; i < nu; i++) out << u[i] << ", ";
+    out << "]" << std::endl;
+    lastControl = u;
+    return 1;
+}
+
+// in-built simulator (simulatorFlag, SmpcController.cu:1679-1725): x+ = x + B u + e(root), then shift u, d
+void SmpcController::moveForewardInTime() {
+    DwnNetwork *net = ptrMyEngine->getDwnNetwork();
+    const uint_t nx = net->getNumTanks(), nu = net->getNumControls(), nd = net->getNumDemands();
+    std::vector<real_t> e(ptrMyEngine->getBufferSize(RN_BUF_E));
+    ptrMyEngine->getBuffer(RN_BUF_E, e.data());
+    std::vector<real_t> x(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getCurrentX() + nx);
+    const real_t *B = net->getMatB();
+    for (uint_t i = 0; i < nx; i++) {
+        real_t s = x[i] + e[i];
+        for (uint_t j = 0; j < nu; j++) s += B[i + (size_t)j * nx] * lastControl[j];
+        x[i] = s;
+    }
+    ptrMySmpcConfig->setCurrentState(x.data());
+    ptrMySmpcConfig->setPreviousControl(lastControl.data());
+    std::vector<real_t> d(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalDemand() + nd);
+    ptrMySmpcConfig->setpreviousdemand(d.data());
+}
+
+void SmpcController::dualExtrapolationStep(real_t lambda) { check(rn_dual_extrapolation_step(ptrMyEngine->getContext(), lambda), "rn_dual_extrapolation_step"); }
+void SmpcController::solveStep() {
+    if (!factorStepFlag) initialiseSmpcController();          // SmpcController.cu:579-582
+    check(rn_solve_step(ptrMyEngine->getContext()), "rn_solve_step");
+}
+void SmpcController::proximalFunG() { check(rn_proximal_fun_g(ptrMyEngine->getContext()), "rn_proximal_fun_g"); }
+void SmpcController::computeFixedPointResidual() { check(rn_compute_fixed_point_residual(ptrMyEngine->getContext()), "rn_compute_fixed_point_residual"); }
+void SmpcController::dualUpdate() { check(rn_dual_update(ptrMyEngine->getContext()), "rn_dual_update"); }
+real_t SmpcController::updatePrimalInfeasibity() {
+    double v = 0;
+    check(rn_update_primal_infeasibility(ptrMyEngine->getContext(), &v), "rn_update_primal_infeasibility");
+    return v;
+}
+uint_t SmpcController::algorithmApg() {
+    check(rn_algorithm_apg(ptrMyEngine->getContext(), ptrMySmpcConfig->getMaxIterations(), vecPrimalInfs.data()), "rn_algorithm_apg");
+    return 1;
+}

@@ -58,8 +58,8 @@ def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
             for c in range(b):
                 ancestor[first + c] = i + 1
                 prob[first + c] = prob[i] * w[c]
-                children.append(first + c + 1)
-            n_children.append(b)
+                children.append(int(first + c + 1))
+            n_children.append(int(b))
     n_nonleaf = nodes - K
     n_children_cumul = np.zeros(nodes, int)
     n_children_cumul[:n_nonleaf] = np.cumsum(n_children)
@@ -77,7 +77,7 @@ def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
         "N": [N], "K": [K], "dimDemand": [nd], "dimPrice": [nu], "nodes": [nodes],
         "nChildrenTot": [nodes - 1], "nNonLeafNodes": [n_nonleaf],
         "stages": stages.tolist(),
-        "nodesPerStage": list(per_stage) + [0],
+        "nodesPerStage": [int(v) for v in per_stage] + [0],
         "nodesPerStageCumul": cumul.tolist() + [nodes],
         "leaves": leaves.tolist(), "children": children, "ancestor": ancestor.tolist(),
         "nChildren": n_children, "nChildrenCumul": n_children_cumul.tolist(),

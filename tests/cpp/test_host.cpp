@@ -1,0 +1,233 @@
+// test_host.cpp -- C++ tests of the host classes, written the way the reference tests itself:
+//   loaders     : Testing::testNetwork / testScenarioTree / testForecaster / testControllerConfig  (src/test/Testing.cu:78-335)
+//   engine      : Testing::testEngineTesting (Testing.cu:340-477) against engineTest.json
+//   controller  : TestSmpcController::testExtrapolation / testSoveStep / testProximalStep / testFixedPointResidual /
+//                 testDualUpdate (src/test/TestSmpcController.cu:114-420) against smpcTest.json, same tolerance rule
+// usage: test_host <loaders|engine|controller|closedloop> <directory with the fixture JSON files>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+
+#include "../../rapidnet_amd/csrc/host/SmpcController.hpp"
+
+static int g_failures = 0;
+#define CHECK(cond)                                                                      \
+    do {                                                                                 \
+        if (!(cond)) { std::cerr << "FAILED " << #cond << " (" << __FILE__ << ":" << __LINE__ << ")\n"; g_failures++; } \
+    } while (0)
+
+// TestSmpcController::compareDeviceArray (TestSmpcController.cu:26-44): abs 1e-1, or 0.1 % relative above 100
+static bool closeRef(const real_t *a, const jsonlite::Value &ref, size_t n, const char *what) {
+    if (ref.Size() != n) { std::cerr << what << ": size " << ref.Size() << " vs " << n << "\n"; return false; }
+    for (size_t i = 0; i < n; i++) {
+        double v = a[i] - ref[i];
+        if (std::fabs(a[i]) > 1e2) v = v / a[i] * 100;
+        if (!(std::fabs(v) < 1e-1)) { std::cerr << what << "[" << i << "] = " << a[i] << " vs " << ref[i] << "\n"; return false; }
+    }
+    return true;
+}
+static bool closeAbs(const real_t *a, const double *ref, size_t n, double tol, const char *what) {
+    for (size_t i = 0; i < n; i++)
+        if (!(std::fabs(a[i] - ref[i]) < tol)) { std::cerr << what << "[" << i << "] = " << a[i] << " vs " << ref[i] << "\n"; return false; }
+    return true;
+}
+template <typename T> static bool sameAsJson(T *arr, const jsonlite::Value &ref, const char *what) {
+    for (size_t i = 0; i < ref.Size(); i++)
+        if (!(std::fabs((double)arr[i] - ref[i]) < 1e-2)) { std::cerr << what << "[" << i << "]\n"; return false; }  // Testing.cu:36
+    return true;
+}
+
+static void testLoaders(const string &dir) {
+    {   // Testing::testNetwork
+        DwnNetwork net(dir + "/network.json");
+        jsonlite::Document j(dir + "/network.json");
+        CHECK(net.getNumTanks() == (uint_t)j["nx"][0] && net.getNumControls() == (uint_t)j["nu"][0]);
+        CHECK(net.getNumDemands() == (uint_t)j["nd"][0] && net.getNumMixNodes() == (uint_t)j["ne"][0]);
+        CHECK(sameAsJson(net.getMatA(), j["matA"], "matA")); CHECK(sameAsJson(net.getMatB(), j["matB"], "matB"));
+        CHECK(sameAsJson(net.getMatGd(), j["matGd"], "matGd")); CHECK(sameAsJson(net.getMatE(), j["matE"], "matE"));
+        CHECK(sameAsJson(net.getMatEd(), j["matEd"], "matEd")); CHECK(sameAsJson(net.getXmin(), j["vecXmin"], "vecXmin"));
+        CHECK(sameAsJson(net.getXmax(), j["vecXmax"], "vecXmax")); CHECK(sameAsJson(net.getXsafe(), j["vecXsafe"], "vecXsafe"));
+        CHECK(sameAsJson(net.getUmin(), j["vecUmin"], "vecUmin")); CHECK(sameAsJson(net.getUmax(), j["vecUmax"], "vecUmax"));
+        CHECK(sameAsJson(net.getAlpha(), j["costAlpha1"], "costAlpha1"));
+    }
+    {   // Testing::testScenarioTree
+        ScenarioTree tree(dir + "/scenarioTree.json");
+        jsonlite::Document j(dir + "/scenarioTree.json");
+        CHECK(tree.getPredHorizon() == (uint_t)j["N"][0] && tree.getNumScenarios() == (uint_t)j["K"][0]);
+        CHECK(tree.getNumNodes() == (uint_t)j["nodes"][0] && tree.getNumNonleafNodes() == (uint_t)j["nNonLeafNodes"][0]);
+        CHECK(tree.getNumChildrenTot() == (uint_t)j["nChildrenTot"][0]);
+        CHECK(sameAsJson(tree.getStageNodes(), j["stages"], "stages"));
+        CHECK(sameAsJson(tree.getNodesPerStage(), j["nodesPerStage"], "nodesPerStage"));
+        CHECK(sameAsJson(tree.getNodesPerStageCumul(), j["nodesPerStageCumul"], "nodesPerStageCumul"));
+        CHECK(sameAsJson(tree.getLeaveArray(), j["leaves"], "leaves")); CHECK(sameAsJson(tree.getChildArray(), j["children"], "children"));
+        CHECK(sameAsJson(tree.getAncestorArray(), j["ancestor"], "ancestor"));
+        CHECK(sameAsJson(tree.getNumChildren(), j["nChildren"], "nChildren"));
+        CHECK(sameAsJson(tree.getNumChildrenCumul(), j["nChildrenCumul"], "nChildrenCumul"));
+        CHECK(sameAsJson(tree.getProbArray(), j["probNode"], "probNode"));
+        CHECK(sameAsJson(tree.getErrorDemandArray(), j["errorDemandNode"], "errorDemandNode"));
+        CHECK(sameAsJson(tree.getErrorPriceArray(), j["errorPriceNode"], "errorPriceNode"));
+        std::cout << "tree: N " << tree.getPredHorizon() << " K " << tree.getNumScenarios() << " nodes " << tree.getNumNodes()
+                  << " finalBranchNode " << tree.getFinalBranchNode() << " finalBranchStage " << tree.getFinalBranchStage() << "\n";
+    }
+    {   // Testing::testForecaster: member order 4+2t / 5+2t
+        Forecaster fc(dir + "/forecastor.json");
+        jsonlite::Document j(dir + "/forecastor.json");
+        CHECK(fc.getPredHorizon() == (uint_t)j["N"][0] && fc.getSimHorizon() == (uint_t)j["simHorizon"][0]);
+        CHECK(fc.getDimDemand() == (uint_t)j["dimDemand"][0] && fc.getDimPrice() == (uint_t)j["dimPrices"][0]);
+        for (uint_t t = 0; t < 2; t++) {
+            CHECK(fc.predictDemand(t) == 1 && fc.predictPrices(t) == 1);
+            CHECK(sameAsJson(fc.getNominalDemand(), j.MemberValue(4 + 2 * t), "nominalDemand"));
+            CHECK(sameAsJson(fc.getNominalPrices(), j.MemberValue(5 + 2 * t), "nominalPrices"));
+        }
+        CHECK(fc.predictDemand(100000) == 0);
+    }
+    {   // Testing::testControllerConfig
+        SmpcConfiguration cfg(dir + "/controllerConfig.json");
+        jsonlite::Document j(dir + "/controllerConfig.json");
+        CHECK(cfg.getNX() == (uint_t)j["nx"][0] && cfg.getNU() == (uint_t)j["nu"][0] && cfg.getND() == (uint_t)j["nd"][0] && cfg.getNV() == (uint_t)j["nv"][0]);
+        CHECK(sameAsJson(cfg.getMatL(), j["matL"], "matL")); CHECK(sameAsJson(cfg.getMatLhat(), j["matLhat"], "matLhat"));
+        CHECK(sameAsJson(cfg.getCostW(), j["costW"], "costW")); CHECK(sameAsJson(cfg.getMatPrcndDiag(), j["matDiagPrecnd"], "matDiagPrecnd"));
+        CHECK(sameAsJson(cfg.getCurrentX(), j["currentX"], "currentX")); CHECK(sameAsJson(cfg.getPrevU(), j["prevU"], "prevU"));
+        CHECK(sameAsJson(cfg.getPrevDemand(), j["prevDemand"], "prevDemand"));
+        CHECK(std::fabs(cfg.getStepSize() - j["stepSize"][0]) < 1e-12 && cfg.getMaxIterations() == (uint_t)j["maxIterations"][0]);
+        CHECK(cfg.getPenaltyState() == j["penaltyStateX"][0] && cfg.getPenaltySafety() == j["penaltySafetyX"][0]);
+        CHECK(cfg.getOptimisationAlgorithm() == j["algorithmName"].str);
+        std::vector<real_t> x(cfg.getNX(), 7.0);
+        cfg.setCurrentState(x.data()); CHECK(cfg.getCurrentX()[0] == 7.0);
+        cfg.setCurrentState(); CHECK(std::fabs(cfg.getCurrentX()[0] - j["currentX"][0]) < 1e-9);
+        cfg.setPreviousDemand(); CHECK(std::fabs(cfg.getPrevDemand()[0] - j["prevDemand"][0]) < 1e-9);   // reference bug fixed
+        CHECK(std::fabs(cfg.getPrevU()[0] - j["prevU"][0]) < 1e-9);
+    }
+    bool threw = false;
+    try { DwnNetwork missing(dir + "/does_not_exist.json"); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+}
+
+// reaches the protected step methods exactly as the reference's TestSmpcController does (TestSmpcController.cuh:80)
+class TestSmpcController : public SmpcController {
+public:
+    explicit TestSmpcController(const string &cfg) : SmpcController(cfg) {}
+    void run(const string &dir) {
+        jsonlite::Document j(dir + "/smpcTest.json");
+        const uint_t nx = getDwnNetwork()->getNumTanks(), nu = getDwnNetwork()->getNumControls(), nodes = getScenarioTree()->getNumNodes();
+        const size_t nxi = (size_t)2 * nx * nodes, nps = (size_t)nu * nodes;
+        std::vector<real_t> a(nxi), b(nps), c(nodes * (size_t)nx);
+        // testExtrapolation (:114)
+        setVector(RN_BUF_XI, j["xi"].arr.data()); setVector(RN_BUF_PSI, j["psi"].arr.data());
+        setVector(RN_BUF_UPD_XI, j["updateXi"].arr.data()); setVector(RN_BUF_UPD_PSI, j["updatePsi"].arr.data());
+        dualExtrapolationStep(j["theta"][1] * (1 / j["theta"][0] - 1));
+        getVector(RN_BUF_ACC_XI, a.data()); CHECK(closeRef(a.data(), j["acceleXi"], nxi, "acceleXi"));
+        getVector(RN_BUF_ACC_PSI, b.data()); CHECK(closeRef(b.data(), j["accelePsi"], nps, "accelePsi"));
+        getVector(RN_BUF_XI, a.data()); CHECK(closeRef(a.data(), j["finalXi"], nxi, "finalXi"));
+        getVector(RN_BUF_PSI, b.data()); CHECK(closeRef(b.data(), j["finalPsi"], nps, "finalPsi"));
+        // testSoveStep (:173)
+        setVector(RN_BUF_ACC_XI, j["acceleXi"].arr.data()); setVector(RN_BUF_ACC_PSI, j["accelePsi"].arr.data());
+        solveStep();
+        getVector(RN_BUF_X, c.data()); CHECK(closeRef(c.data(), j["X"], c.size(), "X"));
+        getVector(RN_BUF_U, b.data()); CHECK(closeRef(b.data(), j["U"], nps, "U"));
+        // testProximalStep (:221)
+        proximalFunG();
+        getVector(RN_BUF_PRIMAL_XI, a.data()); CHECK(closeRef(a.data(), j["primalX"], nxi, "primalX"));
+        getVector(RN_BUF_PRIMAL_PSI, b.data()); CHECK(closeRef(b.data(), j["primalU"], nps, "primalU"));
+        getVector(RN_BUF_DUAL_XI, a.data()); CHECK(closeRef(a.data(), j["dualX"], nxi, "dualX"));
+        getVector(RN_BUF_DUAL_PSI, b.data()); CHECK(closeRef(b.data(), j["dualU"], nps, "dualU"));
+        // testFixedPointResidual (:345)
+        setVector(RN_BUF_PRIMAL_XI, j["primalX"].arr.data()); setVector(RN_BUF_PRIMAL_PSI, j["primalU"].arr.data());
+        setVector(RN_BUF_DUAL_XI, j["dualX"].arr.data()); setVector(RN_BUF_DUAL_PSI, j["dualU"].arr.data());
+        computeFixedPointResidual();
+        getVector(RN_BUF_RES_XI, a.data()); CHECK(closeRef(a.data(), j["fixedPointResidualXi"], nxi, "fixedPointResidualXi"));
+        getVector(RN_BUF_RES_PSI, b.data()); CHECK(closeRef(b.data(), j["fixedPointResidualPsi"], nps, "fixedPointResidualPsi"));
+        // testDualUpdate (:291)
+        setVector(RN_BUF_ACC_XI, j["acceleXi"].arr.data()); setVector(RN_BUF_ACC_PSI, j["accelePsi"].arr.data());
+        setVector(RN_BUF_RES_XI, j["fixedPointResidualXi"].arr.data()); setVector(RN_BUF_RES_PSI, j["fixedPointResidualPsi"].arr.data());
+        dualUpdate();
+        getVector(RN_BUF_UPD_XI, a.data()); CHECK(closeRef(a.data(), j["finalUpdateXi"], nxi, "finalUpdateXi"));
+        getVector(RN_BUF_UPD_PSI, b.data()); CHECK(closeRef(b.data(), j["finalUpdatePsi"], nps, "finalUpdatePsi"));
+        // whole algorithm runs and produces a finite, decreasing infeasibility history
+        CHECK(algorithmApg() == 1);
+        const real_t *h = getPrimalInfeasibility();
+        CHECK(std::isfinite(h[0]) && std::isfinite(h[getSmpcConfiguration()->getMaxIterations() - 1]));
+        CHECK(std::fabs(h[getSmpcConfiguration()->getMaxIterations() - 1]) < std::fabs(h[0]));
+        std::cout << "primal infeasibility: first " << h[0] << " last " << h[getSmpcConfiguration()->getMaxIterations() - 1] << "\n";
+    }
+};
+
+static void testEngine(const string &dir) {   // Testing::testEngineTesting
+    SmpcConfiguration cfg(dir + "/controllerConfig.json");
+    Forecaster fc(dir + "/forecastor.json");
+    Engine eng(&cfg);
+    fc.predictDemand(1); fc.predictPrices(1);
+    eng.factorStep();
+    eng.updateStateControl(cfg.getCurrentX(), cfg.getPrevU(), cfg.getPrevDemand());
+    eng.eliminateInputDistubanceCoupling(fc.getNominalDemand(), fc.getNominalPrices());
+    jsonlite::Document j(dir + "/engineTest.json");
+    const uint_t nx = cfg.getNX(), nu = cfg.getNU(), nv = cfg.getNV(), N = eng.getScenarioTree()->getPredHorizon();
+    struct { int id; const char *key; } all[] = {{RN_BUF_UHAT, "uHat"}, {RN_BUF_E, "vecE"}, {RN_BUF_BETA, "beta"}, {RN_BUF_ALPHA, "costAlpha"}};
+    for (auto &q : all) {
+        std::vector<real_t> v(eng.getBufferSize(q.id));
+        eng.getBuffer(q.id, v.data());
+        CHECK(v.size() == j[q.key].Size() && closeAbs(v.data(), j[q.key].arr.data(), v.size(), 1e-2, q.key));   // Testing.cu:62
+    }
+    struct { int id; const char *key; uint_t dim; } path[] = {{RN_BUF_XMIN, "xmin", nx}, {RN_BUF_XMAX, "xmax", nx}, {RN_BUF_XS, "xs", nx},
+                                                              {RN_BUF_UMIN, "umin", nu}, {RN_BUF_UMAX, "umax", nu}};
+    for (auto &q : path) {   // compareDeviceScenarioArray: along one scenario (1-based node ids in "scenarioNodes")
+        std::vector<real_t> v(eng.getBufferSize(q.id));
+        eng.getBuffer(q.id, v.data());
+        for (uint_t i = 0; i < N; i++) {
+            const uint_t node = (uint_t)j["scenarioNodes"][i] - 1;
+            CHECK(closeAbs(v.data() + (size_t)node * q.dim, j[q.key].arr.data() + (size_t)i * q.dim, q.dim, 1e-2, q.key));
+        }
+    }
+    struct { int op; const char *key; size_t dim; uint_t count; } ops[] = {
+        {RN_OP_D, "d", (size_t)2 * nx * nv, N}, {RN_OP_F, "f", (size_t)nu * nv, N}, {RN_OP_PHI, "Phi", (size_t)2 * nx * nv, N},
+        {RN_OP_PSI, "Psi", (size_t)nu * nv, N}, {RN_OP_OMEGA, "omega", (size_t)nv * nv, eng.getScenarioTree()->getFinalBranchStage()},
+        {RN_OP_THETA, "Theta", (size_t)nx * nv, eng.getScenarioTree()->getFinalBranchStage()},
+        {RN_OP_G, "g", (size_t)nx * nv, eng.getScenarioTree()->getFinalBranchStage()}};
+    for (auto &q : ops) {
+        std::vector<real_t> v(q.dim);
+        for (uint_t i = 0; i < q.count; i++) {
+            eng.getOperator(q.op, (uint_t)j["scenarioNodes"][i] - 1, v.data(), q.dim);
+            CHECK(closeAbs(v.data(), j[q.key].arr.data() + (size_t)i * q.dim, q.dim, 1e-2, q.key));
+        }
+    }
+}
+
+// main.cu:27-63: two closed-loop control steps with the in-built simulator, control written to a stream
+static void testClosedLoop(const string &dir) {
+    SmpcController ctl(dir + "/controllerConfig.json");
+    std::fstream out((dir + "/controlOutput.tmp").c_str(), std::fstream::out);
+    std::vector<real_t> u(ctl.getSmpcConfiguration()->getNU());
+    for (uint_t t = 0; t < 2; t++) {
+        ctl.getForecaster()->predictDemand(t);
+        ctl.getForecaster()->predictPrices(t);
+        if (t == 0) ctl.initialiseSmpcController();
+        CHECK(ctl.controlAction(out) == 1);
+        ctl.moveForewardInTime();
+    }
+    CHECK(ctl.controlAction(u.data()) == 1);
+    for (real_t v : u) CHECK(std::isfinite(v));
+    out.close();
+    std::remove((dir + "/controlOutput.tmp").c_str());
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { std::cerr << "usage: test_host <loaders|engine|controller|closedloop> <fixture dir>\n"; return 2; }
+    const string mode = argv[1], dir = argv[2];
+    try {
+        if (mode == "loaders") testLoaders(dir);
+        else if (mode == "engine") testEngine(dir);
+        else if (mode == "controller") {
+            TestSmpcController t(dir + "/controllerConfig.json");
+            t.getForecaster()->predictDemand(1);   // timeInst = 1, Testing.cu:500-502
+            t.getForecaster()->predictPrices(1);
+            t.run(dir);
+        } else if (mode == "closedloop") testClosedLoop(dir);
+        else { std::cerr << "unknown mode\n"; return 2; }
+    } catch (const std::exception &e) {
+        std::cerr << "EXCEPTION: " << e.what() << "\n";
+        return 3;
+    }
+    if (g_failures) { std::cerr << g_failures << " check(s) failed\n"; return 1; }
+    std::cout << mode << ": all checks passed\n";
+    return 0;
+}

@@ -1,0 +1,36 @@
+"""The C-ABI library loads without a GPU and exports exactly the symbols include/rapidnet.h declares."""
+import os
+import re
+
+from conftest import ROOT
+from rapidnet_amd import capi
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "rapidnet.h")).read()
+    declared = set(re.findall(r"\b(rn_[a-z_0-9]+)\s*\(", hdr))
+    lib = capi.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under rapidnet_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rapidnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("Hessian oracle", ""), os.path.join(dirpath, f)
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_input():
+    import pytest
+    import torch
+
+    from rapidnet_amd import synth
+
+    p = synth.make_problem("tiny")
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.RapidNetError):
+            capi.Solver(p["network"], p["tree"], p["config"])

@@ -1,0 +1,56 @@
+"""Committed golden vectors (tests/golden/synthetic/*.npz, written by tests/golden/make_golden.py): the oracle must
+keep reproducing them (CPU), and the HIP path must match them through the C-ABI (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle.oracle import Oracle
+from rapidnet_amd import synth
+
+CASES = [("toy", 50), ("tiny", 10), ("small", 50), ("odd", 10), ("medium", 10), ("barcelona31", 1)]
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, "synthetic", name + ".npz"))
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("name,k", CASES)
+def test_oracle_reproduces_golden(name, k):
+    g = _load(name)
+    p = synth.make_problem(name)
+    assert p["config"]["stepSize"][0] == g["stepSize"][0]      # the generator is deterministic
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.initialise(dh, ah)
+    hist = o.apg(k)
+    st = int(g["stride"][0])
+    assert _rel(o.get("x")[::st], g["x_%d" % k]) < 1e-12
+    assert _rel(o.get("u")[::st], g["u_%d" % k]) < 1e-12
+    assert _rel(o.get("updXi")[::st], g["updXi_%d" % k]) < 1e-12
+    assert _rel(hist, g["hist_%d" % k]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", [("toy", 50), ("tiny", 50), ("small", 50), ("odd", 50), ("medium", 50), ("barcelona31", 10)])
+def test_hip_path_matches_golden(name, k):
+    from rapidnet_amd import capi
+
+    g = _load(name)
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    s = capi.Solver(p["network"], p["tree"], p["config"])
+    s.initialiseSmpcController(dh, ah)
+    hist = s.algorithmApg(k)
+    st = int(g["stride"][0])
+    tol = 1e-9   # BASELINE.json asks for 1e-8 relative
+    assert _rel(s.get(capi.BUF_X)[::st], g["x_%d" % k]) < tol
+    assert _rel(s.get(capi.BUF_U)[::st], g["u_%d" % k]) < tol
+    assert _rel(s.get(capi.BUF_UPD_XI)[::st], g["updXi_%d" % k]) < tol
+    assert _rel(s.get(capi.BUF_UPD_PSI)[::st], g["updPsi_%d" % k]) < tol
+    assert _rel(hist, g["hist_%d" % k]) < tol

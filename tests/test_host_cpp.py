@@ -1,0 +1,45 @@
+"""Runs the C++ tests of the host classes (tests/cpp/test_host.cpp), which mirror the reference's own harness
+(src/test/Testing.cu, src/test/TestSmpcController.cu) on the reference's fixture files."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import REF_FIXTURE, ROOT
+from rapidnet_amd import build
+
+
+def _run(mode, directory=REF_FIXTURE):
+    exe = build.TEST_HOST
+    if not os.path.exists(exe):
+        build.build_host()
+    r = subprocess.run([exe, mode, directory], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "test_host %s failed (rc %d):\n%s\n%s" % (mode, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return r.stdout
+
+
+def test_loaders_cpp():
+    out = _run("loaders")
+    assert "finalBranchNode 10 finalBranchStage 2" in out
+
+
+def test_loaders_cpp_on_synthetic_files(tmp_path):
+    from rapidnet_amd import synth
+
+    synth.write_problem(synth.make_problem("small"), str(tmp_path))
+    _run("loaders", str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_engine_cpp():
+    _run("engine")
+
+
+@pytest.mark.gpu
+def test_controller_known_answers_cpp():
+    _run("controller")
+
+
+@pytest.mark.gpu
+def test_closed_loop_cpp():
+    _run("closedloop")
