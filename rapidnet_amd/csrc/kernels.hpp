@@ -122,13 +122,16 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 // wave are always in flight.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
 // HBM bytes per node: LD*ny*sizeof(T) + (ny + 2nv + nx)*sizeof(T).
 #ifndef RN_STREAM_THREADS
-#define RN_STREAM_THREADS 512
+#define RN_STREAM_THREADS 256
 #endif
 #ifndef RN_STREAM_G
-#define RN_STREAM_G 3
+#define RN_STREAM_G 5
+#endif
+#ifndef RN_STREAM_BLOCKED
+#define RN_STREAM_BLOCKED 1
 #endif
 #ifndef RN_STREAM_MINW
-#define RN_STREAM_MINW 2
+#define RN_STREAM_MINW 3
 #endif
 constexpr int STREAM_THREADS = RN_STREAM_THREADS;
 constexpr int STREAM_WAVES = STREAM_THREADS / 64;
@@ -153,11 +156,20 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
         const bool active = rb < nRB && cp < nCP && row < LD;
         T part[RPL] = {0, 0, 0, 0};
         const T *Ab = a.A + (size_t)node * ny * LD + (active ? row : 0);
-        const int ncol = (ny - cp + nCP - 1) / nCP;            // columns of this phase: cp, cp+nCP, ...
+        // each column phase owns a CONTIGUOUS block of columns: one wave streams one contiguous region of A_i, so the
+        // 128-B lines straddling two columns are fetched once (interleaved phases re-fetched ~6 %, PMC FETCH_SIZE)
+#if RN_STREAM_BLOCKED
+        const int perPhase = (ny + nCP - 1) / nCP;
+        const int cBeg = cp * perPhase < ny ? cp * perPhase : ny, cStr = 1;
+        const int ncol = (cBeg + perPhase < ny ? cBeg + perPhase : ny) - cBeg;
+#else   // interleaved: the waves of a workgroup walk through A_i side by side (neighbouring columns at the same time)
+        const int cBeg = cp, cStr = nCP;
+        const int ncol = (ny - cp + nCP - 1) / nCP;
+#endif
         const int nG = active ? ncol / STREAM_G : 0;
         T bufA[STREAM_G][RPL], bufB[STREAM_G][RPL];
 #define RN_LOADG(buf, g_)                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) load_rows<T>(Ab + (size_t)(cp + ((g_) * STREAM_G + k) * nCP) * LD, buf[k]);
+    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) load_rows<T>(Ab + (size_t)(cBeg + ((g_) * STREAM_G + k) * cStr) * LD, buf[k]);
         // the first group of A does not depend on y: put it in flight before the prologue
         if (nG > 0) { RN_LOADG(bufA, 0) }
         if (rb0 == 0) {
@@ -171,7 +183,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
         if (active) {
 #define RN_USEG(buf, g_)                                                                                               \
     _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) {                                                             \
-        const T yc = sh_y[cp + ((g_) * STREAM_G + k) * nCP];                                                           \
+        const T yc = sh_y[cBeg + ((g_) * STREAM_G + k) * cStr];                                                        \
         _Pragma("unroll") for (int r = 0; r < RPL; r++) part[r] += buf[k][r] * yc;                                     \
     }
             if (nG > 0) {
@@ -195,7 +207,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
 #undef RN_LOADG
 #undef RN_USEG
             for (int j = nG * STREAM_G; j < ncol; j++) {           // remainder columns
-                const int c = cp + j * nCP;
+                const int c = cBeg + j * cStr;
                 T m[RPL];
                 load_rows<T>(Ab + (size_t)c * LD, m);
                 const T yc = sh_y[c];
