@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="barcelona493", help="named config of rapidnet_amd.synth.CONFIGS")
     ap.add_argument("--precision", default=None, help="f64 | f32 (default: f64, f32 for wide4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
     return ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
     if world > 1:
         cut_stage = partition.default_cut_stage(problem["tree"])
         tree, _ = partition.local_tree(problem["tree"], rank, world, cut_stage)
-    s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank)
+    s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=args.structured)
     if world > 1:
         import torch
 
@@ -150,6 +151,9 @@ def main():
         avg_s = 1e-3 * ms[0] / max(n[0], 1)
         bytes_per_launch = bwd_bytes / launches_per_sweep
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        if args.structured:   # no streaming kernel: the fused dual update is the dominant HBM kernel
+            bytes_per_launch, avg_s = dual_bytes, 1e-3 * ms[2] / max(n[2], 1)
+            achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -157,7 +161,7 @@ def main():
                 traffic = json.load(open(tpath)).get("k_stream_gemv_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+        roofline = {"kernel": "k_dual_fused" if args.structured else "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_s,
                     "launches_per_step": launches_per_sweep,
@@ -173,7 +177,7 @@ def main():
             "dtype": "f64" if precision == "f64" else "f32", "data": "synthetic",
             "config": {"workload": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (
                 args.workload, s.nx, s.nu, s.nv, s.nd, s.N, int(problem["tree"]["K"][0]), nodes_full),
-                "operator_storage": "dense per-node blocks (reference storage model)",
+                "operator_storage": "structured (shared operators, no per-node blocks)" if args.structured else "dense per-node blocks (reference storage model)",
                 "ms_per_controlStep_500it": 500 * 1e3 * dt / args.steps,
                 "parallelism": "1 GPU" if world == 1 else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
             "roofline": roofline, "kernel_classes": classes,

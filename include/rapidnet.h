@@ -108,6 +108,14 @@ int rn_destroy(rn_ctx *ctx);
 const char *rn_last_error(const rn_ctx *ctx);
 int rn_synchronize(rn_ctx *ctx);
 
+/* Operator storage, to be chosen BEFORE rn_factor_step.
+ *   RN_OPS_DENSE (default): the reference's storage model -- dense per-node blocks Phi_i, Psi_i, D_i, Ftil_i
+ *     (Engine.cu:166-189), streamed from HBM once per iteration (4.09 GB for the 493-scenario Barcelona tree).
+ *   RN_OPS_STRUCTURED: the blocks are never materialised; the factor step's own formulas (block = shared matrix x
+ *     stage diagonal x power of p_i, Engine.cu:721-745) are applied as shared-operator GEMMs.  Same iterates. */
+enum { RN_OPS_DENSE = 0, RN_OPS_STRUCTURED = 1 };
+int rn_set_operator_mode(rn_ctx *ctx, int mode);
+
 /* ---- Engine -------------------------------------------------------------------------------------- */
 /* Engine::factorStep (Engine.cu:671-774) incl. initialiseSystemDevice / preconditioning kernels. */
 int rn_factor_step(rn_ctx *ctx, const rn_system *sys);

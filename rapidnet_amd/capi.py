@@ -24,7 +24,7 @@ SYMBOLS = [
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
-    "rn_debug_cut_buffer", "rn_set_cut_children_moments",
+    "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode",
 ]
 
 
@@ -95,6 +95,7 @@ def load():
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
+    lib.rn_set_operator_mode.argtypes = [vp, ip]
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
     lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
     _LIB = lib
@@ -125,8 +126,9 @@ class Solver:
     through the C-ABI.  `problem` dicts use the reference's JSON schema.
     """
 
-    def __init__(self, network, tree, config, precision="f64", device=0):
+    def __init__(self, network, tree, config, precision="f64", device=0, structured=False):
         self.lib = load()
+        self.structured = bool(structured)
         self.network, self.tree, self.config = network, tree, config
         self.nx, self.nu, self.nd = (int(_s(network, k)) for k in ("nx", "nu", "nd"))
         self.nv = int(_s(config, "nv"))
@@ -146,6 +148,8 @@ class Solver:
         self.h = h
         self._check(self.lib.rn_set_parameters(self.h, float(_s(config, "stepSize")), float(_s(config, "penaltyStateX")),
                                                float(_s(config, "penaltySafetyX"))))
+        if self.structured:
+            self._check(self.lib.rn_set_operator_mode(self.h, 1))
         ed, ep = _f64(tree["errorDemandNode"]), _f64(tree["errorPriceNode"])
         self._check(self.lib.rn_set_tree_errors(self.h, ed.ctypes.data, ep.ctypes.data))
 

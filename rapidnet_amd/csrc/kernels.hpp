@@ -46,6 +46,8 @@ struct SweepArgs {
     const T *beta, *uhat, *e;
     const T *curX, *prevU, *prevUhat;
     const T *w;       // accelerated dual the sweep is evaluated at, [node][ny]
+    int structured;   // 1: no per-node blocks; m2_i comes from a shared-operator GEMM, m1_i is folded into the v GEMM
+    T *ab;            // structured: [node][nx+nu]  a_i = F_i' xi_i ; b_i = G_i' psi_i
     T *my;            // [node][2nv]  m1_i = Phi xi + Psi psi ; m2_i = D xi + Ftil psi
     T *qa;            // [node][nx]   a_i = F_i' xi_i
     T *sk;            // [node][nv+nx] s_i = beta_i + sum_children rho_c ; kappa_i
@@ -226,6 +228,28 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     }
 }
 
+// Structured operator mode ("shared-operator model"): every per-node block of the factor step
+// is (shared matrix) x (stage diagonal) x (power of p_i)  --  D_i = Bbt F_i', Ftil_i = L' G_i', Phi_i = -Omega_i D_i / 2,
+// Psi_i = -Omega_i Ftil_i / 2 (Engine.cu:721-745) with F_i, G_i diagonal (Utilities.cu:33-58).  Hence
+//   m2_i = D_i xi_i + Ftil_i psi_i = [Bbt | L'] [a_i; b_i],   a_i = F_i' xi_i,  b_i = G_i' psi_i     (elementwise + one GEMM)
+//   m1_i = -Rinv m2_i / (2 p_i)   is folded into  v_i = -(Rinv rho_i + Rinv Bbt kappa_i) / (2 p_i)
+// and no per-node block is ever stored or read.  This kernel is the elementwise part.
+template <typename T>
+__global__ void k_struct_prep(SweepArgs<T> a) {
+    const int nx = a.nx, nu = a.nu, ny = a.ny, w = nx + nu;
+    const long long n = (long long)a.nodes * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int node = (int)(i / w), t = (int)(i % w);
+        const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+        const T *y = a.w + (size_t)node * ny;
+        const T sp = a.tr.sqrtp[node];
+        T val;
+        if (t < nx) { val = sp * (dy[t] * y[t] + dy[nx + t] * y[nx + t]); a.qa[(size_t)node * nx + t] = val; }
+        else { const int j = t - nx; val = sp * dy[2 * nx + j] * y[2 * nx + j]; }
+        a.ab[i] = val;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Leaf-to-root recursion of the backward sweep (SmpcController.cu:593-673 + solveSumChildren
 // Utilities.cu:168-201), re-associated so that no matrix product sits on the sequential path:
@@ -264,8 +288,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a) {
                     if (k - j >= top) {
                         const size_t node = (size_t)cum[k - j] + s;
                         const T sv = b[j] + rho;                   // s_i
-                        a.sk[node * (nv + nx) + t] = sv;
                         rho = sv + m[j];
+                        a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
                     }
                 }
             }
@@ -316,8 +340,9 @@ __device__ __forceinline__ void up_crown_node(const SweepArgs<T> &a, int stage, 
                 for (int j = 0; j < CHAIN_PF; j++) sum += r[j];
             }
             const T sv = a.beta[(size_t)node * nv + t] + sum;
-            a.sk[(size_t)node * (nv + nx) + t] = sv;
-            a.rkq[(size_t)node * w + t] = sv + a.my[(size_t)node * 2 * nv + nv + t];
+            const T rho = sv + a.my[(size_t)node * 2 * nv + nv + t];
+            a.sk[(size_t)node * (nv + nx) + t] = a.structured ? rho : sv;
+            a.rkq[(size_t)node * w + t] = rho;
         } else {
             const int j0 = t - nv;
             T kap = 0, q = 0;
@@ -373,8 +398,9 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
             T sum = 0;
             for (int p = 0; p < parts; p++) sum += sh[p * w + tt];
             const T sv = a.beta[(size_t)node * nv + tt] + sum;
-            a.sk[(size_t)node * (nv + nx) + tt] = sv;
-            a.rkq[(size_t)node * w + tt] = sv + a.my[(size_t)node * 2 * nv + nv + tt];
+            const T rho = sv + a.my[(size_t)node * 2 * nv + nv + tt];
+            a.sk[(size_t)node * (nv + nx) + tt] = a.structured ? rho : sv;
+            a.rkq[(size_t)node * w + tt] = rho;
         } else {
             const int j0 = tt - nv;
             T ks = 0, qs = 0;
@@ -425,7 +451,7 @@ __global__ void k_cut_partial_sums(SweepArgs<T> a, T *out) {
 //   EPI_V : v_i  = m1_i - acc / (2 p_i)        M = [Rinv | Rinv Bbt], in = [s_i; kappa_i]     (:604-623)
 //   EPI_LV: lv_i = acc                          M = L,  in = v_i                                (:692,:701,:727)
 //   EPI_Z : z_i  = e_i + acc                    M = B,  in = u_i                                (:695,:715,:736)
-enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2 };
+enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2 };   // EPI_LV is also used for the structured m2_i = [Bbt | L'] [a_i; b_i]
 template <typename T>
 struct GemmArgs {
     const T *M; int m, k;        // logical m x k; stored zero-padded, col-major, mp x kp with mp % 64 == 0, kp % 4 == 0
@@ -955,6 +981,7 @@ struct ExpandArgs {
     const T *T1, *T2, *Bbt, *Lt;
     T *A;
     // scaled bounds in y order
+    int skipBlocks;       // structured operator mode: only the scaled bounds are produced
     const T *blo, *bhi;   // [ny] unscaled: xmin|xsafe|umin and xmax|+BIG|umax
     T *lo, *hi;           // [node][ny]
 };
@@ -970,9 +997,11 @@ __global__ void k_expand_operators(ExpandArgs<T> a) {
         const T *m1, *m2;
         if (c < 2 * a.nx) { const int j = c % a.nx; m1 = a.T1 + (size_t)j * a.nv; m2 = a.Bbt + (size_t)j * a.nv; }
         else { const int j = c - 2 * a.nx; m1 = a.T2 + (size_t)j * a.nv; m2 = a.Lt + (size_t)j * a.nv; }
-        T *col = a.A + ((size_t)node * a.ny + c) * a.LD;
-        for (int r = threadIdx.x; r < a.LD; r += blockDim.x)
-            col[r] = r < a.nv ? s1 * m1[r] : (r < 2 * a.nv ? s2 * m2[r - a.nv] : (T)0);
+        if (!a.skipBlocks) {
+            T *col = a.A + ((size_t)node * a.ny + c) * a.LD;
+            for (int r = threadIdx.x; r < a.LD; r += blockDim.x)
+                col[r] = r < a.nv ? s1 * m1[r] : (r < 2 * a.nv ? s2 * m2[r - a.nv] : (T)0);
+        }
         if (threadIdx.x == 0) {
             // bound scaling: preconditionConstraintX/U.  "+BIG" stays +BIG (no upper bound on the safety half)
             const T k = sp * d;

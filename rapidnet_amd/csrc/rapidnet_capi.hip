@@ -93,6 +93,7 @@ struct CtxBase {
     virtual int set_cut_stage(int) = 0;
     virtual int hist_parts(int, int, double *) = 0;
     virtual int sweep_phase(int) = 0;
+    virtual int set_operator_mode(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
 };
@@ -150,7 +151,9 @@ struct Ctx : CtxBase {
     T *d_beta = nullptr, *d_uhat = nullptr, *d_e = nullptr, *d_alpha = nullptr;
     T *d_x = nullptr, *d_u = nullptr, *d_v = nullptr, *d_hx = nullptr;
     T *d_my = nullptr, *d_qa = nullptr, *d_sk = nullptr, *d_rkq = nullptr, *d_lv = nullptr, *d_zz = nullptr;
-    T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
+    T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
+    int structured = 0;
+    std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
     T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
@@ -235,7 +238,7 @@ struct Ctx : CtxBase {
         a.cutStage = cutStage;
         a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
         a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
-        a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B;
+        a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B; a.structured = structured; a.ab = d_ab;
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
         a.w = p_acc; a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lv = d_lv; a.z = d_zz;
         a.x = d_x; a.u = d_u; a.hx = d_hx;
@@ -305,7 +308,6 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd;
 #define DA(ptr, cnt) if (int rc = dalloc(&ptr, (size_t)(cnt))) return rc;
         DA(d_sqrtp, n) DA(d_prob, n) DA(d_dy, (size_t)N * ny)
-        DA(d_A, n * ny * LD)
         DA(d_Rinv, nv * nv) DA(d_Bbt, nv * nx) DA(d_L, nu * nv) DA(d_B, nx * nu) DA(d_Lt, nv * nu) DA(d_WLt, nv * nu)
         DA(d_T1, nv * nx) DA(d_T2, nv * nu) DA(d_Gd, nx * nd) DA(d_Lhat, nu * nd) DA(d_alpha1, nu) DA(d_blo, ny) DA(d_bhi, ny)
         DA(d_errD, n * nd) DA(d_errP, n * nu) DA(d_dhat, (size_t)N * nd) DA(d_ahat, (size_t)N * nu)
@@ -313,6 +315,7 @@ struct Ctx : CtxBase {
         DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
         DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_hx, n * ny)
         DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lv, n * nu) DA(d_zz, n * nx)
+        DA(d_BLp, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_ab, n * (nx + nu))
         DA(d_RTp, (size_t)pad16(nv) * pad4(nv + nx)) DA(d_Lp, (size_t)pad16(nu) * pad4(nv)) DA(d_Bp, (size_t)pad16(nx) * pad4(nu))
         DA(d_lo, n * ny) DA(d_hi, n * ny) DA(d_z, n * ny) DA(d_res, n * ny)
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
@@ -369,6 +372,13 @@ struct Ctx : CtxBase {
         for (int t = 0; t < nx; t++) { blo[t] = s->vecXmin[t]; bhi[t] = s->vecXmax[t]; blo[nx + t] = s->vecXsafe[t]; bhi[nx + t] = (double)big; }
         for (int t = 0; t < nu; t++) { blo[2 * nx + t] = s->vecUmin[t]; bhi[2 * nx + t] = s->vecUmax[t]; }
 #define UP(dst, src, cnt) if (int rc = upload(dst, src, (size_t)(cnt))) return rc;
+        h_T1 = T1; h_T2 = T2; h_Lt = Lt;
+        {   // [Bbt | L'] for the structured m2 GEMM
+            std::vector<double> BL((size_t)nv * (nx + nu));
+            std::copy(h_Bbt.begin(), h_Bbt.end(), BL.begin());
+            std::copy(Lt.begin(), Lt.end(), BL.begin() + (size_t)nv * nx);
+            if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
+        }
         std::vector<double> RTm((size_t)nv * (nv + nx));
         std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
@@ -380,9 +390,13 @@ struct Ctx : CtxBase {
         UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu)
         UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
 #undef UP
+        if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
+            if (int rc = dalloc(&d_A, (size_t)d.nodes * ny * LD)) return rc;
+        }
+        RN_HIP(hipMemsetAsync(d_my, 0, (size_t)d.nodes * 2 * nv * sizeof(T), stream));   // structured mode never writes m1
         ExpandArgs<T> ea{};
         ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.nodes = d.nodes;
-        ea.T1 = d_T1; ea.T2 = d_T2; ea.Bbt = d_Bbt; ea.Lt = d_Lt; ea.A = d_A; ea.blo = d_blo; ea.bhi = d_bhi; ea.lo = d_lo; ea.hi = d_hi;
+        ea.T1 = d_T1; ea.T2 = d_T2; ea.Bbt = d_Bbt; ea.Lt = d_Lt; ea.A = d_A; ea.skipBlocks = structured; ea.blo = d_blo; ea.bhi = d_bhi; ea.lo = d_lo; ea.hi = d_hi;
         const int colChunks = std::min(ny, 8);
         hipLaunchKernelGGL(k_expand_operators<T>, dim3(d.nodes, colChunks), dim3(LD >= 192 ? 256 : (LD >= 96 ? 128 : 64)), 0, stream, ea);
         RN_HIP(hipGetLastError());
@@ -471,7 +485,7 @@ struct Ctx : CtxBase {
     int algorithmic_bytes(double *bwd, double *dual) const override {
         // k_stream_gemv, one launch = the whole tree: A_i (2nv x ny, unpadded) read once + y_i read + m1,m2,a_i written
         const double s = sizeof(T), n = d.nodes;
-        if (bwd) *bwd = n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
+        if (bwd) *bwd = structured ? 0.0 : n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
         if (dual) *dual = 7.0 * (double)ntot() * s;
         return RN_OK;
     }
@@ -502,7 +516,12 @@ struct Ctx : CtxBase {
         const hipEvent_t *e0 = nullptr, *e1 = nullptr;
         if (phase != 2) {
             e0 = prof_begin(0);
-            hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
+            if (structured) {
+                const long long tot = (long long)d.nodes * (nx + nu);
+                const int blocks = (int)std::min<long long>(4096, (tot + 255) / 256);
+                hipLaunchKernelGGL(k_struct_prep<T>, dim3(blocks), dim3(256), 0, stream, a);
+                launch_gemm<EPI_LV>(d_BLp, nv, nx + nu, d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0);
+            } else hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
             prof_end(e0);
         }
         e1 = prof_begin(1);
@@ -826,6 +845,19 @@ struct Ctx : CtxBase {
         const int cols = xiCols ? 2 * nx : nu, c0 = xiCols ? 0 : 2 * nx, r0 = top ? 0 : nv;
         RN_CHECK(n == (size_t)nv * cols, RN_E_ARG, "rn_get_operator: size");
         RN_HIP(hipSetDevice(device));
+        if (structured) {   // no stored blocks: evaluate the factor-step formula (kernels.hpp, k_expand_operators) on the host
+            const int k = h_stageOf[node];
+            const double sp = std::sqrt(p);
+            const double *dk = h_diag.data() + (size_t)k * (2 * nx + nu);
+            for (int c = 0; c < cols; c++) {
+                const int j = xiCols ? c % nx : c;
+                const double dc = xiCols ? dk[nu + c] : dk[c];
+                const double *m = top ? (xiCols ? h_T1.data() : h_T2.data()) + (size_t)j * nv : (xiCols ? h_Bbt.data() : h_Lt.data()) + (size_t)j * nv;
+                const double sc = top ? -0.5 * dc / sp : sp * dc;
+                for (int r = 0; r < nv; r++) host[r + (size_t)c * nv] = sc * m[r];
+            }
+            return RN_OK;
+        }
         std::vector<double> blk((size_t)ny * LD);
         if (int rc = download(blk.data(), d_A + (size_t)node * ny * LD, (size_t)ny * LD)) return rc;
         for (int c = 0; c < cols; c++) for (int r = 0; r < nv; r++) host[r + (size_t)c * nv] = blk[(size_t)(c0 + c) * LD + r0 + r];
@@ -859,6 +891,12 @@ struct Ctx : CtxBase {
         RN_CHECK(host && n == cnt, RN_E_ARG, "rn_debug_cut_buffer: size mismatch");
         RN_HIP(hipSetDevice(device));
         return write ? upload(d_cut, host, n) : download(host, d_cut, n);
+    }
+    int set_operator_mode(int mode) override {
+        RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_operator_mode: 0 (dense per-node blocks) or 1 (structured)");
+        RN_CHECK(!factored || mode == structured, RN_E_STATE, "rn_set_operator_mode must precede rn_factor_step");
+        structured = mode;
+        return RN_OK;
     }
     int set_cut_moments(const double *E, const double *P, size_t nParents) override {
         RN_CHECK(cutStage > 0, RN_E_STATE, "rn_set_cut_children_moments: set the cut stage first");
@@ -938,6 +976,7 @@ int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128) { RN_GUAR
 int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
+int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 

@@ -25,12 +25,12 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def make_pair(name, precision="f64", **kw):
+def make_pair(name, precision="f64", structured=False, **kw):
     p = synth.make_problem(name, **kw)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
     o.initialise(dh, ah)
-    s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision)
+    s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision, structured=structured)
     s.initialiseSmpcController(dh, ah)
     return p, o, s
 
@@ -214,3 +214,31 @@ def test_error_behaviour():
     s2 = capi.Solver(p["network"], p["tree"], sing)
     with pytest.raises(capi.RapidNetError):
         s2.factorStep()
+
+
+@pytest.mark.parametrize("name,iters", [("toy", 40), ("tiny", 40), ("small", 40), ("odd", 40), ("medium", 25), ("barcelona31", 5)])
+def test_structured_operator_mode(name, iters):
+    """RN_OPS_STRUCTURED (no per-node blocks, shared-operator GEMMs) gives the same iterates as the dense-block oracle."""
+    p, o, s = make_pair(name, structured=True)
+    nx, nu, nv = o.nx, o.nu, o.nv
+    for node in sorted(set([0, o.nodes // 2, o.nodes - 1])):   # blocks evaluated from the factor-step formulas
+        for op, oname, dim in ((capi.OP_PHI, "Phi", nv * 2 * nx), (capi.OP_D, "D", nv * 2 * nx), (capi.OP_PSI, "Psi", nv * nu),
+                               (capi.OP_F, "Ftil", nv * nu)):
+            assert relmax(s.getOperator(op, node), o.get(oname).reshape(-1, dim)[node]) < 1e-11, (oname, node)
+    hist, ohist = s.algorithmApg(iters), o.apg(iters)
+    compare_all(s, o, REL_TOL, "structured, %d iterations" % iters)
+    assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
+    # step-wise on top of the iterated state
+    s.dualExtrapolationStep(0.5); o.extrapolate(0.5)
+    s.solveStep(); o.solve_step()
+    for bid, nm in ((capi.BUF_V, "v"), (capi.BUF_U, "u"), (capi.BUF_X, "x"), (capi.BUF_PRIMAL_XI, "primalXi")):
+        assert relmax(s.get(bid), o.get(nm)) < REL_TOL, nm
+
+
+def test_structured_fp32_and_soft_branch():
+    p, o, s = make_pair("small", precision="f32", structured=True)
+    s.algorithmApg(10); o.apg(10)
+    compare_all(s, o, FP32_TOL, "structured fp32")
+    p, o, s = make_pair("small", structured=True, penalty_x=20.0, penalty_xs=5.0)
+    hist, ohist = s.algorithmApg(30), o.apg(30)
+    compare_all(s, o, REL_TOL, "structured soft branch")

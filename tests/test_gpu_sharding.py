@@ -25,8 +25,9 @@ def lambdas(n):
     return out
 
 
-@pytest.mark.parametrize("name,cut,world", [("medium", 2, 2), ("medium", 1, 2), ("small", 3, 2), ("medium", 2, 3)])
-def test_shards_on_one_gpu_match_full_tree(name, cut, world):
+@pytest.mark.parametrize("name,cut,world,structured", [("medium", 2, 2, False), ("medium", 1, 2, False), ("small", 3, 2, False),
+                                                        ("medium", 2, 3, False), ("medium", 2, 2, True)])
+def test_shards_on_one_gpu_match_full_tree(name, cut, world, structured):
     p = synth.make_problem(name)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     o = Oracle(p["network"], p["tree"], p["config"])
@@ -37,7 +38,7 @@ def test_shards_on_one_gpu_match_full_tree(name, cut, world):
     shards, ids = [], []
     for r in range(world):
         lt, gids = partition.local_tree(p["tree"], r, world, cut)
-        s = capi.Solver(p["network"], lt, p["config"])
+        s = capi.Solver(p["network"], lt, p["config"], structured=structured)
         s.commInit(r, world, None)
         s.setCutStage(cut, moments)
         s.initialiseSmpcController(dh, ah)
