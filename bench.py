@@ -102,72 +102,101 @@ def main():
     if world > 1:
         cut_stage = partition.default_cut_stage(problem["tree"])
         tree, _ = partition.local_tree(problem["tree"], rank, world, cut_stage)
-    s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=args.structured)
+    uid = None
     if world > 1:
-        import torch
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
 
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        s.commInit(rank, world, uid[0])
-        s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
-    s.initialiseSmpcController(dh, ah)
-    s.apgReset()
+    def run_mode(structured, steps, warmup, profile_steps, new_uid=None):
+        s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
+        if world > 1:
+            s.commInit(rank, world, new_uid)
+            s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
 
-    def barrier():
-        s.synchronize()
+        def barrier():
+            s.synchronize()
+            if dist is not None:
+                import torch
+
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        s.apgIterate(warmup, history=False)
+        barrier()
+        t0 = time.perf_counter()
+        s.apgIterate(steps, history=False)
+        barrier()
+        dt = time.perf_counter() - t0
         if dist is not None:
             import torch
 
-            dist.barrier()
-            torch.cuda.synchronize()
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
+        ctrl_ms = None
+        if world == 1:
+            s.controlAction(dh, ah, maxIterations=5)
+            t1 = time.perf_counter()
+            s.controlAction(dh, ah, maxIterations=500)
+            ctrl_ms = 1e3 * (time.perf_counter() - t1)
+        # per-launch hipEvent pass on the solver's own stream
+        roofline, classes = None, {}
+        if profile_steps > 0:
+            s.apgReset()
+            s.apgIterate(5, history=False)
+            s.profileEnable(1)
+            s.profileReset()
+            s.apgIterate(profile_steps, history=False)
+            ms, n = s.profileRead()
+            s.profileEnable(0)
+            bwd_bytes, dual_bytes = s.algorithmicBytes()
+            names = ("stream_gemv" if not structured else "struct_prep+gemm_m2", "recursion+shared_gemms", "dual_update", "bookkeeping")
+            for i, nm in enumerate(names):
+                classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
+            dual_s = 1e-3 * ms[2] / max(n[2], 1)
+            dual = {"achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
+                    "avg_launch_us": 1e6 * dual_s}
+            dual["frac"] = dual["achieved"] / 8000.0
+            traffic = {}
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath))
+                except Exception:
+                    traffic = {}
+            if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
+                roofline = {"kernel": "k_dual_fused", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
+                            "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"),
+                            "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
+            else:
+                avg_s = 1e-3 * ms[0] / max(n[0], 1)
+                achieved = bwd_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+                roofline = {"kernel": "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                            "frac": achieved / 8000.0, "traffic": traffic.get("k_stream_gemv_bytes_per_launch"),
+                            "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": 1e6 * avg_s, "launches_per_step": 1,
+                            "dual_update": dual}
+        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps,
+               "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
+               "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}
+        s.close()
+        return res
 
-    s.apgIterate(args.warmup, history=False)
-    barrier()
-    t0 = time.perf_counter()
-    s.apgIterate(args.steps, history=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
+    # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
+    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid)
+    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or world == 1) else None
+    head = struct if args.structured else dense
+    dt = args.steps / head["value"]
+    roofline, classes = head["roofline"], head["kernel_classes"]
+    nx, nu, nv, nd, N = head["dims"]
 
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-launch hipEvent pass on the solver's own stream (events bracket every k_backward_stage launch)
-    roofline = None
-    classes = {}
-    if args.profile_steps > 0:
-        s.profileEnable(1)
-        s.profileReset()
-        s.apgIterate(args.profile_steps, history=False)
-        ms, n = s.profileRead()
-        s.profileEnable(0)
-        bwd_bytes, dual_bytes = s.algorithmicBytes()
-        names = ("backward_sweep", "forward_sweep", "dual_update", "bookkeeping")  # 0 = k_stream_gemv, 1 = recursion + shared GEMMs
-        for i, nm in enumerate(names):
-            classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
-        launches_per_sweep = 1          # k_stream_gemv covers the whole tree in one launch
-        avg_s = 1e-3 * ms[0] / max(n[0], 1)
-        bytes_per_launch = bwd_bytes / launches_per_sweep
-        achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        if args.structured:   # no streaming kernel: the fused dual update is the dominant HBM kernel
-            bytes_per_launch, avg_s = dual_bytes, 1e-3 * ms[2] / max(n[2], 1)
-            achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_stream_gemv_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"kernel": "k_dual_fused" if args.structured else "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_s,
-                    "launches_per_step": launches_per_sweep,
-                    "dual_update": {"achieved": dual_bytes / (1e-3 * ms[2] / max(n[2], 1)) / 1e9 if ms[2] > 0 else 0.0,
-                                    "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": float(1e3 * ms[2] / max(n[2], 1))}}
-        roofline["dual_update"]["frac"] = roofline["dual_update"]["achieved"] / 8000.0
+    class _S:   # dims for the config string below
+        pass
+    s = _S()
+    s.nx, s.nu, s.nv, s.nd, s.N = nx, nu, nv, nd, N
 
     if rank == 0:
         out = {
@@ -178,10 +207,15 @@ def main():
             "config": {"workload": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (
                 args.workload, s.nx, s.nu, s.nv, s.nd, s.N, int(problem["tree"]["K"][0]), nodes_full),
                 "operator_storage": "structured (shared operators, no per-node blocks)" if args.structured else "dense per-node blocks (reference storage model)",
-                "ms_per_controlStep_500it": 500 * 1e3 * dt / args.steps,
+                "ms_per_controlStep_500it": head["ms_per_controlStep_500it_derived"],
+                "ms_per_controlStep_500it_measured": head["ms_per_controlStep_500it_measured"],
                 "parallelism": "1 GPU" if world == 1 else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
             "roofline": roofline, "kernel_classes": classes,
         }
+        if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates
+            out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",
+                                                               "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
+            out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, nodes_full)
         print(json.dumps(out))
