@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="barcelona493", help="named config of rapidnet_amd.synth.CONFIGS")
     ap.add_argument("--precision", default=None, help="f64 | f32 (default: f64, f32 for wide4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true", help="debug: run the sharded code path (partition, RCCL communicator, cut all-reduce) even with one rank")
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
     return ap.parse_args()
@@ -84,11 +85,14 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_shard
+    if sharded:
         import torch
         import torch.distributed as dist  # rendezvous, barrier and max-over-ranks only; the data path is RCCL in C
 
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:   # --force-shard without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
     from rapidnet_amd import capi, synth
     from rapidnet_amd import partition
@@ -99,18 +103,18 @@ def main():
     dh, ah = synth.forecast_at(problem["forecast"], 0)
     cut_stage = -1
     tree = problem["tree"]
-    if world > 1:
+    if sharded:
         cut_stage = partition.default_cut_stage(problem["tree"])
         tree, _ = partition.local_tree(problem["tree"], rank, world, cut_stage)
     uid = None
-    if world > 1:
+    if sharded:
         box = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
 
     def run_mode(structured, steps, warmup, profile_steps, new_uid=None):
         s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
-        if world > 1:
+        if sharded:
             s.commInit(rank, world, new_uid)
             s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
         s.initialiseSmpcController(dh, ah)
@@ -138,7 +142,7 @@ def main():
             dt = float(t.item())
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
         ctrl_ms = None
-        if world == 1:
+        if not sharded:
             s.controlAction(dh, ah, maxIterations=5)
             t1 = time.perf_counter()
             s.controlAction(dh, ah, maxIterations=500)
@@ -187,7 +191,7 @@ def main():
 
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
     dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid)
-    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or world == 1) else None
+    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or not sharded) else None
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
@@ -209,14 +213,14 @@ def main():
                 "operator_storage": "structured (shared operators, no per-node blocks)" if args.structured else "dense per-node blocks (reference storage model)",
                 "ms_per_controlStep_500it": head["ms_per_controlStep_500it_derived"],
                 "ms_per_controlStep_500it_measured": head["ms_per_controlStep_500it_measured"],
-                "parallelism": "1 GPU" if world == 1 else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
+                "parallelism": "1 GPU" if not sharded else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
             "roofline": roofline, "kernel_classes": classes,
         }
         if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates
             out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",
                                                                "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.workload, nodes_full)
         print(json.dumps(out))
     if dist is not None:

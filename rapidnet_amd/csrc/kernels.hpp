@@ -52,7 +52,10 @@ struct SweepArgs {
     T *qa;            // [node][nx]   a_i = F_i' xi_i
     T *sk;            // [node][nv+nx] s_i = beta_i + sum_children rho_c ; kappa_i
     T *rkq;           // [node][nv+2nx] rho_i, kappa_i, q_i (kept for chain tops and crown nodes)
-    T *v, *lv, *z;    // [node][nv], [node][nu] L v_i, [node][nx] e_i + B u_i
+    T *v, *lvb;       // [node][nv] ; [node][nu+nx] = [L v_i ; B L v_i]
+    const T *eb;      // [node][nx] e_i + B uhat_i (per control step)
+    const T *bw0;     // [nx] B (prevU - prevUhat)
+    T *bw;            // [node][nx] B (u_i - uhat_i), kept for the crown nodes (parents of the chain tops)
     T *x, *u, *hx;
     const T *cutSums; // multi-GPU: [cutParents][nv+2nx] all-reduced children sums, or nullptr
     int cutStage;     // stage whose parents take cutSums instead of summing their local children (-1: none)
@@ -480,7 +483,7 @@ constexpr int GEMM_WAVES = GEMM_THREADS / 64;
 constexpr int GEMM_RT = 4;       // 16-row tiles per workgroup tile (64 output rows x 16 nodes)
 // One workgroup = one 64 x 16 output tile; its 4 waves split K (contiguous quarters, multiples of 4) so that 4x more
 // waves are in flight (the loop is latency-, not MFMA-bound), partial tiles are summed through LDS by wave 0.
-template <typename T, int EPI>
+template <typename T, int EPI, int KS>
 __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
     typedef typename Mfma16<T>::acc_t acc_t;
     __shared__ T sh_acc[GEMM_WAVES - 1][GEMM_RT * 4][64];
@@ -498,31 +501,31 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
     const int per = (ksteps + GEMM_WAVES - 1) / GEMM_WAVES;
     const int kBeg = 4 * (wave * per < ksteps ? wave * per : ksteps);
     const int kEnd = 4 * ((wave + 1) * per < ksteps ? (wave + 1) * per : ksteps);
-    const int kLim = kEnd < g.k ? kEnd : g.k;              // the input vector has only g.k entries
     // lanes of nodes past the end read a valid node's data and simply do not write the result
     const T *__restrict__ inp = g.in + (size_t)(nodeOk ? node : g.nodes - 1) * g.ldin + kq;
     const T *__restrict__ Mp = g.M + r0 + col + (size_t)(kBeg + kq) * g.mp;   // mp % 64 == 0: all tiles in bounds
-    const size_t mstep = (size_t)4 * g.mp;
     acc_t acc[GEMM_RT];
 #pragma unroll
     for (int t = 0; t < GEMM_RT; t++) acc[t] = acc_t{0, 0, 0, 0};
-    int k0 = kBeg;
-    for (; k0 + 8 <= kLim; k0 += 8) {   // two k-steps per trip: 10 independent loads, then 8 MFMAs
-        const T b0 = inp[k0], b1 = inp[k0 + 4];
-        T a0[GEMM_RT], a1[GEMM_RT];
+    // every operand of this wave's K range is requested before the first MFMA (KS k-steps: 5 loads each), so the L2
+    // latency is paid once per wave instead of once per k-step pair; steps past the range get a zero B operand
+    const int nsteps = (kEnd - kBeg) / 4;
+    for (int s0 = 0; s0 < nsteps; s0 += KS) {
+        T bv[KS], av[KS][GEMM_RT];
 #pragma unroll
-        for (int t = 0; t < GEMM_RT; t++) { a0[t] = Mp[t * 16]; a1[t] = Mp[t * 16 + mstep]; }
-        Mp += 2 * mstep;
+        for (int i = 0; i < KS; i++) {
+            const int k0 = kBeg + 4 * (s0 + i);
+            const bool on = (s0 + i < nsteps);
+            const int kc = on ? k0 : kBeg;                       // in-bounds address for idle steps
+            const bool live = on && (k0 + kq < g.k);
+            bv[i] = live ? inp[live ? k0 : 0] : (T)0;          // inp already carries +kq; index 0 is always in bounds
 #pragma unroll
-        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(a0[t], b0, acc[t]);
+            for (int t = 0; t < GEMM_RT; t++) av[i][t] = Mp[t * 16 + (size_t)(kc - kBeg) * g.mp];
+        }
 #pragma unroll
-        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(a1[t], b1, acc[t]);
-    }
-    for (; k0 < kLim; k0 += 4) {        // tail: M is zero-padded in k, the input vector is not
-        const T b = (k0 + kq < g.k) ? inp[k0] : (T)0;
+        for (int i = 0; i < KS; i++)
 #pragma unroll
-        for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(Mp[t * 16], b, acc[t]);
-        Mp += mstep;
+            for (int t = 0; t < GEMM_RT; t++) acc[t] = Mfma16<T>::run(av[i][t], bv[i], acc[t]);
     }
     if (wave > 0) {
 #pragma unroll
@@ -568,91 +571,118 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
 // ------------------------------------------------------------------------------------------------------
 // Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
 // Utilities.cu:142-155) and the diagonal Hx products (:744-747):
-//   pass U:  u_i = uhat_i + (u_anc - uhat_anc) + L v_i        root: (prevU - prevUhat)
-//   pass X:  x_i = x_anc + (e_i + B u_i)                       root: currentX
+//   u_i = uhat_i + (u_anc - uhat_anc) + L v_i        root: (prevU - prevUhat)
+//   x_i = x_anc + (e_i + B u_i)                       root: currentX
 //   Hx_i = sqrt(p_i) [d_x o x_i ; d_xs o x_i ; d_u o u_i]
-template <typename T, bool PASS_X>
+// With w_i = u_i - uhat_i = w_anc + L v_i  the state recursion x_i = x_anc + e_i + B u_i becomes
+//   x_i = x_anc + (e_i + B uhat_i) + bw_i,   bw_i = B w_i = bw_anc + (B L) v_i
+// so ONE GEMM gives [L v_i ; B L v_i] and ONE pass over the tree does both recursions (eb_i = e_i + B uhat_i is
+// iteration-invariant, computed with the affine terms).
+template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a) {
     const int s = blockIdx.x;
-    const int nx = a.nx, nu = a.nu, ny = a.ny;
+    const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage;
-    const int dim = PASS_X ? nx : nu;
     const int ntop = a.tr.stageCum[top] + s;
     const int par = a.tr.parent[ntop];
     const T sp = a.tr.sqrtp[ntop];   // p is constant along a chain
-    const T *__restrict__ inc = PASS_X ? a.z : a.lv;
+    const T *__restrict__ lvb = a.lvb;
     const T *__restrict__ uhat = a.uhat;
+    const T *__restrict__ eb = a.eb;
     const T *__restrict__ dyAll = a.tr.dy;
     const int *__restrict__ cum = a.tr.stageCum;
-    for (int t = threadIdx.x; t < dim; t += CHAIN_THREADS) {
-        T run;
-        if (PASS_X) run = par < 0 ? a.curX[t] : a.x[(size_t)par * nx + t];
-        else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-        for (int k = top; k < a.N; k += CHAIN_PF) {
-            T dv[CHAIN_PF], uh[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
+    for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
+        if (t < nu) {
+            T run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+            for (int k = top; k < a.N; k += CHAIN_PF) {
+                T dv[CHAIN_PF], uh[CHAIN_PF], d0[CHAIN_PF];
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                const int kk = k + j < a.N ? k + j : a.N - 1;
-                const size_t node = (size_t)cum[kk] + s;
-                dv[j] = inc[node * dim + t];
-                if (PASS_X) { d0[j] = dyAll[(size_t)kk * ny + t]; d1[j] = dyAll[(size_t)kk * ny + nx + t]; uh[j] = 0; }
-                else { d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t]; d1[j] = 0; uh[j] = uhat[node * nu + t]; }
-            }
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const size_t node = (size_t)cum[kk] + s;
+                    dv[j] = lvb[node * w + t];
+                    uh[j] = uhat[node * nu + t];
+                    d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t];
+                }
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                if (k + j < a.N) {
-                    const size_t node = (size_t)cum[k + j] + s;
-                    run += dv[j];
-                    if (PASS_X) {
-                        a.x[node * nx + t] = run;
-                        a.hx[node * ny + t] = sp * d0[j] * run;
-                        a.hx[node * ny + nx + t] = sp * d1[j] * run;
-                    } else {
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k + j < a.N) {
+                        const size_t node = (size_t)cum[k + j] + s;
+                        run += dv[j];
                         const T uv = uh[j] + run;
                         a.u[node * nu + t] = uv;
                         a.hx[node * ny + 2 * nx + t] = sp * d0[j] * uv;
                     }
                 }
             }
+        } else {
+            const int j0 = t - nu;
+            T bw = par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0];
+            T xr = par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0];
+            for (int k = top; k < a.N; k += CHAIN_PF) {
+                T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const size_t node = (size_t)cum[kk] + s;
+                    dv[j] = lvb[node * w + nu + j0];
+                    ev[j] = eb[node * nx + j0];
+                    d0[j] = dyAll[(size_t)kk * ny + j0];
+                    d1[j] = dyAll[(size_t)kk * ny + nx + j0];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k + j < a.N) {
+                        const size_t node = (size_t)cum[k + j] + s;
+                        bw += dv[j];
+                        xr += ev[j] + bw;
+                        a.x[node * nx + j0] = xr;
+                        a.hx[node * ny + j0] = sp * d0[j] * xr;
+                        a.hx[node * ny + nx + j0] = sp * d1[j] * xr;
+                    }
+                }
+            }
         }
     }
 }
-template <typename T, bool PASS_X>
+template <typename T>
 __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads) {
     const int node = a.tr.stageCum[stage] + pos;
-    const int nx = a.nx, nu = a.nu, ny = a.ny;
+    const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int par = a.tr.parent[node];
     const T sp = a.tr.sqrtp[node];
     const T *dy = a.tr.dy + (size_t)stage * ny;
-    const int dim = PASS_X ? nx : nu;
-    for (int t = tid; t < dim; t += nthreads) {
-        if (PASS_X) {
-            const T xv = (par < 0 ? a.curX[t] : a.x[(size_t)par * nx + t]) + a.z[(size_t)node * nx + t];
-            a.x[(size_t)node * nx + t] = xv;
-            a.hx[(size_t)node * ny + t] = sp * dy[t] * xv;
-            a.hx[(size_t)node * ny + nx + t] = sp * dy[nx + t] * xv;
-        } else {
+    for (int t = tid; t < w; t += nthreads) {
+        if (t < nu) {
             const T wanc = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-            const T uv = a.uhat[(size_t)node * nu + t] + wanc + a.lv[(size_t)node * nu + t];
+            const T uv = a.uhat[(size_t)node * nu + t] + wanc + a.lvb[(size_t)node * w + t];
             a.u[(size_t)node * nu + t] = uv;
             a.hx[(size_t)node * ny + 2 * nx + t] = sp * dy[2 * nx + t] * uv;
+        } else {
+            const int j0 = t - nu;
+            const T bw = (par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0]) + a.lvb[(size_t)node * w + nu + j0];
+            const T xv = (par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0]) + a.eb[(size_t)node * nx + j0] + bw;
+            a.bw[(size_t)node * nx + j0] = bw;
+            a.x[(size_t)node * nx + j0] = xv;
+            a.hx[(size_t)node * ny + j0] = sp * dy[j0] * xv;
+            a.hx[(size_t)node * ny + nx + j0] = sp * dy[nx + j0] * xv;
         }
     }
 }
-template <typename T, bool PASS_X>
+template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_crown(SweepArgs<T> a, int stage) {
-    down_crown_node<T, PASS_X>(a, stage, blockIdx.x, threadIdx.x, CHAIN_THREADS);
+    down_crown_node<T>(a, stage, blockIdx.x, threadIdx.x, CHAIN_THREADS);
 }
-template <typename T, bool PASS_X>
+template <typename T>
 __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a, int nStages) {
-    const int per = PASS_X ? a.nx : a.nu;
+    const int per = a.nx + a.nu;
     for (int k = 0; k < nStages; k++) {
         const int nk = a.tr.stageCum[k + 1] - a.tr.stageCum[k];
         const int lanesPerNode = per < CROWN_THREADS ? ((per + 63) / 64) * 64 : CROWN_THREADS;
         const int nodesPerPass = CROWN_THREADS / lanesPerNode;
         for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
             const int pos = p0 + threadIdx.x / lanesPerNode;
-            if (pos < nk && threadIdx.x / lanesPerNode < nodesPerPass) down_crown_node<T, PASS_X>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
+            if (pos < nk && threadIdx.x / lanesPerNode < nodesPerPass) down_crown_node<T>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
         }
         __threadfence_block();
         __syncthreads();
@@ -667,7 +697,8 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 //   t = hx + w/lambda ; z = clamp(t, lo, hi) [+ sc_half (t - clamp) when the soft-constraint branch trips]
 //   res = hx - z ; ynew = w + lambda res ; wnext = (1 + ln) ynew - ln yprev
 struct IterState {         // device-resident scalars of the APG loop
-    int it;                // iteration counter (incremented by k_finalize)
+    int it;                // iteration counter (incremented by k_finalize / k_decide_finalize)
+    unsigned int ticket;   // arrival counter of the fix-up kernel's blocks (rare path only)
     int tripped;           // soft-constraint branch taken in this iteration
     double scaleX, scaleS; // 1 - gamma/(lambda dist) for the two halves (0 when not tripped)
     double distX, distS;   // tree-global distances of this iteration
@@ -692,6 +723,8 @@ struct DualArgs {
     Partial *partials;     // [gridDim.x]
     int crownElems;        // multi-GPU: leading elements replicated on every rank (counted once, on rank 0)
     int countCrown;
+    int finalizedEarly;    // 1: k_decide_finalize already wrote hist[it] and advanced it; the fix-up must redo hist[it-1]
+    double *hist, *histParts; int histCap;
 };
 
 __device__ __forceinline__ void better(double &a, double &v, long long &i, double a2, double v2, long long i2) {
@@ -727,7 +760,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
         if (!a.st->tripped) return;   // common case: nothing to redo
         scX = (T)a.st->scaleX; scS = (T)a.st->scaleS;
     }
-    const T ln = (T)a.lamNext[a.st->it + 1];
+    // the fix-up runs after the iteration counter has been advanced (single-GPU path: k_decide_finalize)
+    const int itIdx = (FIXUP && a.finalizedEarly) ? a.st->it - 1 : a.st->it;
+    const T ln = (T)a.lamNext[itIdx + 1];
     const T lambda = a.lambda, invLambda = a.invLambda;
     const int nx = a.nx, ny = a.ny;
     double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
@@ -800,6 +835,80 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
             better(p.absPsi, p.valPsi, p.idxPsi, sh_p[k].absPsi, sh_p[k].valPsi, sh_p[k].idxPsi);
         }
         a.partials[blockIdx.x] = p;
+        if (FIXUP && a.finalizedEarly) {
+            // rare path: the residual changed, so the history entry written by k_decide_finalize must be redone by
+            // the last block to arrive (release -> ticket -> acquire, Guideline 16)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int t = atomicAdd(&a.st->ticket, 1u);
+            if (t == gridDim.x - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                double aX = -1, vX = 0, aP = -1, vP = 0;
+                long long iX = 0x7fffffffffffffffLL, iP = 0x7fffffffffffffffLL;
+                for (unsigned int b = 0; b < gridDim.x; b++) {
+                    const Partial q = a.partials[b];
+                    better(aX, vX, iX, q.absXi, q.valXi, q.idxXi);
+                    better(aP, vP, iP, q.absPsi, q.valPsi, q.idxPsi);
+                }
+                const int it = a.st->it - 1;
+                if (it >= 0 && it < a.histCap) {
+                    a.hist[it] = vX > vP ? vX : vP;
+                    a.histParts[4 * (size_t)it + 0] = aX; a.histParts[4 * (size_t)it + 1] = vX;
+                    a.histParts[4 * (size_t)it + 2] = aP; a.histParts[4 * (size_t)it + 3] = vP;
+                }
+                a.st->ticket = 0;
+            }
+        }
+    }
+}
+
+// single-GPU bookkeeping in ONE launch: k_decide + k_finalize (the fix-up kernel then redoes the history entry itself
+// if, and only if, the soft-constraint branch tripped)
+__global__ void __launch_bounds__(ELT_THREADS) k_decide_finalize(const Partial *partials, int nblocks, IterState *st, double thrX,
+                                                                 double thrS, double *hist, double *histParts, int histCap) {
+    __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
+    __shared__ Partial sh[ELT_THREADS / 64];
+    double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
+    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
+    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
+        const Partial q = partials[b];
+        d2x += q.d2x; d2s += q.d2s;
+        better(absXi, valXi, idxXi, q.absXi, q.valXi, q.idxXi);
+        better(absPsi, valPsi, idxPsi, q.absPsi, q.valPsi, q.idxPsi);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off);
+        const double a2 = __shfl_down(absXi, off), v2 = __shfl_down(valXi, off);
+        const long long i2 = __shfl_down(idxXi, off);
+        better(absXi, valXi, idxXi, a2, v2, i2);
+        const double a3 = __shfl_down(absPsi, off), v3 = __shfl_down(valPsi, off);
+        const long long i3 = __shfl_down(idxPsi, off);
+        better(absPsi, valPsi, idxPsi, a3, v3, i3);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sx[wave] = d2x; ss[wave] = d2s; sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi}; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Partial p = sh[0];
+        double tx2 = sx[0], ts2 = ss[0];
+        for (int k = 1; k < ELT_THREADS / 64; k++) {
+            tx2 += sx[k]; ts2 += ss[k];
+            better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
+            better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
+        }
+        const double dX = sqrt(tx2), dS = sqrt(ts2);
+        st->distX = dX; st->distS = dS;
+        const bool trX = dX > thrX, trS = dS > thrS;
+        st->tripped = (trX || trS) ? 1 : 0;
+        st->scaleX = trX ? 1.0 - thrX / dX : 0.0;
+        st->scaleS = trS ? 1.0 - thrS / dS : 0.0;
+        const int it = st->it;
+        if (it < histCap) {
+            hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
+            histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
+            histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
+        }
+        st->it = it + 1;
     }
 }
 
@@ -1091,6 +1200,14 @@ __global__ void __launch_bounds__(AFF_THREADS) k_affine_beta(AffineArgs<T> a) {
 }
 
 // small utilities ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_bw0(const T *B, int nx, int nu, const T *prevU, const T *prevUhat, T *bw0) {   // bw0 = B (prevU - prevUhat)
+    for (int r = threadIdx.x; r < nx; r += blockDim.x) {
+        T s = 0;
+        for (int j = 0; j < nu; j++) s += B[r + (size_t)j * nx] * (prevU[j] - prevUhat[j]);
+        bw0[r] = s;
+    }
+}
 template <typename T>
 __global__ void k_gemv_small(const T *M, int rows, int cols, const T *x, T *y) {   // y = M x, one block
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {

@@ -16,6 +16,10 @@
 #include "../../include/rapidnet.h"
 #include "kernels.hpp"
 
+#ifndef RN_GEMM_KS
+#define RN_GEMM_KS 3   // k-steps whose operands a wave requests at once in k_gemm_shared (tuning knob)
+#endif
+
 namespace rn {
 
 #define RN_HIP(call)                                                                                   \
@@ -150,7 +154,9 @@ struct Ctx : CtxBase {
     T *d_curX = nullptr, *d_prevU = nullptr, *d_prevUhat = nullptr, *d_prevD = nullptr;
     T *d_beta = nullptr, *d_uhat = nullptr, *d_e = nullptr, *d_alpha = nullptr;
     T *d_x = nullptr, *d_u = nullptr, *d_v = nullptr, *d_hx = nullptr;
-    T *d_my = nullptr, *d_qa = nullptr, *d_sk = nullptr, *d_rkq = nullptr, *d_lv = nullptr, *d_zz = nullptr;
+    T *d_my = nullptr, *d_qa = nullptr, *d_sk = nullptr, *d_rkq = nullptr, *d_lvb = nullptr, *d_eb = nullptr, *d_bw0 = nullptr, *d_bw = nullptr;
+    T *d_LBLp = nullptr;
+    bool aux_dirty = true;   // eb = e + B uhat and bw0 = B (prevU - prevUhat) must be refreshed before the next sweep
     T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
     int structured = 0;
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
@@ -240,7 +246,7 @@ struct Ctx : CtxBase {
         a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
         a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B; a.structured = structured; a.ab = d_ab;
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
-        a.w = p_acc; a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lv = d_lv; a.z = d_zz;
+        a.w = p_acc; a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
         a.x = d_x; a.u = d_u; a.hx = d_hx;
         return a;
     }
@@ -314,7 +320,8 @@ struct Ctx : CtxBase {
         DA(d_curX, nx) DA(d_prevU, nu) DA(d_prevUhat, nu) DA(d_prevD, nd)
         DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
         DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_hx, n * ny)
-        DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lv, n * nu) DA(d_zz, n * nx)
+        DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lvb, n * (nu + nx)) DA(d_eb, n * nx) DA(d_bw0, nx) DA(d_bw, n * nx)
+        DA(d_LBLp, (size_t)pad16(nu + nx) * pad4(nv))
         DA(d_BLp, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_ab, n * (nx + nu))
         DA(d_RTp, (size_t)pad16(nv) * pad4(nv + nx)) DA(d_Lp, (size_t)pad16(nu) * pad4(nv)) DA(d_Bp, (size_t)pad16(nx) * pad4(nu))
         DA(d_lo, n * ny) DA(d_hi, n * ny) DA(d_z, n * ny) DA(d_res, n * ny)
@@ -379,6 +386,15 @@ struct Ctx : CtxBase {
             std::copy(Lt.begin(), Lt.end(), BL.begin() + (size_t)nv * nx);
             if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
         }
+        {   // [L ; B L]  ((nu+nx) x nv) for the forward GEMM
+            std::vector<double> BLm((size_t)nx * nv), LBL((size_t)(nu + nx) * nv);
+            h_gemm(false, false, nx, nv, nu, s->matB, nx, s->matL, nu, BLm.data());
+            for (int j = 0; j < nv; j++) {
+                for (int i = 0; i < nu; i++) LBL[i + (size_t)j * (nu + nx)] = s->matL[i + (size_t)j * nu];
+                for (int i = 0; i < nx; i++) LBL[nu + i + (size_t)j * (nu + nx)] = BLm[i + (size_t)j * nx];
+            }
+            if (int rc = upload_padded(d_LBLp, LBL.data(), nu + nx, nv)) return rc;
+        }
         std::vector<double> RTm((size_t)nv * (nv + nx));
         std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
@@ -420,6 +436,7 @@ struct Ctx : CtxBase {
         if (int rc = upload(d_prevD, dp, d.nd)) return rc;
         hipLaunchKernelGGL(k_gemv_small<T>, dim3(1), dim3(128), 0, stream, d_Lhat, d.nu, d.nd, d_prevD, d_prevUhat);  // Engine.cu:1314
         RN_HIP(hipGetLastError());
+        aux_dirty = true;
         return RN_OK;
     }
     int eliminate(const double *dhat, const double *ahat) override {
@@ -442,7 +459,7 @@ struct Ctx : CtxBase {
         hipLaunchKernelGGL(k_affine_beta<T>, dim3(d.nodes), dim3(AFF_THREADS), sh2, stream, a);
         prof_end(e0);
         RN_HIP(hipGetLastError());
-        affine_ready = true;
+        affine_ready = true; aux_dirty = true;
         return RN_OK;
     }
     int set_parameters(double step, double px, double pxs) override {
@@ -503,7 +520,7 @@ struct Ctx : CtxBase {
     void launch_gemm(const T *Mp, int m, int k, const T *in, int ldin, T *out, int ldout, const T *aux, int ldaux) {
         GemmArgs<T> g{Mp, m, k, pad16(m), pad4(k), in, ldin, out, ldout, aux, ldaux, d_prob, d.nodes};
         const int units = (g.mp / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);   // one 64 x 16 output tile per workgroup
-        hipLaunchKernelGGL((k_gemm_shared<T, EPI>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
+        hipLaunchKernelGGL((k_gemm_shared<T, EPI, RN_GEMM_KS>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
     }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
     // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
@@ -513,6 +530,11 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
         auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
         // (1) all per-node mat-vecs of the backward sweep in one streaming launch
+        if (aux_dirty) {   // iteration-invariant pieces of the forward sweep (once per control step)
+            launch_gemm<EPI_Z>(d_Bp, nx, nu, d_uhat, nu, d_eb, nx, d_e, nx);            // eb_i = e_i + B uhat_i
+            hipLaunchKernelGGL(k_bw0<T>, dim3(1), dim3(128), 0, stream, d_B, nx, nu, d_prevU, d_prevUhat, d_bw0);
+            aux_dirty = false;
+        }
         const hipEvent_t *e0 = nullptr, *e1 = nullptr;
         if (phase != 2) {
             e0 = prof_begin(0);
@@ -552,15 +574,11 @@ struct Ctx : CtxBase {
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
         launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
-        launch_gemm<EPI_LV>(d_Lp, nu, nv, d_v, nv, d_lv, nu, nullptr, 0);
-        // (4) root-to-leaf: u, then z_i = e_i + B u_i, then x and Hx
-        if (fusedCrown) hipLaunchKernelGGL((k_down_crown_all<T, false>), dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
-        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL((k_down_crown<T, false>), dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
-        hipLaunchKernelGGL((k_down_chain<T, false>), dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
-        launch_gemm<EPI_Z>(d_Bp, nx, nu, d_u, nu, d_zz, nx, d_e, nx);
-        if (fusedCrown) hipLaunchKernelGGL((k_down_crown_all<T, true>), dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
-        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL((k_down_crown<T, true>), dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
-        hipLaunchKernelGGL((k_down_chain<T, true>), dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
+        // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
+        if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
+        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
@@ -574,6 +592,7 @@ struct Ctx : CtxBase {
         a.lamNext = d_lam; a.thrX = penX / stepSize; a.thrS = penXs / stepSize;
         a.st = d_state; a.partials = d_partials;
         a.crownElems = 0; a.countCrown = 1;
+        a.finalizedEarly = 0; a.hist = d_hist; a.histParts = d_histParts; a.histCap = histCap;
         if (cutStage > 0) { a.crownElems = h_stageCum[cutStage] * ny; a.countCrown = (rank == 0); }
         return a;
     }
@@ -637,10 +656,16 @@ struct Ctx : CtxBase {
                 const int rc = g_nccl.AllReduce(d_dist2, d_dist2, 2, 8 /*ncclFloat64*/, 0 /*ncclSum*/, comm, stream);
                 RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist) failed");
                 hipLaunchKernelGGL(k_decide_from, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
-            } else hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
-            if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-            else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
+                if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+                else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
+            } else {   // single GPU: decide + finalize in one launch; the (early-exit) fix-up redoes the history if it trips
+                hipLaunchKernelGGL(k_decide_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS,
+                                   d_hist, d_histParts, histCap);
+                a.finalizedEarly = 1;
+                if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+                else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            }
             prof_end(e3);
             // rotate: y_t := y+_{t-1} (old upd), y+_t := buffer just written; w_{t+1} becomes the sweep input
             std::swap(p_xi, p_upd);
@@ -823,7 +848,7 @@ struct Ctx : CtxBase {
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr, RN_E_ARG, "rn_set: unknown buffer id");
         RN_CHECK(n == cnt, RN_E_ARG, "rn_set: size mismatch");
-        if (id == RN_BUF_UHAT || id == RN_BUF_E || id == RN_BUF_BETA) affine_ready = true;
+        if (id == RN_BUF_UHAT || id == RN_BUF_E || id == RN_BUF_BETA) { affine_ready = true; aux_dirty = true; }
         return upload(p, host, n);
     }
     int get_operator(int op, int node, double *host, size_t n) override {
