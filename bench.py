@@ -167,8 +167,8 @@ def main():
             dual["frac"] = dual["achieved"] / 8000.0
             traffic = {}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
+            if os.path.exists(tpath) and args.workload == "barcelona493" and precision == "f64" and not sharded:
+                try:   # PMC counters were collected on exactly this workload (profiles/traffic.json says how)
                     traffic = json.load(open(tpath))
                 except Exception:
                     traffic = {}
