@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="barcelona493", help="named config of rapidnet_amd.synth.CONFIGS")
     ap.add_argument("--precision", default=None, help="f64 | f32 (default: f64, f32 for wide4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-only", action="store_true", help="skip the structured-mode pass (tuning sweeps)")
     ap.add_argument("--force-shard", action="store_true", help="debug: run the sharded code path (partition, RCCL communicator, cut all-reduce) even with one rank")
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
@@ -191,7 +192,7 @@ def main():
 
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
     dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid)
-    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or not sharded) else None
+    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or (not sharded and not args.dense_only)) else None
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
