@@ -147,6 +147,10 @@ int rn_control_action(rn_ctx *ctx, const double *currentX, const double *prevU, 
                       const double *nominalDemand, const double *nominalPrices, int maxIterations,
                       int projectOnBounds, double *u0);
 
+/* Extension (the reference always cold-starts, SmpcController.cu:1509): when on,
+ * rn_control_action keeps the duals of the previous control step and only restarts the momentum. */
+int rn_set_warm_start(rn_ctx *ctx, int on);
+
 /* step-wise entry points mirroring the protected methods the reference's known-answer tests call */
 int rn_dual_extrapolation_step(rn_ctx *ctx, double lambda); /* SmpcController.cu:535-557  */
 int rn_solve_step(rn_ctx *ctx);                             /* SmpcController.cu:563-755  */

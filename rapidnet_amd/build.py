@@ -41,8 +41,8 @@ TEST_HOST = os.path.join(BIN_DIR, "test_host")
 def build_host(force=False):
     """librapidnet_host.so (the reference's C++ class surface over the C-ABI) and the C++ test driver."""
     hdir = os.path.join(CSRC, "host")
-    srcs = [os.path.join(hdir, f) for f in ("DataModel.cpp", "Engine.cpp", "SmpcController.cpp")]
-    deps = srcs + [os.path.join(hdir, f) for f in ("DataModel.hpp", "Engine.hpp", "SmpcController.hpp", "JsonLite.hpp", "Configuration.h")]
+    srcs = [os.path.join(hdir, f) for f in ("DataModel.cpp", "Engine.cpp", "SmpcController.cpp", "NullSpace.cpp")]
+    deps = srcs + [os.path.join(hdir, f) for f in ("DataModel.hpp", "Engine.hpp", "SmpcController.hpp", "JsonLite.hpp", "Configuration.h", "NullSpace.hpp")]
     build_hip()
     if force or _stale(LIB_HOST, deps + [LIB_HIP]):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-fPIC", "-shared", "-o", LIB_HOST] + srcs +

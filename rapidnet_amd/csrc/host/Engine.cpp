@@ -1,6 +1,8 @@
 // Engine.cpp -- see Engine.hpp.
 #include "Engine.hpp"
 
+#include "NullSpace.hpp"
+
 void Engine::check(int rc, const char *what) {
     if (rc != RN_OK) throw std::runtime_error(string(what) + ": " + rn_last_error(ctx));
 }
@@ -46,7 +48,7 @@ Engine::~Engine() { if (ctx) rn_destroy(ctx); }
 void Engine::factorStep() {
     rn_system s;
     s.matB = ptrMyNetwork->getMatB(); s.matGd = ptrMyNetwork->getMatGd();
-    s.matL = ptrMySmpcConfig->getMatL(); s.matLhat = ptrMySmpcConfig->getMatLhat();
+    s.matL = getMatL(); s.matLhat = getMatLhat();
     s.costW = ptrMySmpcConfig->getCostW(); s.matDiagPrecnd = ptrMySmpcConfig->getMatPrcndDiag();
     s.vecXmin = ptrMyNetwork->getXmin(); s.vecXmax = ptrMyNetwork->getXmax(); s.vecXsafe = ptrMyNetwork->getXsafe();
     s.vecUmin = ptrMyNetwork->getUmin(); s.vecUmax = ptrMyNetwork->getUmax(); s.costAlpha1 = ptrMyNetwork->getAlpha();
@@ -70,3 +72,13 @@ size_t Engine::getBufferSize(int id) { return rn_buffer_size(ctx, id); }
 void Engine::getBuffer(int id, real_t *host) { check(rn_get(ctx, id, host, rn_buffer_size(ctx, id)), "rn_get"); }
 void Engine::setBuffer(int id, const real_t *host) { check(rn_set(ctx, id, host, rn_buffer_size(ctx, id)), "rn_set"); }
 void Engine::getOperator(int op, uint_t node, real_t *host, size_t n) { check(rn_get_operator(ctx, op, node, host, n), "rn_get_operator"); }
+
+void Engine::calculateMatLandMatLhat() {
+    const int ne = ptrMyNetwork->getNumMixNodes(), nu = ptrMyNetwork->getNumControls(), nd = ptrMyNetwork->getNumDemands();
+    const int rank = computeNullSpaceAndParticular(ptrMyNetwork->getMatE(), ptrMyNetwork->getMatEd(), ne, nu, nd, computedL, computedLhat);
+    if (nu - rank != (int)ptrMySmpcConfig->getNV())
+        throw std::logic_error("calculateMatLandMatLhat: null space of E has dimension " + std::to_string(nu - rank) + ", the configuration says nv = " +
+                               std::to_string(ptrMySmpcConfig->getNV()));
+    useComputedL = true;
+}
+void Engine::setWarmStart(bool on) { check(rn_set_warm_start(ctx, on ? 1 : 0), "rn_set_warm_start"); }

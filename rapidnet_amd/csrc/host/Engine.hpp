@@ -19,6 +19,14 @@ public:
     void eliminateInputDistubanceCoupling(real_t *nominalDemand, real_t *nominalPrices);  // Engine.cu:1147
     void updateStateControl(real_t *currentX, real_t *prevU, real_t *prevDemand);        // Engine.cu:1300
     void factorStep();                                                                    // Engine.cu:671
+    // Engine::calculateMatLandMatLhat (Engine.cu:466-669): L = null(E), Lhat = -pinv(E) Ed from the network's E, Ed.
+    // By default the factor step uses matL / matLhat of the controller configuration (they are already there,
+    // SmpcConfiguration.cu:59-68); after this call it uses the computed ones.  Any orthonormal basis of null(E) gives
+    // the same x, u and duals.
+    void calculateMatLandMatLhat();
+    real_t *getMatL() { return useComputedL ? computedL.data() : ptrMySmpcConfig->getMatL(); }
+    real_t *getMatLhat() { return useComputedL ? computedLhat.data() : ptrMySmpcConfig->getMatLhat(); }
+    void setWarmStart(bool on);
     ScenarioTree *getScenarioTree() { return ptrMyScenarioTree; }
     DwnNetwork *getDwnNetwork() { return ptrMyNetwork; }
     SmpcConfiguration *getSmpcConfiguration() { return ptrMySmpcConfig; }
@@ -45,6 +53,8 @@ private:
     SmpcConfiguration *ptrMySmpcConfig;
     rn_ctx *ctx;
     bool priceUncertaintyFlag, demandUncertaintyFlag, apgFlag, globalFbeFlag, namaFlag;
+    bool useComputedL = false;
+    std::vector<real_t> computedL, computedLhat;
 };
 
 #endif

@@ -1,6 +1,8 @@
 // SmpcController.cpp -- see SmpcController.hpp.
 #include "SmpcController.hpp"
 
+#include <cmath>
+
 void SmpcController::check(int rc, const char *what) {
     if (rc != RN_OK) throw std::runtime_error(string(what) + ": " + rn_last_error(ptrMyEngine->getContext()));
 }
@@ -10,6 +12,7 @@ SmpcController::SmpcController(Forecaster *f, Engine *e, SmpcConfiguration *c)
     stepSize = c->getStepSize();
     vecPrimalInfs.assign(c->getMaxIterations() + 1, 0.0);
     lastControl.assign(c->getNU(), 0.0);
+    economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
 
 SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
@@ -19,6 +22,7 @@ SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false),
     stepSize = ptrMySmpcConfig->getStepSize();
     vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
     lastControl.assign(ptrMySmpcConfig->getNU(), 0.0);
+    economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
 
 // the reference never deletes the objects its path-constructor news (SmpcController.cu:2091-2102); callers that want
@@ -66,8 +70,18 @@ uint_t SmpcController::controlAction(std::fstream &out) {
     return 1;
 }
 
-// in-built simulator (simulatorFlag, SmpcController.cu:1679-1725): x+ = x + B u + e(root), then shift u, d
+// SmpcController::moveForewardInTime (SmpcController.cu:1679-1716).  In-built simulator: x+ = x + e_root + B u with the
+// control returned by the last controlAction, KPIs updated, then state / previous control / previous demand shifted.
+// (The reference's version adds e to devVecX instead of the state update, :1695 -- so its simulated plant ignores the
+// demand; here the plant equation x+ = x + B u + Gd d of DwnNetwork.cuh:41-57 is applied.)
+// External simulator (simulatorFlag == false): the three vectors are re-read from the configuration file.
 void SmpcController::moveForewardInTime() {
+    if (!simulatorFlag) {
+        ptrMySmpcConfig->setCurrentState();
+        ptrMySmpcConfig->setPreviousControl();
+        ptrMySmpcConfig->setPreviousDemand();
+        return;
+    }
     DwnNetwork *net = ptrMyEngine->getDwnNetwork();
     const uint_t nx = net->getNumTanks(), nu = net->getNumControls(), nd = net->getNumDemands();
     std::vector<real_t> e(ptrMyEngine->getBufferSize(RN_BUF_E));
@@ -79,11 +93,43 @@ void SmpcController::moveForewardInTime() {
         for (uint_t j = 0; j < nu; j++) s += B[i + (size_t)j * nx] * lastControl[j];
         x[i] = s;
     }
+    updateKpi(x.data(), lastControl.data());                  // uses the still-unshifted previous control (:1706)
     ptrMySmpcConfig->setCurrentState(x.data());
     ptrMySmpcConfig->setPreviousControl(lastControl.data());
     std::vector<real_t> d(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalDemand() + nd);
     ptrMySmpcConfig->setpreviousdemand(d.data());
 }
+
+// SmpcController::updateKpi (SmpcController.cu:1769-1802)
+void SmpcController::updateKpi(real_t *state, real_t *control) {
+    const uint_t nx = ptrMySmpcConfig->getNX(), nu = ptrMySmpcConfig->getNU();
+    const real_t *safeX = ptrMyEngine->getDwnNetwork()->getXsafe();
+    const real_t *constantPrice = ptrMyEngine->getDwnNetwork()->getAlpha();
+    const real_t *variablePrice = ptrMyForecaster->getNominalPrices();
+    const real_t *previousControl = ptrMySmpcConfig->getPrevU();
+    const real_t weightEconomic = ptrMySmpcConfig->getWeightEconomical();
+    real_t ecoKpi = 0, smKpi = 0, saKpi = 0, netKpi = 0;
+    for (uint_t i = 0; i < nu; i++) {
+        ecoKpi += weightEconomic * (constantPrice[i] + variablePrice[i]) * std::fabs(control[i]);
+        const real_t dU = previousControl[i] - control[i];
+        smKpi += dU * dU;
+    }
+    for (uint_t i = 0; i < nx; i++) {
+        real_t level = state[i] - safeX[i];
+        if (level > 0) level = 0;
+        saKpi += std::fabs(level);
+        netKpi += std::fabs(state[i]);
+    }
+    economicKpi += ecoKpi; smoothKpi += smKpi; safeKpi += saKpi; networkKpi += netKpi;
+}
+real_t SmpcController::getEconomicKpi(uint_t simulationTime) { return economicKpi / 3600 / simulationTime; }
+real_t SmpcController::getSmoothKpi(uint_t simulationTime) { return smoothKpi / 3600 / simulationTime; }
+real_t SmpcController::getNetworkKpi(uint_t simulationTime) {
+    real_t safeLevelNorm = 0;
+    for (uint_t i = 0; i < ptrMySmpcConfig->getNX(); i++) safeLevelNorm += getDwnNetwork()->getXsafe()[i];
+    return 100 * simulationTime * safeLevelNorm / networkKpi;
+}
+real_t SmpcController::getSafetyKpi(uint_t) { return safeKpi; }
 
 void SmpcController::dualExtrapolationStep(real_t lambda) { check(rn_dual_extrapolation_step(ptrMyEngine->getContext(), lambda), "rn_dual_extrapolation_step"); }
 void SmpcController::solveStep() {

@@ -20,7 +20,12 @@ public:
     SmpcConfiguration *getSmpcConfiguration() { return ptrMySmpcConfig; }
     Forecaster *getForecaster() { return ptrMyForecaster; }
     Engine *getEngine() { return ptrMyEngine; }
-    void moveForewardInTime();                              // :1679-1770 (in-built simulator step x+ = x + B u + e)
+    void moveForewardInTime();                              // :1679-1716
+    real_t getEconomicKpi(uint_t simulationTime);           // :1808-1811
+    real_t getSmoothKpi(uint_t simulationTime);             // :1817-1820
+    real_t getNetworkKpi(uint_t simulationTime);            // :1826-1835
+    real_t getSafetyKpi(uint_t simulationTime);             // :1841-1843
+    void updateKpi(real_t *state, real_t *control);         // :1769-1802
     real_t *getPrimalInfeasibility() { return vecPrimalInfs.data(); }
     ~SmpcController();
 
@@ -42,6 +47,7 @@ protected:
     real_t stepSize;
     bool factorStepFlag, simulatorFlag, ownsObjects;
     std::vector<real_t> vecPrimalInfs, lastControl;
+    real_t economicKpi, smoothKpi, safeKpi, networkKpi;
 };
 
 #endif

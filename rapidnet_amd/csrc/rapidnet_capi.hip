@@ -98,6 +98,7 @@ struct CtxBase {
     virtual int hist_parts(int, int, double *) = 0;
     virtual int sweep_phase(int) = 0;
     virtual int set_operator_mode(int) = 0;
+    virtual int set_warm_start(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
 };
@@ -158,7 +159,7 @@ struct Ctx : CtxBase {
     T *d_LBLp = nullptr;
     bool aux_dirty = true;   // eb = e + B uhat and bw0 = B (prevU - prevUhat) must be refreshed before the next sweep
     T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
-    int structured = 0;
+    int structured = 0, warmStart = 0;
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
@@ -632,6 +633,16 @@ struct Ctx : CtxBase {
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
         return ensure_tables(0);
     }
+    // warm start: keep the duals of the previous control step, restart the momentum (theta = {1,1} => w_0 = y+)
+    int apg_restart_keep_duals() {
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipMemcpyAsync(p_xi, p_upd, (size_t)ntot() * sizeof(T), hipMemcpyDeviceToDevice, stream));   // y := y+
+        RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
+        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
+        acc_ready = false;   // the first iteration re-derives w_0 = (1 + 0) y+ - 0 y
+        return ensure_tables(0);
+    }
+    int set_warm_start(int on) override { warmStart = on ? 1 : 0; return RN_OK; }
     int apg_iterate(int n, double *primalInfs) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
@@ -691,7 +702,8 @@ struct Ctx : CtxBase {
         RN_CHECK(u0, RN_E_ARG, "rn_control_action: null output");
         if (int rc = update_state_control(x0, up, dp)) return rc;
         if (int rc = eliminate(dhat, ahat)) return rc;
-        if (int rc = apg_reset()) return rc;
+        if (warmStart && h_it > 0) { if (int rc = apg_restart_keep_duals()) return rc; }   // y, y+ kept; theta = {1,1}
+        else if (int rc = apg_reset()) return rc;
         if (int rc = apg_iterate(maxIt, nullptr)) return rc;
         T *src = d_u;
         if (project) {  // SmpcController.cu:1647-1650: clamp with the (scaled) bounds of the root node
@@ -1002,6 +1014,7 @@ int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
+int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 

@@ -4,6 +4,7 @@
 //   controller  : TestSmpcController::testExtrapolation / testSoveStep / testProximalStep / testFixedPointResidual /
 //                 testDualUpdate (src/test/TestSmpcController.cu:114-420) against smpcTest.json, same tolerance rule
 // usage: test_host <loaders|engine|controller|closedloop> <directory with the fixture JSON files>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -206,8 +207,102 @@ static void testClosedLoop(const string &dir) {
     }
     CHECK(ctl.controlAction(u.data()) == 1);
     for (real_t v : u) CHECK(std::isfinite(v));
+    // KPIs of the two simulated steps (main.cu:66-69)
+    const real_t eco = ctl.getEconomicKpi(2), smooth = ctl.getSmoothKpi(2), safe = ctl.getSafetyKpi(2), net = ctl.getNetworkKpi(2);
+    CHECK(std::isfinite(eco) && eco > 0);
+    CHECK(std::isfinite(smooth) && smooth >= 0);
+    CHECK(std::isfinite(safe) && safe >= 0);
+    CHECK(std::isfinite(net) && net > 0);
+    std::cout << "KPIs: economic " << eco << " smooth " << smooth << " safety " << safe << " network " << net << "\n";
+    // updateKpi against a hand computation
+    {
+        SmpcConfiguration *cfg = ctl.getSmpcConfiguration();
+        const uint_t nx = cfg->getNX(), nu = cfg->getNU();
+        std::vector<real_t> st(nx, 1.0), cu(nu, 2.0);
+        const real_t e0 = ctl.getEconomicKpi(1) * 3600, s0 = ctl.getSmoothKpi(1) * 3600;
+        ctl.updateKpi(st.data(), cu.data());
+        real_t de = 0, ds = 0;
+        for (uint_t i = 0; i < nu; i++) {
+            de += (ctl.getDwnNetwork()->getAlpha()[i] + ctl.getForecaster()->getNominalPrices()[i]) * 2.0;
+            ds += (cfg->getPrevU()[i] - 2.0) * (cfg->getPrevU()[i] - 2.0);
+        }
+        CHECK(std::fabs(ctl.getEconomicKpi(1) * 3600 - e0 - de) < 1e-9 * (1 + std::fabs(de)));
+        CHECK(std::fabs(ctl.getSmoothKpi(1) * 3600 - s0 - ds) < 1e-9 * (1 + std::fabs(ds)));
+    }
     out.close();
     std::remove((dir + "/controlOutput.tmp").c_str());
+}
+
+// Engine::calculateMatLandMatLhat: E L = 0, L'L = I, E Lhat = -Ed, and the solve does not depend on the basis
+static void testNullSpace(const string &dir) {
+    SmpcConfiguration cfg(dir + "/controllerConfig.json");
+    Forecaster fc(dir + "/forecastor.json");
+    fc.predictDemand(1); fc.predictPrices(1);
+    std::vector<real_t> xRef, uRef;
+    for (int pass = 0; pass < 2; pass++) {
+        Engine eng(&cfg);
+        DwnNetwork *net = eng.getDwnNetwork();
+        const uint_t ne = net->getNumMixNodes(), nu = net->getNumControls(), nd = net->getNumDemands(), nv = cfg.getNV();
+        if (pass == 1) {
+            eng.calculateMatLandMatLhat();
+            const real_t *L = eng.getMatL(), *Lh = eng.getMatLhat(), *E = net->getMatE(), *Ed = net->getMatEd();
+            for (uint_t j = 0; j < nv; j++) {
+                for (uint_t i = 0; i < ne; i++) { real_t s = 0; for (uint_t k = 0; k < nu; k++) s += E[i + (size_t)k * ne] * L[k + (size_t)j * nu]; CHECK(std::fabs(s) < 1e-12); }
+                for (uint_t j2 = 0; j2 < nv; j2++) { real_t s = 0; for (uint_t k = 0; k < nu; k++) s += L[k + (size_t)j * nu] * L[k + (size_t)j2 * nu]; CHECK(std::fabs(s - (j == j2)) < 1e-12); }
+            }
+            for (uint_t j = 0; j < nd; j++)
+                for (uint_t i = 0; i < ne; i++) { real_t s = 0; for (uint_t k = 0; k < nu; k++) s += E[i + (size_t)k * ne] * Lh[k + (size_t)j * nu]; CHECK(std::fabs(s + Ed[i + (size_t)j * ne]) < 1e-12); }
+            // Lhat is unique (minimum-norm particular solution): it must equal the configuration's
+            CHECK(closeAbs(Lh, cfg.getMatLhat(), (size_t)nu * nd, 1e-6, "matLhat"));
+        }
+        eng.factorStep();
+        eng.updateStateControl(cfg.getCurrentX(), cfg.getPrevU(), cfg.getPrevDemand());
+        eng.eliminateInputDistubanceCoupling(fc.getNominalDemand(), fc.getNominalPrices());
+        std::vector<real_t> hist(40), x(eng.getBufferSize(RN_BUF_X)), u(eng.getBufferSize(RN_BUF_U));
+        if (rn_algorithm_apg(eng.getContext(), 40, hist.data()) != RN_OK) { CHECK(false); return; }
+        eng.getBuffer(RN_BUF_X, x.data()); eng.getBuffer(RN_BUF_U, u.data());
+        if (pass == 0) { xRef = x; uRef = u; }
+        else {
+            real_t ex = 0, eu = 0, nx_ = 0, nu_ = 0;
+            for (size_t i = 0; i < x.size(); i++) { ex = std::max(ex, std::fabs(x[i] - xRef[i])); nx_ = std::max(nx_, std::fabs(xRef[i])); }
+            for (size_t i = 0; i < u.size(); i++) { eu = std::max(eu, std::fabs(u[i] - uRef[i])); nu_ = std::max(nu_, std::fabs(uRef[i])); }
+            std::cout << "null-space basis invariance: max rel diff x " << ex / nx_ << " u " << eu / nu_ << "\n";
+            // the configuration's matL is a 7-digit print (orthonormal / in null(E) to ~1e-7 only), the computed basis is exact
+            CHECK(ex < 1e-6 * nx_ && eu < 1e-6 * nu_);
+        }
+    }
+}
+
+// warm start (extension; the reference always cold-starts, SmpcController.cu:1509): the next control step starts
+// from the duals the previous one ended with (momentum restarted), a cold start from zero
+static void testWarmStart(const string &dir) {
+    for (int warm = 0; warm < 2; warm++) {
+        SmpcConfiguration cfg(dir + "/controllerConfig.json");
+        Forecaster fc(dir + "/forecastor.json");
+        Engine eng(&cfg);
+        eng.setWarmStart(warm == 1);
+        eng.factorStep();
+        std::vector<real_t> u(cfg.getNU());
+        fc.predictDemand(0); fc.predictPrices(0);
+        CHECK(rn_control_action(eng.getContext(), cfg.getCurrentX(), cfg.getPrevU(), cfg.getPrevDemand(), fc.getNominalDemand(),
+                                fc.getNominalPrices(), 60, 0, u.data()) == RN_OK);
+        std::vector<real_t> y1(eng.getBufferSize(RN_BUF_UPD_XI)), y2(y1.size()), w2(y1.size());
+        eng.getBuffer(RN_BUF_UPD_XI, y1.data());
+        fc.predictDemand(1); fc.predictPrices(1);
+        // zero iterations: only the (re)start of the next control step happens
+        CHECK(rn_control_action(eng.getContext(), cfg.getCurrentX(), u.data(), cfg.getPrevDemand(), fc.getNominalDemand(),
+                                fc.getNominalPrices(), 0, 0, u.data()) == RN_OK);
+        eng.getBuffer(RN_BUF_UPD_XI, y2.data());
+        real_t diff = 0, norm1 = 0, norm2 = 0;
+        for (size_t i = 0; i < y1.size(); i++) { diff = std::max(diff, std::fabs(y1[i] - y2[i])); norm1 = std::max(norm1, std::fabs(y1[i])); norm2 = std::max(norm2, std::fabs(y2[i])); }
+        CHECK(norm1 > 0);
+        if (warm) CHECK(diff == 0);          // duals carried over
+        else CHECK(norm2 == 0);              // cold start: zeroed (SmpcController.cu:420-450)
+        // and the solve continues from there
+        CHECK(rn_control_action(eng.getContext(), cfg.getCurrentX(), u.data(), cfg.getPrevDemand(), fc.getNominalDemand(),
+                                fc.getNominalPrices(), 25, 0, u.data()) == RN_OK);
+        for (real_t v : u) CHECK(std::isfinite(v));
+    }
 }
 
 int main(int argc, char **argv) {
@@ -222,6 +317,8 @@ int main(int argc, char **argv) {
             t.getForecaster()->predictPrices(1);
             t.run(dir);
         } else if (mode == "closedloop") testClosedLoop(dir);
+        else if (mode == "nullspace") testNullSpace(dir);
+        else if (mode == "warmstart") testWarmStart(dir);
         else { std::cerr << "unknown mode\n"; return 2; }
     } catch (const std::exception &e) {
         std::cerr << "EXCEPTION: " << e.what() << "\n";

@@ -43,3 +43,14 @@ def test_controller_known_answers_cpp():
 @pytest.mark.gpu
 def test_closed_loop_cpp():
     _run("closedloop")
+
+
+@pytest.mark.gpu
+def test_null_space_basis_invariance_cpp():
+    out = _run("nullspace")
+    assert "null-space basis invariance" in out
+
+
+@pytest.mark.gpu
+def test_warm_start_cpp():
+    _run("warmstart")
