@@ -188,6 +188,12 @@ int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
 /* stage c of the (rank-local) tree whose nodes are the roots of the sharded subtrees: the children sums of the
  * stage c-1 nodes (replicated on every rank) are all-reduced once per iteration; -1 switches sharding off. */
 int rn_set_cut_stage(rn_ctx *ctx, int stage);
+/* How the tree-global prox distances (SmpcController.cu:792,810) are obtained across ranks.
+ *   1 (default) optimistic: the prox runs as a pure projection, every rank's dist^2 of iteration t rides in the tail of
+ *     iteration t+1's cut all-reduce and is checked on the device -- ONE collective per iteration; if a threshold is
+ *     ever exceeded the batch is replayed from a checkpoint with mode 0, so the result is exact either way;
+ *   0 exact: a second 2-element all-reduce per iteration before the trip decision. */
+int rn_set_exchange_mode(rn_ctx *ctx, int mode);
 /* static tree data a shard cannot derive from its local children: for every cut parent i (stage-1 nodes of the cut, in
  * stage order) E_i = sum over ALL children c of p_c * errorDemand_c (nd reals) and P_i = sum_c p_c.  They replace the
  * children loop of calculateZeta (Utilities.cu:100-131) for those nodes: sum_c p_c uhat_c = Lhat (E_i + P_i dhat). */

@@ -24,7 +24,7 @@ SYMBOLS = [
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
-    "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start",
+    "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
 ]
 
 
@@ -97,6 +97,7 @@ def load():
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
     lib.rn_set_operator_mode.argtypes = [vp, ip]
     lib.rn_set_warm_start.argtypes = [vp, ip]
+    lib.rn_set_exchange_mode.argtypes = [vp, ip]
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
     lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
     _LIB = lib
@@ -225,6 +226,9 @@ class Solver:
         n = self.max_iterations if maxIterations is None else int(maxIterations)
         self._check(self.lib.rn_control_action(self.h, *[v.ctypes.data for v in a], n, int(project), u0.ctypes.data))
         return u0
+
+    def setExchangeMode(self, optimistic=True):
+        self._check(self.lib.rn_set_exchange_mode(self.h, 1 if optimistic else 0))
 
     def setWarmStart(self, on=True):
         self._check(self.lib.rn_set_warm_start(self.h, int(on)))

@@ -34,6 +34,14 @@ struct TreeDev {
     const T *dy;            // [N][ny] preconditioner diagonal in y order: d_x | d_xs | d_u
 };
 
+struct IterState {         // device-resident scalars of the APG loop
+    int it;                // iteration counter (incremented by k_finalize / k_decide_finalize)
+    unsigned int ticket;   // arrival counter of the fix-up kernel's blocks (rare path only)
+    int violated;          // multi-GPU optimistic mode: a tree-global distance exceeded its threshold (sticky)
+    int tripped;           // soft-constraint branch taken in this iteration
+    double scaleX, scaleS; // 1 - gamma/(lambda dist) for the two halves (0 when not tripped)
+    double distX, distS;   // tree-global distances of this iteration
+};
 template <typename T>
 struct SweepArgs {
     TreeDev<T> tr;
@@ -59,6 +67,9 @@ struct SweepArgs {
     T *x, *u, *hx;
     const T *cutSums; // multi-GPU: [cutParents][nv+2nx] all-reduced children sums, or nullptr
     int cutStage;     // stage whose parents take cutSums instead of summing their local children (-1: none)
+    // optimistic exchange: the all-reduced payload ends with the tree-global dist^2 of the previous iteration; the first
+    // crown kernel after the all-reduce checks it against the thresholds (no extra launch)
+    const T *distTail; double thrX, thrS; void *iterState;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -377,6 +388,12 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
+    if (presummed && a.distTail != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        IterState *st = reinterpret_cast<IterState *>(a.iterState);
+        const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
+        st->distX = dX; st->distS = dS;
+        if (dX > a.thrX || dS > a.thrS) st->violated = 1;
+    }
     const int wp = (w + 63) / 64 * 64;
     const int parts = CROWN_THREADS / wp > 0 ? CROWN_THREADS / wp : 1;
     const int part = threadIdx.x / wp, t = threadIdx.x % wp;
@@ -696,13 +713,6 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // elements) [+ z, res when MATERIALIZE].
 //   t = hx + w/lambda ; z = clamp(t, lo, hi) [+ sc_half (t - clamp) when the soft-constraint branch trips]
 //   res = hx - z ; ynew = w + lambda res ; wnext = (1 + ln) ynew - ln yprev
-struct IterState {         // device-resident scalars of the APG loop
-    int it;                // iteration counter (incremented by k_finalize / k_decide_finalize)
-    unsigned int ticket;   // arrival counter of the fix-up kernel's blocks (rare path only)
-    int tripped;           // soft-constraint branch taken in this iteration
-    double scaleX, scaleS; // 1 - gamma/(lambda dist) for the two halves (0 when not tripped)
-    double distX, distS;   // tree-global distances of this iteration
-};
 struct Partial {           // per-block partial reductions of the fused kernel
     double d2x, d2s;       // sum (t - clamp)^2 over the box / safety halves
     double absXi, valXi;   // max |res| over xi entries and the signed entry there
@@ -933,6 +943,60 @@ __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials,
         st->scaleX = tx ? 1.0 - thrX / dX : 0.0;
         st->scaleS = ts ? 1.0 - thrS / dS : 0.0;
     }
+}
+
+// Multi-GPU optimistic bookkeeping (one collective per iteration).  The fused kernel runs without the soft-constraint
+// correction; this kernel folds the block partials, stores the rank-local dist^2 of THIS iteration in the tail of the
+// cut payload (it rides on the NEXT iteration's all-reduce), writes the rank-local history entry and advances `it`.
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Partial *partials, int nblocks, IterState *st, T *tail,
+                                                                     double *hist, double *histParts, int histCap) {
+    __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
+    __shared__ Partial sh[ELT_THREADS / 64];
+    double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
+    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
+    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
+        const Partial q = partials[b];
+        d2x += q.d2x; d2s += q.d2s;
+        better(absXi, valXi, idxXi, q.absXi, q.valXi, q.idxXi);
+        better(absPsi, valPsi, idxPsi, q.absPsi, q.valPsi, q.idxPsi);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off);
+        const double a2 = __shfl_down(absXi, off), v2 = __shfl_down(valXi, off);
+        const long long i2 = __shfl_down(idxXi, off);
+        better(absXi, valXi, idxXi, a2, v2, i2);
+        const double a3 = __shfl_down(absPsi, off), v3 = __shfl_down(valPsi, off);
+        const long long i3 = __shfl_down(idxPsi, off);
+        better(absPsi, valPsi, idxPsi, a3, v3, i3);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sx[wave] = d2x; ss[wave] = d2s; sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi}; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Partial p = sh[0];
+        double tx2 = sx[0], ts2 = ss[0];
+        for (int k = 1; k < ELT_THREADS / 64; k++) {
+            tx2 += sx[k]; ts2 += ss[k];
+            better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
+            better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
+        }
+        tail[0] = (T)tx2; tail[1] = (T)ts2;
+        const int it = st->it;
+        if (it < histCap) {
+            hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
+            histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
+            histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
+        }
+        st->it = it + 1;
+    }
+}
+// after the all-reduce: the tail holds the tree-global dist^2 of the previous iteration
+template <typename T>
+__global__ void k_check_dist(const T *tail, IterState *st, double thrX, double thrS) {
+    const double dX = sqrt((double)tail[0]), dS = sqrt((double)tail[1]);
+    st->distX = dX; st->distS = dS;
+    if (dX > thrX || dS > thrS) st->violated = 1;
 }
 
 // multi-GPU variant of k_decide: fold the local partials to (d2x, d2s), all-reduce those two numbers, then decide

@@ -99,6 +99,7 @@ struct CtxBase {
     virtual int sweep_phase(int) = 0;
     virtual int set_operator_mode(int) = 0;
     virtual int set_warm_start(int) = 0;
+    virtual int set_exchange_mode(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
 };
@@ -160,6 +161,10 @@ struct Ctx : CtxBase {
     bool aux_dirty = true;   // eb = e + B uhat and bw0 = B (prevU - prevUhat) must be refreshed before the next sweep
     T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
     int structured = 0, warmStart = 0;
+    int optimistic = 1;      // multi-GPU: 1 = one collective per iteration + verification, 0 = exact two-collective path
+    bool carryTail = false;  // the cut payload carries 2 extra reals (rank-local dist^2 of the previous iteration)
+    T *d_ck[3] = {nullptr, nullptr, nullptr};   // checkpoint of (y, y+, w) for the exact fallback
+    long fallbacks = 0;
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
@@ -249,6 +254,8 @@ struct Ctx : CtxBase {
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
         a.w = p_acc; a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
         a.x = d_x; a.u = d_u; a.hx = d_hx;
+        a.distTail = (carryTail && a.cutSums) ? d_cut + cut_tail_offset() : nullptr;
+        a.thrX = penX / stepSize; a.thrS = penXs / stepSize; a.iterState = d_state;
         return a;
     }
     long long ntot() const { return (long long)d.nodes * ny; }
@@ -556,7 +563,8 @@ struct Ctx : CtxBase {
             if (phase == 2) return RN_OK;              // payload already summed by the caller
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k)), dim3(128), 0, stream, a, d_cut);
             if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
-            const int rc = g_nccl.AllReduce(d_cut, d_cut, (size_t)nk(k) * (nv + 2 * nx), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
+            const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
+            const int rc = g_nccl.AllReduce(d_cut, d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
                                             0 /*ncclSum*/, comm, stream);
             RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
             return RN_OK;
@@ -643,10 +651,80 @@ struct Ctx : CtxBase {
         return ensure_tables(0);
     }
     int set_warm_start(int on) override { warmStart = on ? 1 : 0; return RN_OK; }
+    size_t cut_tail_offset() const { return (size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx); }
+    // Multi-GPU, optimistic exchange: ONE collective per iteration.  The prox runs as a pure projection (what happens
+    // unless a tree-global distance exceeds gamma/lambda, SmpcController.cu:793/811); every rank's dist^2 of iteration t
+    // rides in the tail of iteration t+1's cut all-reduce and is checked on the device.  If a threshold was ever
+    // exceeded, the batch is replayed from a checkpoint with the exact two-collective path.  Results are exact either way.
+    int apg_iterate_optimistic(int n, double *primalInfs) {
+        const int first = h_it;
+        const size_t bytes = (size_t)ntot() * sizeof(T);
+        for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
+        if (int rc = ensure_tables(h_it + n)) return rc;
+        // checkpoint
+        RN_HIP(hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream));
+        T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
+        const bool s_ready = acc_ready;
+        const size_t tail = cut_tail_offset();
+        RN_HIP(hipMemsetAsync(d_cut + tail, 0, 2 * sizeof(T), stream));
+        RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
+        carryTail = true;
+        for (int k = 0; k < n; k++) {
+            if (!acc_ready) {
+                hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
+                acc_ready = true;
+            }
+            if (int rc = launch_sweep()) { carryTail = false; return rc; }
+            DualArgs<T> a = dual_args();
+            const hipEvent_t *e2 = prof_begin(2);
+            if (k == n - 1) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            prof_end(e2);
+            const hipEvent_t *e3 = prof_begin(3);
+            hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_cut + tail,
+                               d_hist, d_histParts, histCap);
+            prof_end(e3);
+            std::swap(p_xi, p_upd);
+            p_acc_view = p_acc;
+            std::swap(p_acc, p_acc_other);
+            h_it++;
+        }
+        carryTail = false;
+        if (n > 0) {   // the last iteration's distances: one 2-element all-reduce per BATCH
+            const int rc = g_nccl.AllReduce(d_cut + tail, d_cut + tail, 2, sizeof(T) == 8 ? 8 : 7, 0, comm, stream);
+            RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist tail) failed");
+            hipLaunchKernelGGL(k_check_dist<T>, dim3(1), dim3(1), 0, stream, d_cut + tail, d_state, penX / stepSize, penXs / stepSize);
+        }
+        RN_HIP(hipGetLastError());
+        int violated = 0;
+        RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        if (violated) {   // replay the batch exactly
+            fallbacks++;
+            p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
+            RN_HIP(hipMemcpyAsync(p_xi, d_ck[0], bytes, hipMemcpyDeviceToDevice, stream));
+            RN_HIP(hipMemcpyAsync(p_upd, d_ck[1], bytes, hipMemcpyDeviceToDevice, stream));
+            RN_HIP(hipMemcpyAsync(p_acc, d_ck[2], bytes, hipMemcpyDeviceToDevice, stream));
+            h_it = first;
+            RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
+            RN_HIP(hipStreamSynchronize(stream));
+            const int keep = optimistic;
+            optimistic = 0;
+            const int rc = apg_iterate(n, primalInfs);
+            optimistic = keep;
+            return rc;
+        }
+        if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        return RN_OK;
+    }
+    int set_exchange_mode(int mode) override { RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic"); optimistic = mode; return RN_OK; }
     int apg_iterate(int n, double *primalInfs) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
         RN_HIP(hipSetDevice(device));
+        if (comm && cutStage > 0 && optimistic && n > 0) return apg_iterate_optimistic(n, primalInfs);
         const int first = h_it;
         if (int rc = ensure_tables(h_it + n)) return rc;
         for (int k = 0; k < n; k++) {
@@ -1015,6 +1093,7 @@ int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
+int rn_set_exchange_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_exchange_mode(mode); }
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 
