@@ -76,6 +76,16 @@ typedef struct {
     real *q, *r;         /* K x nx, K x nv, indexed by position within the stage */
     real stepSize, penaltyX, penaltyXs;
     real distXcst, distXs;
+    /* ---- global-FBE / NAMA outer loops (SmpcController.cuh:380-458) ---- */
+    int algorithm;             /* 0 APG, 1 globalFbeAlgorithm, 2 namaAlgorithm (Engine.cu:151-163) */
+    int lbfgsSize, lbfgsCol, lbfgsMem, lbfgsSkip;
+    real lbfgsH;
+    real *prevXi, *prevPsi, *gradXi, *gradPsi, *prevGradXi, *prevGradPsi;
+    real *curResXi, *curResPsi, *prevResXi, *prevResPsi;
+    real *dirXi, *dirPsi, *xdir, *udir, *primalXiDir, *primalPsiDir;
+    real *matS, *matY, *rho;   /* (lbfgsSize + 1) columns: the reference indexes columns 1..lbfgsSize (see oracle_lbfgs_update) */
+    real valueGxBox, valueGxSafe, valueGuBox;
+    real *W;                   /* costW, nu x nu (computeValueFbe) */
 } oracle_t;
 
 static real *ralloc(size_t n) { real *p = (real *)calloc(n ? n : 1, sizeof(real)); return p; }
@@ -223,6 +233,7 @@ oracle_t *oracle_create(int nx, int nu, int nv, int nd, int N, int K, int nodes,
     o->resXi = ralloc(n * 2 * nx); o->resPsi = ralloc(n * nu);
     o->q = ralloc((size_t)K * nx); o->r = ralloc((size_t)K * nv);
     o->stepSize = (real)1e-4; o->penaltyX = (real)1e6; o->penaltyXs = (real)1e4;
+    o->W = ralloc((size_t)nu * nu);
     return o;
 }
 
@@ -255,7 +266,7 @@ int oracle_factor_step(oracle_t *o, const double *matB, const double *matL, cons
     for (int i = 0; i < nx * nd; i++) o->Gd[i] = (real)matGd[i];
     for (int i = 0; i < nu; i++) o->alpha1[i] = (real)alpha1[i];
     real *W = ralloc((size_t)nu * nu);
-    for (int i = 0; i < nu * nu; i++) W[i] = (real)costW[i];
+    for (int i = 0; i < nu * nu; i++) { W[i] = (real)costW[i]; o->W[i] = W[i]; }
     /* Wv = W*L ; Rbar = L' * Wv   (Engine.cu:412-416) */
     gemm(0, 0, nu, nv, nu, 1, W, nu, o->L, nu, 0, o->Wv, nu);
     real *Rbar = ralloc((size_t)nv * nv);
@@ -573,13 +584,16 @@ void oracle_prox(oracle_t *o) {
             d2x += (double)db * db; d2s += (double)ds * ds;
         }
     o->distXcst = (real)sqrt(d2x); o->distXs = (real)sqrt(d2s);                                  /* :792, :810 */
+    o->valueGxBox = 0; o->valueGxSafe = 0; o->valueGuBox = 0;   /* :808, :826, :828: zero unless the soft branch trips */
     if (o->distXcst > invLambda * o->penaltyX) {                                                 /* :793-797 */
         real sc = 1 - invLambda * o->penaltyX / o->distXcst;
+        o->valueGxBox = o->penaltyX * (o->distXcst - invLambda * o->penaltyX);   /* gamma * dist(prox point, C) */
         for (int i = 0; i < nodes; i++)
             for (int t = 0; t < nx; t++) o->dualXi[(size_t)i * 2 * nx + t] += sc * diff[(size_t)i * 2 * nx + t];
     }
     if (o->distXs > invLambda * o->penaltyXs) {                                                  /* :811-815 */
         real sc = 1 - invLambda * o->penaltyXs / o->distXs;
+        o->valueGxSafe = o->penaltyXs * (o->distXs - invLambda * o->penaltyXs);
         for (int i = 0; i < nodes; i++)
             for (int t = 0; t < nx; t++) o->dualXi[(size_t)i * 2 * nx + nx + t] += sc * diff[(size_t)i * 2 * nx + nx + t];
     }
@@ -597,11 +611,21 @@ void oracle_residual(oracle_t *o) {
     for (size_t i = 0; i < nps; i++) o->resPsi[i] = o->primalPsi[i] - o->dualPsi[i];
 }
 
-/* SmpcController::dualUpdate (APG branch), SmpcController.cu:859-864 */
+/* SmpcController::dualUpdate, SmpcController.cu:854-881 (APG branch :859-864, FBE / NAMA branch :866-880) */
 void oracle_dual_update(oracle_t *o) {
     size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu;
-    for (size_t i = 0; i < nxi; i++) o->updXi[i] = o->accXi[i] + o->stepSize * o->resXi[i];
-    for (size_t i = 0; i < nps; i++) o->updPsi[i] = o->accPsi[i] + o->stepSize * o->resPsi[i];
+    if (o->algorithm == 0) {
+        for (size_t i = 0; i < nxi; i++) o->updXi[i] = o->accXi[i] + o->stepSize * o->resXi[i];
+        for (size_t i = 0; i < nps; i++) o->updPsi[i] = o->accPsi[i] + o->stepSize * o->resPsi[i];
+        return;
+    }
+    real *curYXi = o->algorithm == 1 ? o->gradXi : o->curResXi, *curYPsi = o->algorithm == 1 ? o->gradPsi : o->curResPsi;
+    real *prvYXi = o->algorithm == 1 ? o->prevGradXi : o->prevResXi, *prvYPsi = o->algorithm == 1 ? o->prevGradPsi : o->prevResPsi;
+    memcpy(prvYXi, curYXi, nxi * sizeof(real)); memcpy(prvYPsi, curYPsi, nps * sizeof(real));      /* :868-869 */
+    memcpy(o->prevXi, o->xi, nxi * sizeof(real)); memcpy(o->prevPsi, o->psi, nps * sizeof(real));  /* :871-872 */
+    for (size_t i = 0; i < nxi; i++) o->xi[i] = o->accXi[i] + o->stepSize * o->resXi[i];           /* :874-877 */
+    for (size_t i = 0; i < nps; i++) o->psi[i] = o->accPsi[i] + o->stepSize * o->resPsi[i];
+    memcpy(o->accXi, o->xi, nxi * sizeof(real)); memcpy(o->accPsi, o->psi, nps * sizeof(real));    /* :879-880 */
 }
 
 /* SmpcController::updatePrimalInfeasibity, SmpcController.cu:1480-1496: isamax returns the FIRST index of
@@ -649,6 +673,300 @@ void oracle_apg_continue(oracle_t *o, int iters, double *theta01) {
     theta01[0] = theta[0]; theta01[1] = theta[1];
 }
 
+
+/* ======================================================================================================
+ * global-FBE and NAMA outer loops.  Restated from SmpcController.cu with the
+ * reference's exact control flow; pinned by src/test/testDataFiles/{smpcFbeTest,smpcNamaTest}.json through
+ * tests/test_oracle_fbe_nama.py (the Python twin of TestSmpcController.cu:403-1040).
+ * ====================================================================================================== */
+void oracle_set_algorithm(oracle_t *o, int algorithm, int lbfgsBufferSize) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, n = nxi + nps;
+    o->algorithm = algorithm;
+    if (algorithm == 0 || o->matS) return;
+    o->lbfgsSize = lbfgsBufferSize;
+    o->prevXi = ralloc(nxi); o->prevPsi = ralloc(nps); o->gradXi = ralloc(nxi); o->gradPsi = ralloc(nps);
+    o->prevGradXi = ralloc(nxi); o->prevGradPsi = ralloc(nps);
+    o->curResXi = ralloc(nxi); o->curResPsi = ralloc(nps); o->prevResXi = ralloc(nxi); o->prevResPsi = ralloc(nps);
+    o->dirXi = ralloc(nxi); o->dirPsi = ralloc(nps);
+    o->xdir = ralloc((size_t)o->nodes * o->nx); o->udir = ralloc(nps); o->primalXiDir = ralloc(nxi); o->primalPsiDir = ralloc(nps);
+    /* the reference allocates lbfgsSize columns but addresses columns 1..lbfgsSize (SmpcController.cu:1146, 256-257:
+     * a device heap overrun); one spare column makes the same indexing safe here */
+    o->matS = ralloc((size_t)(lbfgsBufferSize + 1) * n); o->matY = ralloc((size_t)(lbfgsBufferSize + 1) * n);
+    o->rho = ralloc((size_t)lbfgsBufferSize + 1);
+    o->lbfgsCol = 0; o->lbfgsMem = 0; o->lbfgsSkip = 0; o->lbfgsH = 1;
+}
+
+/* SmpcController::initialiseAlgorithm (FBE / NAMA parts, :436-449) + initaliseLbfgBuffer (:453-468) */
+void oracle_fbe_reset(oracle_t *o) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, n = nxi + nps;
+    oracle_apg_reset(o);
+    memset(o->prevXi, 0, nxi * sizeof(real)); memset(o->prevPsi, 0, nps * sizeof(real));
+    if (o->algorithm == 1) { memset(o->gradXi, 0, nxi * sizeof(real)); memset(o->gradPsi, 0, nps * sizeof(real)); }
+    else { memset(o->resXi, 0, nxi * sizeof(real)); memset(o->resPsi, 0, nps * sizeof(real)); }
+    o->lbfgsCol = 0; o->lbfgsMem = 0; o->lbfgsSkip = 0; o->lbfgsH = 1;
+    memset(o->matS, 0, (size_t)(o->lbfgsSize + 1) * n * sizeof(real));
+    memset(o->rho, 0, ((size_t)o->lbfgsSize + 1) * sizeof(real));
+}
+
+/* SmpcController::computeHessianOracalGlobalFbe, SmpcController.cu:884-1058: the sweep of solveStep with sigma = 0 and
+ * no affine terms, applied to the direction (dXi, dPsi) -> xdir, udir, primalXiDir, primalPsiDir */
+static void hessian_oracle(oracle_t *o, const real *dXi, const real *dPsi) {
+    int nx = o->nx, nu = o->nu, nv = o->nv, N = o->N, nodes = o->nodes, K = o->K;
+    real *tmpQ = ralloc((size_t)K * nx), *tmpR = ralloc((size_t)K * nv), *Lv = ralloc((size_t)K * nu);
+    memset(o->sigma, 0, (size_t)nodes * nv * sizeof(real));                                        /* :907 */
+    for (int k = N - 1; k > -1; k--) {
+        int cum = o->nodesPerStageCumul[k], nk = o->nodesPerStage[k];
+        for (int j = 0; j < nk; j++) {
+            int i = cum + j;
+            real *sig = o->sigma + (size_t)i * nv, *v = o->v + (size_t)i * nv;
+            real *qj = o->q + (size_t)j * nx, *rj = o->r + (size_t)j * nv;
+            const real *xi = dXi + (size_t)i * 2 * nx, *psi = dPsi + (size_t)i * nu;
+            if (k < N - 1) for (int t = 0; t < nv; t++) sig[t] += rj[t];
+            gemv_n(nv, nv, (real)-0.5, o->Omega + (size_t)o->opIdx[i] * nv * nv, nv, sig, 0, v);
+            if (k < N - 1) gemv_n(nv, nx, 1, o->Theta + (size_t)o->opIdx[i] * nv * nx, nv, qj, 1, v);
+            gemv_n(nv, nu, 1, o->Psi + (size_t)i * nv * nu, nv, psi, 1, v);
+            gemv_n(nv, 2 * nx, 1, o->Phi + (size_t)i * nv * 2 * nx, nv, xi, 1, v);
+            memcpy(rj, sig, nv * sizeof(real));
+            gemv_n(nv, 2 * nx, 1, o->D + (size_t)i * nv * 2 * nx, nv, xi, 1, rj);
+            gemv_n(nv, nu, 1, o->Ftil + (size_t)i * nv * nu, nv, psi, 1, rj);
+            if (k < N - 1) gemv_n(nv, nx, 1, o->Gtil, nv, qj, 1, rj);
+            const real *F = o->sysF + (size_t)i * 2 * nx * nx;
+            for (int t = 0; t < nx; t++) {
+                real s = F[(size_t)2 * nx * t + t] * xi[t] + F[(size_t)2 * nx * t + nx + t] * xi[nx + t];
+                qj[t] = (k < N - 1) ? s + qj[t] : s;
+            }
+        }
+        if (k > 0) {
+            int pn = o->nodesPerStage[k - 1], pc = o->nodesPerStageCumul[k - 1];
+            if (nk - pn > 0) {
+                sum_children(o, o->q, tmpQ, pc, pn, k - 1, nx);
+                sum_children(o, o->r, tmpR, pc, pn, k - 1, nv);
+                memcpy(o->r, tmpR, (size_t)pn * nv * sizeof(real));
+                memcpy(o->q, tmpQ, (size_t)pn * nx * sizeof(real));
+            }
+        }
+    }
+    for (int k = 0; k < N; k++) {                                                                  /* :998-1046 */
+        int cum = o->nodesPerStageCumul[k], nk = o->nodesPerStage[k];
+        if (k == 0) {
+            gemv_n(nu, nv, 1, o->L, nu, o->v, 0, o->udir);
+            gemv_n(nx, nu, 1, o->B, nx, o->udir, 0, o->xdir);
+        } else {
+            int pc = o->nodesPerStageCumul[k - 1], pn = o->nodesPerStage[k - 1];
+            for (int j = 0; j < nk; j++) gemv_n(nu, nv, 1, o->L, nu, o->v + (size_t)(cum + j) * nv, 0, o->udir + (size_t)(cum + j) * nu);
+            if (nk - pn > 0) {
+                int prevAnc = o->ancestor[cum];
+                for (int j = 0; j < nk; j++) {
+                    int a = o->ancestor[cum + j] - prevAnc;
+                    for (int t = 0; t < nu; t++) o->udir[(size_t)(cum + j) * nu + t] += o->udir[(size_t)(pc + a) * nu + t];
+                }
+                for (int j = 0; j < nk; j++) gemv_n(nx, nu, 1, o->B, nx, o->udir + (size_t)(cum + j) * nu, 0, o->xdir + (size_t)(cum + j) * nx);
+                for (int j = 0; j < nk; j++) {
+                    int a = o->ancestor[cum + j] - prevAnc;
+                    for (int t = 0; t < nx; t++) o->xdir[(size_t)(cum + j) * nx + t] += o->xdir[(size_t)(pc + a) * nx + t];
+                }
+            } else {
+                for (size_t t = 0; t < (size_t)nk * nu; t++) o->udir[(size_t)cum * nu + t] += o->udir[(size_t)pc * nu + t];
+                memcpy(o->xdir + (size_t)cum * nx, o->xdir + (size_t)pc * nx, (size_t)nk * nx * sizeof(real));
+                for (int j = 0; j < nk; j++) gemv_n(nx, nu, 1, o->B, nx, o->udir + (size_t)(cum + j) * nu, 1, o->xdir + (size_t)(cum + j) * nx);
+            }
+        }
+    }
+    for (int i = 0; i < nodes; i++) {                                                              /* :1049-1052 */
+        const real *F = o->sysF + (size_t)i * 2 * nx * nx, *G = o->sysG + (size_t)i * nu * nu;
+        for (int t = 0; t < nx; t++) {
+            o->primalXiDir[(size_t)i * 2 * nx + t] = F[(size_t)2 * nx * t + t] * o->xdir[(size_t)i * nx + t];
+            o->primalXiDir[(size_t)i * 2 * nx + nx + t] = F[(size_t)2 * nx * t + nx + t] * o->xdir[(size_t)i * nx + t];
+        }
+        for (int t = 0; t < nu; t++) o->primalPsiDir[(size_t)i * nu + t] = G[(size_t)nu * t + t] * o->udir[(size_t)i * nu + t];
+    }
+    free(tmpQ); free(tmpR); free(Lv);
+}
+/* the oracle's input is whatever devPtrVecHessianOracleXi/Psi point at: the FBE gradient (:356-357) or, for NAMA,
+ * the fixed-point residual (:408-409) */
+void oracle_hessian_oracle(oracle_t *o) {
+    if (o->algorithm == 2) hessian_oracle(o, o->resXi, o->resPsi);
+    else hessian_oracle(o, o->gradXi, o->gradPsi);
+}
+
+/* SmpcController::computeGradientFbe, SmpcController.cu:1077-1097 */
+void oracle_gradient_fbe(oracle_t *o) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu;
+    for (size_t i = 0; i < nxi; i++) o->gradXi[i] = -o->resXi[i];
+    for (size_t i = 0; i < nps; i++) o->gradPsi[i] = -o->resPsi[i];
+    hessian_oracle(o, o->gradXi, o->gradPsi);
+    for (size_t i = 0; i < nxi; i++) o->gradXi[i] += o->stepSize * o->primalXiDir[i];
+    for (size_t i = 0; i < nps; i++) o->gradPsi[i] += o->stepSize * o->primalPsiDir[i];
+}
+/* SmpcController::updateFixedPointResidualNamaAlgorithm, SmpcController.cu:1060-1072 */
+void oracle_nama_residual(oracle_t *o) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu;
+    for (size_t i = 0; i < nxi; i++) o->curResXi[i] = -o->resXi[i];
+    for (size_t i = 0; i < nps; i++) o->curResPsi[i] = -o->resPsi[i];
+}
+
+static double dot2(const real *a, const real *b, size_t n) { double s = 0; for (size_t i = 0; i < n; i++) s += (double)a[i] * (double)b[i]; return s; }
+
+/* SmpcController::updateLbfgsBuffer, SmpcController.cu:1103-1169 */
+static void lbfgs_update(oracle_t *o) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, n = nxi + nps;
+    real *curYXi = o->algorithm == 1 ? o->gradXi : o->curResXi, *curYPsi = o->algorithm == 1 ? o->gradPsi : o->curResPsi;
+    real *prvYXi = o->algorithm == 1 ? o->prevGradXi : o->prevResXi, *prvYPsi = o->algorithm == 1 ? o->prevGradPsi : o->prevResPsi;
+    real *S = ralloc(n), *Y = ralloc(n);
+    for (size_t i = 0; i < nxi; i++) { S[i] = o->xi[i] - o->prevXi[i]; Y[i] = curYXi[i] - prvYXi[i]; }
+    for (size_t i = 0; i < nps; i++) { S[nxi + i] = o->psi[i] - o->prevPsi[i]; Y[nxi + i] = curYPsi[i] - prvYPsi[i]; }
+    real normGrad = (real)sqrt(dot2(curYXi, curYXi, nxi) + dot2(curYPsi, curYPsi, nps));
+    real invRho = (real)dot2(S, Y, n), normY = (real)sqrt(dot2(Y, Y, n)), normS = (real)sqrt(dot2(S, S, n));
+    if (normGrad < 1) normGrad = normGrad * normGrad * normGrad;                                   /* :1133-1135 */
+    if (invRho / (normS * normS) > (real)1e-6 * normGrad) {                                        /* :1137 */
+        o->lbfgsCol = 1 + (o->lbfgsCol % o->lbfgsSize);
+        o->lbfgsMem = o->lbfgsMem + 1 < o->lbfgsSize ? o->lbfgsMem + 1 : o->lbfgsSize;
+        memcpy(o->matY + (size_t)o->lbfgsCol * n, Y, n * sizeof(real));
+        memcpy(o->matS + (size_t)o->lbfgsCol * n, S, n * sizeof(real));
+        o->rho[o->lbfgsCol] = 1 / invRho;
+    } else o->lbfgsSkip++;
+    real gammaH = invRho / (normY * normY);                                                        /* :1151-1156 */
+    if (gammaH < 0 || fabs((double)(gammaH - o->lbfgsH)) == 0) o->lbfgsH = 1; else o->lbfgsH = gammaH;
+    for (size_t i = 0; i < nxi; i++) o->dirXi[i] = -curYXi[i];                                     /* :1158-1161 */
+    for (size_t i = 0; i < nps; i++) o->dirPsi[i] = -curYPsi[i];
+    free(S); free(Y);
+}
+/* SmpcController::twoLoopRecursionLbfgs, SmpcController.cu:1175-1229 */
+static void lbfgs_two_loop(oracle_t *o) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, n = nxi + nps;
+    real *alpha = ralloc((size_t)o->lbfgsSize + 1);
+    for (int is = 0; is < o->lbfgsMem; is++) {
+        int c = o->lbfgsCol - is;
+        if (c < 0) c = o->lbfgsMem + c;
+        const real *Sc = o->matS + (size_t)c * n, *Yc = o->matY + (size_t)c * n;
+        alpha[c] = o->rho[c] * (real)(dot2(Sc, o->dirXi, nxi) + dot2(Sc + nxi, o->dirPsi, nps));
+        for (size_t i = 0; i < nxi; i++) o->dirXi[i] += -alpha[c] * Yc[i];
+        for (size_t i = 0; i < nps; i++) o->dirPsi[i] += -alpha[c] * Yc[nxi + i];
+    }
+    for (size_t i = 0; i < nxi; i++) o->dirXi[i] *= o->lbfgsH;
+    for (size_t i = 0; i < nps; i++) o->dirPsi[i] *= o->lbfgsH;
+    for (int is = o->lbfgsMem; is > 0; is--) {
+        int c = o->lbfgsCol - is + 1;
+        if (c < 0) c = o->lbfgsMem + c;
+        const real *Sc = o->matS + (size_t)c * n, *Yc = o->matY + (size_t)c * n;
+        real beta = o->rho[c] * (real)(dot2(Yc, o->dirXi, nxi) + dot2(Yc + nxi, o->dirPsi, nps));
+        real sc = alpha[c] - beta;
+        for (size_t i = 0; i < nxi; i++) o->dirXi[i] += sc * Sc[i];
+        for (size_t i = 0; i < nps; i++) o->dirPsi[i] += sc * Sc[nxi + i];
+    }
+    free(alpha);
+}
+/* SmpcController::computeLbfgsDirection, SmpcController.cu:1234-1237 */
+void oracle_lbfgs_direction(oracle_t *o) { lbfgs_update(o); lbfgs_two_loop(o); }
+
+/* SmpcController::computeValueFbe, SmpcController.cu:1416-1476 */
+double oracle_value_fbe(oracle_t *o) {
+    int nu = o->nu, nodes = o->nodes;
+    size_t nxi = (size_t)nodes * 2 * o->nx, nps = (size_t)nodes * nu;
+    real cost = (real)(dot2(o->accXi, o->resXi, nxi) + dot2(o->accPsi, o->resPsi, nps));
+    real nX = (real)sqrt(dot2(o->resXi, o->resXi, nxi)), nP = (real)sqrt(dot2(o->resPsi, o->resPsi, nps));
+    cost = cost + (real)0.5 * o->stepSize * (nX * nX + nP * nP);
+    cost = cost + o->valueGuBox + o->valueGxBox + o->valueGxSafe;
+    real *dU = ralloc(nps), *WdU = ralloc(nps);
+    for (int i = 0; i < nodes; i++)                                    /* calculateDiffUhat on u (Utilities.cu:69-88) */
+        for (int t = 0; t < nu; t++)
+            dU[(size_t)i * nu + t] = (i == 0) ? o->u[t] - o->prevU[t] : o->u[(size_t)i * nu + t] - o->u[(size_t)(o->ancestor[i] - 1) * nu + t];
+    for (int i = 0; i < nodes; i++) gemv_n(nu, nu, 1, o->W, nu, dU + (size_t)i * nu, 0, WdU + (size_t)i * nu);
+    double quad = 0, lin = 0;
+    for (int i = 0; i < nodes; i++)
+        for (int t = 0; t < nu; t++) {
+            quad += (double)(o->prob[i] * dU[(size_t)i * nu + t]) * (double)WdU[(size_t)i * nu + t];
+            lin += (double)(o->prob[i] * o->u[(size_t)i * nu + t]) * (double)o->alpha[(size_t)i * nu + t];
+        }
+    cost = cost + (real)quad;
+    cost = cost + (real)lin;
+    free(dU); free(WdU);
+    return (double)cost;
+}
+
+/* common tail of the two line searches (SmpcController.cu:1272-1300 and 1381-1409) */
+static real line_search_loop(oracle_t *o, real valueY) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, nxx = (size_t)o->nodes * o->nx;
+    real tau = 1;
+    int maxStep = 10, iStep = 0;
+    while (iStep < maxStep + 1) {
+        for (size_t i = 0; i < nxx; i++) o->x[i] += tau * o->xdir[i];
+        for (size_t i = 0; i < nps; i++) o->u[i] += tau * o->udir[i];
+        for (size_t i = 0; i < nxi; i++) o->accXi[i] += tau * o->dirXi[i];
+        for (size_t i = 0; i < nps; i++) o->accPsi[i] += tau * o->dirPsi[i];
+        for (size_t i = 0; i < nxi; i++) o->primalXi[i] += tau * o->primalXiDir[i];
+        for (size_t i = 0; i < nps; i++) o->primalPsi[i] += tau * o->primalPsiDir[i];
+        oracle_prox(o);
+        oracle_residual(o);
+        real val = (real)oracle_value_fbe(o);
+        if (val <= valueY) {
+            iStep = iStep + 1;
+            if (iStep < maxStep) {
+                if (iStep == 1) tau = -1;
+                tau = tau + (real)(1 / pow(2, iStep));
+            }
+        } else iStep = maxStep + 1;
+    }
+    return tau;
+}
+/* SmpcController::computeLineSearchLbfgsUpdate, SmpcController.cu:1242-1305 */
+double oracle_line_search_fbe(oracle_t *o, double valueFbeY) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu;
+    real tau = 1;
+    hessian_oracle(o, o->dirXi, o->dirPsi);   /* the swap / oracle / swap of :1251-1255 */
+    real valueDirection = (real)(dot2(o->gradXi, o->dirXi, nxi) + dot2(o->gradPsi, o->dirPsi, nps));
+    if (valueDirection > 0) { /* "LBFGS direction is positive": nothing is applied, tau stays 1 (:1262-1263) */ }
+    else if (fabs((double)valueDirection) < 1e-4) tau = 0;
+    else tau = line_search_loop(o, (real)valueFbeY);
+    return fabs((double)tau);
+}
+/* SmpcController::computeLineSearchAmeLbfgsUpdate, SmpcController.cu:1311-1414 */
+double oracle_line_search_ame(oracle_t *o, double valueAmeY) {
+    size_t nxi = (size_t)o->nodes * 2 * o->nx, nps = (size_t)o->nodes * o->nu, nxx = (size_t)o->nodes * o->nx;
+    real tau = 1, alpha = o->stepSize;
+    real valueDirection = -(real)(dot2(o->resXi, o->dirXi, nxi) + dot2(o->resPsi, o->dirPsi, nps));
+    hessian_oracle(o, o->resXi, o->resPsi);                                                        /* :1331 */
+    for (size_t i = 0; i < nxi; i++) o->accXi[i] += alpha * o->resXi[i];                           /* :1332-1337 */
+    for (size_t i = 0; i < nps; i++) o->accPsi[i] += alpha * o->resPsi[i];
+    for (size_t i = 0; i < nxx; i++) o->x[i] += alpha * o->xdir[i];
+    for (size_t i = 0; i < nps; i++) o->u[i] += alpha * o->udir[i];
+    for (size_t i = 0; i < nxi; i++) o->primalXi[i] += alpha * o->primalXiDir[i];
+    for (size_t i = 0; i < nps; i++) o->primalPsi[i] += alpha * o->primalPsiDir[i];
+    for (size_t i = 0; i < nxi; i++) o->dirXi[i] += -o->stepSize * o->resXi[i];                    /* :1338-1340 */
+    for (size_t i = 0; i < nps; i++) o->dirPsi[i] += -o->stepSize * o->resPsi[i];
+    hessian_oracle(o, o->dirXi, o->dirPsi);                                                        /* swap / oracle / swap :1341-1345 */
+    if (valueDirection > 0) { }
+    else if (fabs((double)valueDirection) < 1e-4) tau = 0;
+    else tau = line_search_loop(o, (real)valueAmeY);
+    return fabs((double)tau);
+}
+
+/* SmpcController::algorithmGlobalFbe (:1529-1555) / algorithmNama (:1559-1586).  hist: vecPrimalInfs[iter];
+ * valueFbe / tau (may be NULL): vecValueFbe[iter-1], vecTau[iter-1] */
+void oracle_fbe_nama(oracle_t *o, int maxIterations, double *hist, double *valueFbe, double *tauHist) {
+    oracle_fbe_reset(o);
+    for (int it = 0; it < maxIterations; it++) {
+        oracle_solve_step(o);
+        oracle_prox(o);
+        oracle_residual(o);
+        if (o->algorithm == 1) oracle_gradient_fbe(o); else oracle_nama_residual(o);
+        if (it > 0) {
+            double val = oracle_value_fbe(o);
+            oracle_lbfgs_direction(o);
+            double tau = o->algorithm == 1 ? oracle_line_search_fbe(o, val) : oracle_line_search_ame(o, val);
+            if (valueFbe) valueFbe[it - 1] = val;
+            if (tauHist) tauHist[it - 1] = tau;
+        }
+        oracle_dual_update(o);
+        double inf = oracle_primal_infeasibility(o);
+        if (hist) hist[it] = inf;
+    }
+}
+void oracle_lbfgs_state(oracle_t *o, int set, int *col, int *mem, double *H) {
+    if (set) { o->lbfgsCol = *col; o->lbfgsMem = *mem; o->lbfgsH = (real)*H; }
+    else { *col = o->lbfgsCol; *mem = o->lbfgsMem; *H = (double)o->lbfgsH; }
+}
+
 int oracle_sizeof_real(void) { return (int)sizeof(real); }
 int oracle_final_branch_node(const oracle_t *o) { return o->finalBranchNode; }
 double oracle_dist(const oracle_t *o, int which) { return which ? (double)o->distXs : (double)o->distXcst; }
@@ -673,6 +991,19 @@ real *oracle_buffer(oracle_t *o, const char *name, long *count) {
     BUF("Phi", o->Phi, n * nv * 2 * nx) BUF("D", o->D, n * nv * 2 * nx)
     BUF("Psi", o->Psi, n * nv * nu) BUF("Ftil", o->Ftil, n * nv * nu) BUF("Gtil", o->Gtil, (size_t)nv * nx)
     BUF("prevUhat", o->prevUhat, nu) BUF("curX", o->curX, nx) BUF("prevU", o->prevU, nu)
+    if (o->matS) {
+        size_t nall = n * (2 * nx + nu);
+        BUF("prevXi", o->prevXi, n * 2 * nx) BUF("prevPsi", o->prevPsi, n * nu)
+        BUF("gradXi", o->gradXi, n * 2 * nx) BUF("gradPsi", o->gradPsi, n * nu)
+        BUF("prevGradXi", o->prevGradXi, n * 2 * nx) BUF("prevGradPsi", o->prevGradPsi, n * nu)
+        BUF("curResXi", o->curResXi, n * 2 * nx) BUF("curResPsi", o->curResPsi, n * nu)
+        BUF("prevResXi", o->prevResXi, n * 2 * nx) BUF("prevResPsi", o->prevResPsi, n * nu)
+        BUF("dirXi", o->dirXi, n * 2 * nx) BUF("dirPsi", o->dirPsi, n * nu)
+        BUF("xdir", o->xdir, n * nx) BUF("udir", o->udir, n * nu)
+        BUF("primalXiDir", o->primalXiDir, n * 2 * nx) BUF("primalPsiDir", o->primalPsiDir, n * nu)
+        BUF("matS", o->matS, (size_t)(o->lbfgsSize + 1) * nall) BUF("matY", o->matY, (size_t)(o->lbfgsSize + 1) * nall)
+        BUF("rho", o->rho, (size_t)o->lbfgsSize + 1)
+    }
     BUF("L", o->L, (size_t)nu * nv) BUF("B", o->B, (size_t)nx * nu) BUF("Wv", o->Wv, (size_t)nu * nv)
 #undef BUF
     *count = 0;

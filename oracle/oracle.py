@@ -70,6 +70,18 @@ def _lib(precision):
         lib.oracle_final_branch_node.argtypes = [C.c_void_p]
         lib.oracle_dist.restype = C.c_double
         lib.oracle_dist.argtypes = [C.c_void_p, C.c_int]
+        lib.oracle_set_algorithm.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for fn in ("oracle_fbe_reset", "oracle_hessian_oracle", "oracle_gradient_fbe", "oracle_nama_residual",
+                   "oracle_lbfgs_direction"):
+            getattr(lib, fn).argtypes = [C.c_void_p]
+        lib.oracle_value_fbe.restype = C.c_double
+        lib.oracle_value_fbe.argtypes = [C.c_void_p]
+        for fn in ("oracle_line_search_fbe", "oracle_line_search_ame"):
+            getattr(lib, fn).restype = C.c_double
+            getattr(lib, fn).argtypes = [C.c_void_p, C.c_double]
+        lib.oracle_fbe_nama.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_lbfgs_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_double)]
         _LIBS[tag] = lib
     return _LIBS[tag]
 
@@ -199,6 +211,53 @@ class Oracle:
 
     def dist(self):
         return self.lib.oracle_dist(self.h, 0), self.lib.oracle_dist(self.h, 1)
+
+    # --- global FBE / NAMA (SmpcController.cu:884-1476, 1529-1586) ------------------------------------
+    ALGORITHMS = {"proximalAlgorithm": 0, "globalFbeAlgorithm": 1, "namaAlgorithm": 2}  # Engine.cu:151-163
+
+    def set_algorithm(self, name, lbfgs_buffer_size=None):
+        if lbfgs_buffer_size is None:
+            lbfgs_buffer_size = int(_scalar(self.config, "lbfgsBufferSize")) if "lbfgsBufferSize" in self.config else 5
+        self.algorithm = self.ALGORITHMS[name]
+        self.lbfgs_size = int(lbfgs_buffer_size)
+        self.lib.oracle_set_algorithm(self.h, self.algorithm, self.lbfgs_size)
+
+    def fbe_reset(self):
+        self.lib.oracle_fbe_reset(self.h)
+
+    def hessian_oracle(self):
+        self.lib.oracle_hessian_oracle(self.h)
+
+    def gradient_fbe(self):
+        self.lib.oracle_gradient_fbe(self.h)
+
+    def nama_residual(self):
+        self.lib.oracle_nama_residual(self.h)
+
+    def lbfgs_direction(self):
+        self.lib.oracle_lbfgs_direction(self.h)
+
+    def value_fbe(self):
+        return self.lib.oracle_value_fbe(self.h)
+
+    def line_search_fbe(self, value_y):
+        return self.lib.oracle_line_search_fbe(self.h, float(value_y))
+
+    def line_search_ame(self, value_y):
+        return self.lib.oracle_line_search_ame(self.h, float(value_y))
+
+    def lbfgs_state(self, col=None, mem=None, H=None):
+        """get (no arguments) or set (col, mem, H) lbfgsBufferCol / lbfgsBufferMemory / lbfgsBufferHessian."""
+        c, m, h = C.c_int(0 if col is None else col), C.c_int(0 if mem is None else mem), C.c_double(0 if H is None else H)
+        self.lib.oracle_lbfgs_state(self.h, 0 if col is None else 1, C.byref(c), C.byref(m), C.byref(h))
+        return c.value, m.value, h.value
+
+    def fbe_nama(self, iters=None):
+        """algorithmGlobalFbe / algorithmNama: returns (vecPrimalInfs, vecValueFbe, vecTau)."""
+        iters = self.max_iterations if iters is None else int(iters)
+        hist, val, tau = (np.zeros(max(iters, 1)) for _ in range(3))
+        self.lib.oracle_fbe_nama(self.h, iters, hist.ctypes.data, val.ctypes.data, tau.ctypes.data)
+        return hist[:iters], val[: max(iters - 1, 0)], tau[: max(iters - 1, 0)]
 
     @property
     def final_branch_node(self):

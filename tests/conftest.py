@@ -21,5 +21,6 @@ def ref_fixture():
     from oracle.oracle import load_json
 
     names = {"network": "network.json", "tree": "scenarioTree.json", "config": "controllerConfig.json",
-             "forecast": "forecastor.json", "engine": "engineTest.json", "smpc": "smpcTest.json"}
+             "forecast": "forecastor.json", "engine": "engineTest.json", "smpc": "smpcTest.json",
+             "smpc_fbe": "smpcFbeTest.json", "smpc_nama": "smpcNamaTest.json"}
     return {k: load_json(os.path.join(REF_FIXTURE, v)) for k, v in names.items()}
