@@ -93,6 +93,14 @@ enum {
     RN_BUF_ALPHA,      /* Engine devVecAlpha nodes*nu (getPriceAlpha) */
     RN_BUF_XMIN, RN_BUF_XMAX, RN_BUF_XS, /* scaled bounds, nodes*nx */
     RN_BUF_UMIN, RN_BUF_UMAX,            /* nodes*nu */
+    /* global FBE / NAMA (valid after rn_set_algorithm selected one of them) */
+    RN_BUF_PREV_XI, RN_BUF_PREV_PSI,                       /* devVecPrevXi / devVecPrevPsi                              */
+    RN_BUF_LBFGS_CUR_YVEC_XI, RN_BUF_LBFGS_CUR_YVEC_PSI,   /* ptrLbfgsCurrentYvec*: devVecGradientFbe* (FBE) or
+                                                              devVecCurrentFixedPointResidual* (NAMA), SmpcController.cu:513-524 */
+    RN_BUF_LBFGS_PREV_YVEC_XI, RN_BUF_LBFGS_PREV_YVEC_PSI, /* ptrLbfgsPreviousYvec*                                     */
+    RN_BUF_LBFGS_DIR_XI, RN_BUF_LBFGS_DIR_PSI,             /* devVecLbfgsDirXi / Psi                                    */
+    RN_BUF_PRIMAL_XI_DIR, RN_BUF_PRIMAL_PSI_DIR,           /* devVecPrimalXiDir / PsiDir                                */
+    RN_BUF_XDIR, RN_BUF_UDIR,                              /* devVecXdir nodes*nx, devVecUdir nodes*nu                  */
     RN_BUF_COUNT
 };
 
@@ -160,6 +168,33 @@ int rn_dual_update(rn_ctx *ctx);                            /* SmpcController.cu
 int rn_update_primal_infeasibility(rn_ctx *ctx, double *value); /* SmpcController.cu:1480-1496 */
 /* tree-global distances computed by the last prox (SmpcController.cu:792,810) */
 int rn_get_prox_distances(rn_ctx *ctx, double *distanceXcst, double *distanceXs);
+
+/* ---- SmpcController: the global-FBE and NAMA loops --------------------- */
+/* Engine's algorithm flags (Engine.cu:151-163, "algorithmName" of the controller configuration).  Selecting FBE or
+ * NAMA allocates their vectors and the L-BFGS buffers (SmpcController::allocateGlobalFbeAlgorithm /
+ * allocateNamaAlgorithm / allocateLbfgsBuffer, SmpcController.cu:234-330) and runs rn_fbe_reset.  Single GPU. */
+enum { RN_ALG_APG = 0, RN_ALG_GLOBAL_FBE = 1, RN_ALG_NAMA = 2 };
+int rn_set_algorithm(rn_ctx *ctx, int algorithm, int lbfgsBufferSize);
+/* SmpcController::initialiseAlgorithm (FBE / NAMA part, :436-449) + initaliseLbfgBuffer (:453-468) */
+int rn_fbe_reset(rn_ctx *ctx);
+/* SmpcController::algorithmGlobalFbe (:1529-1555) or algorithmNama (:1559-1586), whichever is selected.
+ * primalInfs[maxIterations] = vecPrimalInfs, valueFbe / tau [maxIterations-1] = vecValueFbe / vecTau (may be NULL). */
+int rn_algorithm_fbe_nama(rn_ctx *ctx, int maxIterations, double *primalInfs, double *valueFbe, double *tau);
+/* step-wise entry points (the reference's known-answer tests call these protected methods);
+ * rn_dual_update takes the FBE / NAMA branch (SmpcController.cu:866-880) once one of them is selected */
+int rn_compute_hessian_oracle(rn_ctx *ctx);                 /* computeHessianOracalGlobalFbe          :884-1055  */
+int rn_compute_gradient_fbe(rn_ctx *ctx);                   /* computeGradientFbe                     :1077-1097 */
+int rn_update_fixed_point_residual_nama(rn_ctx *ctx);       /* updateFixedPointResidualNamaAlgorithm  :1060-1072 */
+int rn_compute_lbfgs_direction(rn_ctx *ctx);                /* computeLbfgsDirection                  :1103-1237 */
+int rn_compute_value_fbe(rn_ctx *ctx, double *value);       /* computeValueFbe                        :1416-1476 */
+int rn_line_search_lbfgs_update(rn_ctx *ctx, double valueFbeY, double *tau);     /* computeLineSearchLbfgsUpdate    :1242-1305 */
+int rn_line_search_ame_lbfgs_update(rn_ctx *ctx, double valueAmeY, double *tau); /* computeLineSearchAmeLbfgsUpdate :1311-1414 */
+/* lbfgsBufferCol / lbfgsBufferMemory / lbfgsBufferHessian and lbfgsBufferRho (lbfgsBufferSize + 1 entries, the
+ * reference addresses entries 1..lbfgsBufferSize; rho may be NULL): get (set = 0) or set (set = 1) */
+int rn_lbfgs_state(rn_ctx *ctx, int set, int *col, int *mem, double *H, double *rho);
+/* one column (0..lbfgsBufferSize) of devLbfgsBufferMatS (which = 0) / MatY (which = 1), nodes*(2nx+nu) reals in the
+ * reference's order (all xi, then all psi) */
+int rn_lbfgs_column(rn_ctx *ctx, int set, int which, int col, double *host, size_t n);
 
 /* ---- raw access (tests, closed loop) ------------------------------------------------------------- */
 size_t rn_buffer_size(const rn_ctx *ctx, int buffer_id); /* element count, 0 for a bad id */

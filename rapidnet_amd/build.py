@@ -23,7 +23,8 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     `defines` / `out` build tuning variants (e.g. RN_STREAM_G=6) next to the default library; capi.load() picks the
     library named by $RAPIDNET_LIB when set."""
     out = out or LIB_HIP
-    srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "rapidnet.h")]
+    srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "fbe_kernels.hpp"),
+            os.path.join(CSRC, "fbe_methods.inc"), os.path.join(ROOT, "include", "rapidnet.h")]
     if force or _stale(out, srcs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
                "-Wno-pass-failed"] + ["-D" + d for d in defines] + ["-o", out, srcs[0], "-ldl"]

@@ -12,7 +12,12 @@ from . import build as _build
 RN_F32, RN_F64 = 0, 1
 (BUF_X, BUF_U, BUF_V, BUF_XI, BUF_PSI, BUF_ACC_XI, BUF_ACC_PSI, BUF_UPD_XI, BUF_UPD_PSI, BUF_PRIMAL_XI,
  BUF_PRIMAL_PSI, BUF_DUAL_XI, BUF_DUAL_PSI, BUF_RES_XI, BUF_RES_PSI, BUF_UHAT, BUF_E, BUF_BETA, BUF_ALPHA,
- BUF_XMIN, BUF_XMAX, BUF_XS, BUF_UMIN, BUF_UMAX) = range(24)
+ BUF_XMIN, BUF_XMAX, BUF_XS, BUF_UMIN, BUF_UMAX,
+ BUF_PREV_XI, BUF_PREV_PSI, BUF_LBFGS_CUR_YVEC_XI, BUF_LBFGS_CUR_YVEC_PSI, BUF_LBFGS_PREV_YVEC_XI,
+ BUF_LBFGS_PREV_YVEC_PSI, BUF_LBFGS_DIR_XI, BUF_LBFGS_DIR_PSI, BUF_PRIMAL_XI_DIR, BUF_PRIMAL_PSI_DIR,
+ BUF_XDIR, BUF_UDIR) = range(36)
+ALG_APG, ALG_GLOBAL_FBE, ALG_NAMA = 0, 1, 2
+ALGORITHMS = {"proximalAlgorithm": ALG_APG, "globalFbeAlgorithm": ALG_GLOBAL_FBE, "namaAlgorithm": ALG_NAMA}  # Engine.cu:151-163
 OP_PHI, OP_PSI, OP_D, OP_F, OP_OMEGA, OP_THETA, OP_G = range(7)
 
 # every symbol include/rapidnet.h declares
@@ -25,6 +30,9 @@ SYMBOLS = [
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
+    "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
+    "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_compute_value_fbe",
+    "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
 ]
 
 
@@ -100,6 +108,16 @@ def load():
     lib.rn_set_exchange_mode.argtypes = [vp, ip]
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
     lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
+    lib.rn_set_algorithm.argtypes = [vp, ip, ip]
+    for f in ("rn_fbe_reset", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe", "rn_update_fixed_point_residual_nama",
+              "rn_compute_lbfgs_direction"):
+        getattr(lib, f).argtypes = [vp]
+    lib.rn_algorithm_fbe_nama.argtypes = [vp, ip, dp, dp, dp]
+    lib.rn_compute_value_fbe.argtypes = [vp, dp]
+    lib.rn_line_search_lbfgs_update.argtypes = [vp, C.c_double, dp]
+    lib.rn_line_search_ame_lbfgs_update.argtypes = [vp, C.c_double, dp]
+    lib.rn_lbfgs_state.argtypes = [vp, ip, dp, dp, dp, dp]
+    lib.rn_lbfgs_column.argtypes = [vp, ip, ip, ip, dp, C.c_size_t]
     _LIB = lib
     return lib
 
@@ -257,6 +275,77 @@ class Solver:
         a, b = C.c_double(0), C.c_double(0)
         self._check(self.lib.rn_get_prox_distances(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    # ---- global FBE / NAMA (SmpcController.cu:884-1476, 1529-1586) ---------------------------------------------
+    def setAlgorithm(self, name, lbfgsBufferSize=None):
+        if lbfgsBufferSize is None:
+            lbfgsBufferSize = int(_s(self.config, "lbfgsBufferSize")) if "lbfgsBufferSize" in self.config else 5
+        self.algorithm = ALGORITHMS[name] if isinstance(name, str) else int(name)
+        self.lbfgsBufferSize = int(lbfgsBufferSize)
+        self._check(self.lib.rn_set_algorithm(self.h, self.algorithm, self.lbfgsBufferSize))
+
+    def fbeReset(self):
+        self._check(self.lib.rn_fbe_reset(self.h))
+
+    def _algorithmFbeNama(self, maxIterations):
+        n = self.max_iterations if maxIterations is None else int(maxIterations)
+        hist, val, tau = (np.zeros(max(n, 1)) for _ in range(3))
+        self._check(self.lib.rn_algorithm_fbe_nama(self.h, n, hist.ctypes.data, val.ctypes.data, tau.ctypes.data))
+        return hist[:n], val[: max(n - 1, 0)], tau[: max(n - 1, 0)]
+
+    def algorithmGlobalFbe(self, maxIterations=None):
+        """returns (vecPrimalInfs, vecValueFbe, vecTau)"""
+        assert getattr(self, "algorithm", ALG_APG) == ALG_GLOBAL_FBE
+        return self._algorithmFbeNama(maxIterations)
+
+    def algorithmNama(self, maxIterations=None):
+        assert getattr(self, "algorithm", ALG_APG) == ALG_NAMA
+        return self._algorithmFbeNama(maxIterations)
+
+    def computeHessianOracalGlobalFbe(self):
+        self._check(self.lib.rn_compute_hessian_oracle(self.h))
+
+    def computeGradientFbe(self):
+        self._check(self.lib.rn_compute_gradient_fbe(self.h))
+
+    def updateFixedPointResidualNamaAlgorithm(self):
+        self._check(self.lib.rn_update_fixed_point_residual_nama(self.h))
+
+    def computeLbfgsDirection(self):
+        self._check(self.lib.rn_compute_lbfgs_direction(self.h))
+
+    def computeValueFbe(self):
+        v = C.c_double(0)
+        self._check(self.lib.rn_compute_value_fbe(self.h, C.byref(v)))
+        return v.value
+
+    def computeLineSearchLbfgsUpdate(self, valueFbeY):
+        t = C.c_double(0)
+        self._check(self.lib.rn_line_search_lbfgs_update(self.h, float(valueFbeY), C.byref(t)))
+        return t.value
+
+    def computeLineSearchAmeLbfgsUpdate(self, valueAmeY):
+        t = C.c_double(0)
+        self._check(self.lib.rn_line_search_ame_lbfgs_update(self.h, float(valueAmeY), C.byref(t)))
+        return t.value
+
+    def lbfgsState(self, col=None, mem=None, H=None, rho=None):
+        """get (no arguments) or set lbfgsBufferCol / Memory / Hessian / Rho; returns (col, mem, H, rho[size+1])."""
+        c, m, h = C.c_int(0 if col is None else col), C.c_int(0 if mem is None else mem), C.c_double(0 if H is None else H)
+        r = np.zeros(self.lbfgsBufferSize + 1)
+        if rho is not None:
+            r[:] = rho
+        self._check(self.lib.rn_lbfgs_state(self.h, 0 if col is None else 1, C.addressof(c), C.addressof(m), C.addressof(h),
+                                            r.ctypes.data))
+        return c.value, m.value, h.value, r
+
+    def lbfgsColumn(self, which, col, values=None):
+        """column `col` of matS (which=0) / matY (which=1) in the reference's (all xi | all psi) order."""
+        n = self.nodes * (2 * self.nx + self.nu)
+        a = np.zeros(n) if values is None else _f64(values).copy()
+        assert a.size == n
+        self._check(self.lib.rn_lbfgs_column(self.h, 0 if values is None else 1, int(which), int(col), a.ctypes.data, n))
+        return a
 
     # ---- raw access -----------------------------------------------------------------------------------------
     def get(self, buf):

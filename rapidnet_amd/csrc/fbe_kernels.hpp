@@ -1,0 +1,159 @@
+// fbe_kernels.hpp -- device kernels of the global-FBE and NAMA outer loops (SURVEY.md section 8(f) rank 3;
+// SmpcController.cu:884-1476).  The expensive part of both loops is the Hessian oracle, which is the tree sweep of
+// kernels.hpp run with zero affine terms; what is here is the vector algebra around it: deterministic multi-dot
+// reductions, the L-BFGS two-loop updates driven by device-resident scalars (no host round trip inside the
+// recursion), the line-search trial step and the FBE value terms.  All of it is HBM-bound streaming over the dual
+// vectors in the y layout ([node][2nx | nu]); dot products are permutation invariant, so the layout
+// difference to the reference's (all xi | all psi) vectors does not change any value.
+#ifndef RAPIDNET_FBE_KERNELS_HPP_
+#define RAPIDNET_FBE_KERNELS_HPP_
+
+#include "kernels.hpp"
+
+namespace rn {
+
+constexpr int DOT_MAX = 6;
+constexpr int FBE_SCALARS = 64;   // device scalar slots: [0, DOT_MAX) latest k_dots result, [16, 16 + m] L-BFGS alpha
+
+template <typename T>
+struct DotArgs {
+    const T *a[DOT_MAX];
+    const T *b[DOT_MAX];
+    int cnt;
+    long long n;
+    double *partials;   // [blocks][DOT_MAX]
+};
+// up to DOT_MAX dot products <a_j, b_j> over the same index range in ONE pass; fp64 accumulation, fixed reduction
+// order (thread-strided partial sums -> wave shuffle -> LDS -> one partial per block), so a repeat is bitwise equal
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
+    __shared__ double sh[ELT_THREADS / 64][DOT_MAX];
+    double acc[DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
+    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < g.n; i += (long long)gridDim.x * ELT_THREADS) {
+#pragma unroll
+        for (int j = 0; j < DOT_MAX; j++)
+            if (j < g.cnt) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
+    }
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) {
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < DOT_MAX) {
+        double s = 0;
+        for (int k = 0; k < ELT_THREADS / 64; k++) s += sh[k][threadIdx.x];
+        g.partials[(size_t)blockIdx.x * DOT_MAX + threadIdx.x] = s;
+    }
+}
+// second stage: out[j] = sum over blocks of partials[b][j], fixed order
+__global__ void __launch_bounds__(ELT_THREADS) k_dots_finish(const double *partials, int nblocks, int cnt, double *out) {
+    __shared__ double sh[ELT_THREADS];
+    for (int j = 0; j < cnt; j++) {
+        double s = 0;
+        for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) s += partials[(size_t)b * DOT_MAX + j];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = ELT_THREADS / 2; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[j] = sh[0];
+        __syncthreads();
+    }
+}
+
+// L-BFGS two-loop updates (SmpcController::twoLoopRecursionLbfgs, SmpcController.cu:1175-1229); scal[0] holds the
+// dot product just reduced by k_dots_finish, alphaArr the first loop's coefficients.
+//   mode 0: alpha_c = rho_c <S_c, dir> ; dir -= alpha_c Y_c         (vec = Y_c)
+//   mode 1: beta   = rho_c <Y_c, dir> ; dir += (alpha_c - beta) S_c (vec = S_c)
+template <typename T>
+__global__ void k_lbfgs_axpy(T *dir, const T *vec, const double *scal, double rho, double *alphaArr, int c, int mode, long long n) {
+    const T prod = (T)rho * (T)scal[0];
+    const T coef = mode == 0 ? -prod : (T)alphaArr[c] - prod;
+    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) alphaArr[c] = (double)prod;   // nobody reads alphaArr in mode 0
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dir[i] += coef * vec[i];
+}
+// S = y - yPrev ; Y = g - gPrev   (SmpcController::updateLbfgsBuffer, SmpcController.cu:1119-1130)
+template <typename T>
+__global__ void k_lbfgs_diffs(T *S, T *Y, const T *y, const T *yPrev, const T *g, const T *gPrev, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        S[i] = y[i] - yPrev[i];
+        Y[i] = g[i] - gPrev[i];
+    }
+}
+
+// one line-search trial step (SmpcController.cu:1274-1283 / 1383-1392): x += tau xdir, u += tau udir, w += tau dir,
+// Hx += tau HxDir in one launch over the four index ranges
+template <typename T>
+struct TrialArgs {
+    T *x, *u, *w, *hx;
+    const T *xdir, *udir, *dir, *hxdir;
+    long long nX, nU, nY;
+    T tau;
+};
+template <typename T>
+__global__ void k_trial_step(TrialArgs<T> g) {
+    const long long total = g.nX + g.nU + 2 * g.nY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (i < g.nY) g.w[i] += g.tau * g.dir[i];
+        else if (i < 2 * g.nY) { const long long k = i - g.nY; g.hx[k] += g.tau * g.hxdir[k]; }
+        else if (i < 2 * g.nY + g.nX) { const long long k = i - 2 * g.nY; g.x[k] += g.tau * g.xdir[k]; }
+        else { const long long k = i - 2 * g.nY - g.nX; g.u[k] += g.tau * g.udir[k]; }
+    }
+}
+
+// SmpcController::dualUpdate, FBE / NAMA branch (SmpcController.cu:866-880) in one pass:
+//   gPrev = g ; yPrev = y ; y = w + lambda res ; w = y
+template <typename T>
+__global__ void k_fbe_dual_update(T *gPrev, const T *g, T *yPrev, T *y, T *w, const T *res, T lambda, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        gPrev[i] = g[i];
+        yPrev[i] = y[i];
+        const T yn = w[i] + lambda * res[i];
+        y[i] = yn;
+        w[i] = yn;
+    }
+}
+
+// the two primal terms of SmpcController::computeValueFbe (SmpcController.cu:1451-1472):
+//   quad = sum_i p_i du_i' W du_i  with du_i = u_i - u_anc(i) (root: u_0 - prevU)   and   lin = sum_i p_i u_i' alpha_i
+// one workgroup per node (grid-stride), du staged in LDS, one row of W du per thread; partials[block][0..1]
+constexpr int VALUE_THREADS = 128;
+template <typename T>
+__global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const T *prevU, const int *parent, const T *prob, const T *W,
+                                                              const T *alpha, int nu, int nodes, double *partials) {
+    extern __shared__ unsigned char fbe_smem[];
+    T *du = reinterpret_cast<T *>(fbe_smem);
+    __shared__ double sq[VALUE_THREADS / 64], sl[VALUE_THREADS / 64];
+    double quad = 0, lin = 0;
+    for (int node = blockIdx.x; node < nodes; node += gridDim.x) {
+        const int par = parent[node];
+        const T p = prob[node];
+        for (int t = threadIdx.x; t < nu; t += VALUE_THREADS)
+            du[t] = u[(size_t)node * nu + t] - (par < 0 ? prevU[t] : u[(size_t)par * nu + t]);
+        __syncthreads();
+        for (int t = threadIdx.x; t < nu; t += VALUE_THREADS) {
+            T wd = 0;
+            for (int j = 0; j < nu; j++) wd += W[t + (size_t)j * nu] * du[j];
+            quad += (double)(p * du[t]) * (double)wd;
+            lin += (double)(p * u[(size_t)node * nu + t]) * (double)alpha[(size_t)node * nu + t];
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) { quad += __shfl_down(quad, off); lin += __shfl_down(lin, off); }
+    if ((threadIdx.x & 63) == 0) { sq[threadIdx.x >> 6] = quad; sl[threadIdx.x >> 6] = lin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int k = 0; k < VALUE_THREADS / 64; k++) { a += sq[k]; b += sl[k]; }
+        partials[(size_t)blockIdx.x * DOT_MAX + 0] = a;
+        partials[(size_t)blockIdx.x * DOT_MAX + 1] = b;
+    }
+}
+
+}  // namespace rn
+#endif

@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "../../include/rapidnet.h"
-#include "kernels.hpp"
+#include "fbe_kernels.hpp"
 
 #ifndef RN_GEMM_KS
 #define RN_GEMM_KS 3   // k-steps whose operands a wave requests at once in k_gemm_shared (tuning knob)
@@ -102,6 +102,19 @@ struct CtxBase {
     virtual int set_exchange_mode(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
+    // global FBE / NAMA
+    virtual int set_algorithm(int, int) = 0;
+    virtual int fbe_reset() = 0;
+    virtual int hessian_oracle() = 0;
+    virtual int gradient_fbe() = 0;
+    virtual int nama_residual() = 0;
+    virtual int lbfgs_direction() = 0;
+    virtual int value_fbe(double *) = 0;
+    virtual int line_search_fbe(double, double *) = 0;
+    virtual int line_search_ame(double, double *) = 0;
+    virtual int algorithm_fbe_nama(int, double *, double *, double *) = 0;
+    virtual int lbfgs_state(int, int *, int *, double *, double *) = 0;
+    virtual int lbfgs_column(int, int, int, double *, size_t) = 0;
 };
 
 // dense host helpers (fp64, column-major) ---------------------------------------------------------------
@@ -322,7 +335,7 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd;
 #define DA(ptr, cnt) if (int rc = dalloc(&ptr, (size_t)(cnt))) return rc;
         DA(d_sqrtp, n) DA(d_prob, n) DA(d_dy, (size_t)N * ny)
-        DA(d_Rinv, nv * nv) DA(d_Bbt, nv * nx) DA(d_L, nu * nv) DA(d_B, nx * nu) DA(d_Lt, nv * nu) DA(d_WLt, nv * nu)
+        DA(d_Rinv, nv * nv) DA(d_Bbt, nv * nx) DA(d_L, nu * nv) DA(d_B, nx * nu) DA(d_Lt, nv * nu) DA(d_WLt, nv * nu) DA(d_W, nu * nu)
         DA(d_T1, nv * nx) DA(d_T2, nv * nu) DA(d_Gd, nx * nd) DA(d_Lhat, nu * nd) DA(d_alpha1, nu) DA(d_blo, ny) DA(d_bhi, ny)
         DA(d_errD, n * nd) DA(d_errP, n * nu) DA(d_dhat, (size_t)N * nd) DA(d_ahat, (size_t)N * nu)
         DA(d_curX, nx) DA(d_prevU, nu) DA(d_prevUhat, nu) DA(d_prevD, nd)
@@ -411,7 +424,7 @@ struct Ctx : CtxBase {
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
         UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
         UP(d_Lt, Lt.data(), nv * nu) UP(d_WLt, WLt.data(), nv * nu) UP(d_T1, T1.data(), nv * nx) UP(d_T2, T2.data(), nv * nu)
-        UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu)
+        UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu) UP(d_W, s->costW, nu * nu)
         UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
 #undef UP
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
@@ -532,8 +545,16 @@ struct Ctx : CtxBase {
     }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
     // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
-    int launch_sweep(int phase = 0) {
+    // hessianInput != nullptr: SmpcController::computeHessianOracalGlobalFbe (SmpcController.cu:884-1055) -- the same
+    // sweep evaluated at `hessianInput` with sigma = 0 and every affine term zero, writing xdir / udir / H * dir
+    int launch_sweep(int phase = 0, const T *hessianInput = nullptr) {
         SweepArgs<T> a = sweep_args();
+        if (hessianInput) {
+            a.w = hessianInput;
+            a.beta = d_zero; a.uhat = d_zero; a.e = d_zero; a.eb = d_zero; a.bw0 = d_zero;
+            a.curX = d_zero; a.prevU = d_zero; a.prevUhat = d_zero;
+            a.x = d_xdir; a.u = d_udir; a.hx = d_hxDir;
+        }
         RN_CHECK(phase == 0 || a.cutSums, RN_E_STATE, "rn_debug_sweep_phase needs rn_set_cut_stage and nranks > 1");
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
         auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
@@ -825,6 +846,7 @@ struct Ctx : CtxBase {
     }
     int dual_update() override {
         RN_HIP(hipSetDevice(device));
+        if (algorithm != RN_ALG_APG) return fbe_dual_update();   // SmpcController.cu:866-880
         hipLaunchKernelGGL(k_axpby<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_upd, p_acc_view, d_res, (T)1, (T)stepSize, ntot());
         RN_HIP(hipGetLastError());
         acc_ready = false;
@@ -878,6 +900,20 @@ struct Ctx : CtxBase {
             case RN_BUF_XS: *base = d_lo; *off = nx; *dim = nx; return true;
             case RN_BUF_UMIN: *base = d_lo; *off = 2 * nx; *dim = nu; return true;
             case RN_BUF_UMAX: *base = d_hi; *off = 2 * nx; *dim = nu; return true;
+            default: break;
+        }
+        if (!d_matS) return false;   // the FBE / NAMA vectors exist once rn_set_algorithm selected one of them
+        switch (id) {
+            case RN_BUF_PREV_XI: *base = d_prevY; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_PREV_PSI: *base = d_prevY; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_LBFGS_CUR_YVEC_XI: *base = d_g; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_LBFGS_CUR_YVEC_PSI: *base = d_g; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_LBFGS_PREV_YVEC_XI: *base = d_gPrev; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_LBFGS_PREV_YVEC_PSI: *base = d_gPrev; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_LBFGS_DIR_XI: *base = d_dir; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_LBFGS_DIR_PSI: *base = d_dir; *off = 2 * nx; *dim = nu; return true;
+            case RN_BUF_PRIMAL_XI_DIR: *base = d_hxDir; *off = 0; *dim = 2 * nx; return true;
+            case RN_BUF_PRIMAL_PSI_DIR: *base = d_hxDir; *off = 2 * nx; *dim = nu; return true;
             default: return false;
         }
     }
@@ -891,6 +927,8 @@ struct Ctx : CtxBase {
             case RN_BUF_E: *n = N_ * d.nx; return d_e;
             case RN_BUF_BETA: *n = N_ * d.nv; return d_beta;
             case RN_BUF_ALPHA: *n = N_ * d.nu; return d_alpha;
+            case RN_BUF_XDIR: *n = d_xdir ? N_ * d.nx : 0; return d_xdir;
+            case RN_BUF_UDIR: *n = d_udir ? N_ * d.nu : 0; return d_udir;
             default: *n = 0; return nullptr;
         }
     }
@@ -921,7 +959,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         T *b; int off, dim; size_t cnt;
         if (ymap(id, &b, &off, &dim)) {
-            RN_CHECK(id < RN_BUF_XMIN, RN_E_ARG, "rn_set: the scaled bounds are read-only");
+            RN_CHECK(id < RN_BUF_XMIN || id > RN_BUF_UMAX, RN_E_ARG, "rn_set: the scaled bounds are read-only");
             RN_CHECK(n == (size_t)d.nodes * dim, RN_E_ARG, "rn_set: size mismatch");
             if (int rc = upload(d_tmp, host, n)) return rc;
             hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b, d_tmp, ny, off, dim, (long long)d.nodes, 1);
@@ -1025,9 +1063,12 @@ struct Ctx : CtxBase {
     }
     int set_cut_stage(int c) override {
         RN_CHECK(c == -1 || (c >= 1 && c < d.N), RN_E_ARG, "rn_set_cut_stage: stage out of range");
+        RN_CHECK(c == -1 || algorithm == RN_ALG_APG, RN_E_STATE, "rn_set_cut_stage: the FBE / NAMA loops are single-GPU");
         cutStage = c; moments_set = false;
         return RN_OK;
     }
+
+#include "fbe_methods.inc"
 };
 
 }  // namespace rn
@@ -1094,6 +1135,18 @@ int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, s
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
 int rn_set_exchange_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_exchange_mode(mode); }
+int rn_set_algorithm(rn_ctx *ctx, int alg, int m) { RN_GUARD(ctx); return ctx->impl->set_algorithm(alg, m); }
+int rn_fbe_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->fbe_reset(); }
+int rn_compute_hessian_oracle(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->hessian_oracle(); }
+int rn_compute_gradient_fbe(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->gradient_fbe(); }
+int rn_update_fixed_point_residual_nama(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->nama_residual(); }
+int rn_compute_lbfgs_direction(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->lbfgs_direction(); }
+int rn_compute_value_fbe(rn_ctx *ctx, double *v) { RN_GUARD(ctx); return ctx->impl->value_fbe(v); }
+int rn_line_search_lbfgs_update(rn_ctx *ctx, double vy, double *tau) { RN_GUARD(ctx); return ctx->impl->line_search_fbe(vy, tau); }
+int rn_line_search_ame_lbfgs_update(rn_ctx *ctx, double vy, double *tau) { RN_GUARD(ctx); return ctx->impl->line_search_ame(vy, tau); }
+int rn_algorithm_fbe_nama(rn_ctx *ctx, int n, double *h, double *v, double *t) { RN_GUARD(ctx); return ctx->impl->algorithm_fbe_nama(n, h, v, t); }
+int rn_lbfgs_state(rn_ctx *ctx, int set, int *col, int *mem, double *H, double *rho) { RN_GUARD(ctx); return ctx->impl->lbfgs_state(set, col, mem, H, rho); }
+int rn_lbfgs_column(rn_ctx *ctx, int set, int which, int col, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->lbfgs_column(set, which, col, h, n); }
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 

@@ -1,0 +1,267 @@
+"""GPU parity of the global-FBE and NAMA outer loops through the C-ABI.
+
+Two anchors, as for the APG path:
+  * the reference's own known-answer vectors (smpcFbeTest.json / smpcNamaTest.json), fed through the HIP path exactly
+    as Testing::testSmpcFbeController / testSmpcNamaController feed the reference (src/test/Testing.cu:536-590,
+    TestSmpcController.cu:403-1040) -- tolerances are those of the 7-digit prints (see tests/test_oracle_fbe_nama.py);
+  * the CPU oracle on seeded synthetic problems, step by step and over whole loops, at 1e-9 of each vector's scale.
+The line searches branch on computed values (value <= previous value, skip rule of the L-BFGS update): the loops are
+compared through the accepted step lengths tau (must be identical) as well as through the iterates.
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, forecast_at
+from rapidnet_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9
+
+
+def relmax(a, b):
+    a = np.asarray(a, float).ravel()
+    b = np.asarray(b, float).ravel()
+    assert a.shape == b.shape
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def rel_err(a, b, floor=1.0):
+    a = np.asarray(a, float).ravel()
+    b = np.asarray(b, float).ravel()
+    assert a.size == b.size
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+ALGS = ["globalFbeAlgorithm", "namaAlgorithm"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's known-answer vectors through the HIP path
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=ALGS)
+def case(request, ref_fixture):
+    s = capi.Solver(ref_fixture["network"], ref_fixture["tree"], ref_fixture["config"])
+    dh, ah = forecast_at(ref_fixture["forecast"], 1)  # timeInst = 1, Testing.cu:540-542
+    s.initialiseSmpcController(dh, ah)
+    s.setAlgorithm(request.param, 5)
+    key = "smpc_fbe" if request.param == "globalFbeAlgorithm" else "smpc_nama"
+    return request.param, s, ref_fixture[key]
+
+
+def test_fixture_hessian_oracle(case):
+    name, s, f = case
+    fbe = name == "globalFbeAlgorithm"
+    s.set(capi.BUF_LBFGS_CUR_YVEC_XI if fbe else capi.BUF_RES_XI, f["fixedPointResidualXi"])
+    s.set(capi.BUF_LBFGS_CUR_YVEC_PSI if fbe else capi.BUF_RES_PSI, f["fixedPointResidualPsi"])
+    s.computeHessianOracalGlobalFbe()
+    kx, ku = ("fbeHessianDirXdir", "fbeHessianDirUdir") if fbe else ("ameFixedPointDirXdir", "ameFixedPointDirUdir")
+    assert relmax(s.get(capi.BUF_UDIR), f[ku]) < 1e-6
+    assert relmax(s.get(capi.BUF_XDIR), f[kx]) < 1e-6
+
+
+def test_fixture_gradient_and_nama_residual(case):
+    name, s, f = case
+    s.set(capi.BUF_RES_XI, f["fixedPointResidualXi"]); s.set(capi.BUF_RES_PSI, f["fixedPointResidualPsi"])
+    if name == "globalFbeAlgorithm":
+        s.computeGradientFbe()
+        assert rel_err(s.get(capi.BUF_LBFGS_CUR_YVEC_XI), f["fbeGradXi"]) < 2e-6
+        assert rel_err(s.get(capi.BUF_LBFGS_CUR_YVEC_PSI), f["fbeGradPsi"]) < 2e-6
+    else:
+        s.updateFixedPointResidualNamaAlgorithm()
+        assert rel_err(s.get(capi.BUF_LBFGS_CUR_YVEC_XI), f["lbfgsCurrentYvecXi"]) < 1e-6
+        assert rel_err(s.get(capi.BUF_LBFGS_CUR_YVEC_PSI), f["lbfgsCurrentYvecPsi"]) < 1e-6
+
+
+def test_fixture_value_fbe(case):
+    name, s, f = case
+    s.set(capi.BUF_RES_XI, f["fixedPointResidualXi"]); s.set(capi.BUF_RES_PSI, f["fixedPointResidualPsi"])
+    s.set(capi.BUF_ACC_XI, f["acceleXi"]); s.set(capi.BUF_ACC_PSI, f["accelePsi"])
+    s.set(capi.BUF_U, f["U"])
+    assert abs(s.computeValueFbe() / f["fbeObjDual"][0] - 1) < 2e-6
+
+
+def test_fixture_lbfgs_direction(case):
+    name, s, f = case
+    n = s.nodes * (2 * s.nx + s.nu)
+    s.set(capi.BUF_PREV_XI, f["xi"]); s.set(capi.BUF_PREV_PSI, f["psi"])
+    s.set(capi.BUF_XI, f["acceleXi"]); s.set(capi.BUF_PSI, f["accelePsi"])
+    s.set(capi.BUF_LBFGS_CUR_YVEC_XI, f["lbfgsCurrentYvecXi"]); s.set(capi.BUF_LBFGS_CUR_YVEC_PSI, f["lbfgsCurrentYvecPsi"])
+    s.set(capi.BUF_LBFGS_PREV_YVEC_XI, f["lbfgsPreviousYvecXi"]); s.set(capi.BUF_LBFGS_PREV_YVEC_PSI, f["lbfgsPreviousYvecPsi"])
+    S, Y = np.array(f["matS"]).reshape(5, n), np.array(f["matY"]).reshape(5, n)
+    for c in range(5):
+        s.lbfgsColumn(0, c, S[c]); s.lbfgsColumn(1, c, Y[c])
+    inv = np.array(f["vecInvRho"], float)
+    rho = np.zeros(6); rho[:5] = np.where(inv != 0, 1 / np.where(inv != 0, inv, 1), 0)
+    s.lbfgsState(int(f["colLbfgs"][0]), int(f["memLbfgs"][0]), float(f["H"][0]), rho)
+    s.computeLbfgsDirection()
+    col, mem, H, rho2 = s.lbfgsState()
+    assert col == int(f["updateColLbfgs"][0]) and mem == int(f["updateMemLbfgs"][0])
+    assert abs(H / f["updateH"][0] - 1) < 2e-6
+    assert rel_err(1 / rho2[:5], f["updateVecInvRho"], floor=1e-300) < 2e-6
+    S2 = np.concatenate([s.lbfgsColumn(0, c) for c in range(5)])
+    Y2 = np.concatenate([s.lbfgsColumn(1, c) for c in range(5)])
+    assert rel_err(S2, f["updateMatS"]) < 1e-4 and rel_err(Y2, f["updateMatY"]) < 1e-4
+    scale = np.abs(np.array(f["lbfgsDirXi"])).max()
+    assert np.abs(s.get(capi.BUF_LBFGS_DIR_XI) - f["lbfgsDirXi"]).max() < 1e-4 * scale
+    assert np.abs(s.get(capi.BUF_LBFGS_DIR_PSI) - f["lbfgsDirPsi"]).max() < 1e-4 * scale
+
+
+def test_fixture_line_search(case):
+    name, s, f = case
+    fbe = name == "globalFbeAlgorithm"
+    s.set(capi.BUF_RES_XI, f["fixedPointResidualXi"]); s.set(capi.BUF_RES_PSI, f["fixedPointResidualPsi"])
+    s.set(capi.BUF_ACC_XI, f["acceleXi"]); s.set(capi.BUF_ACC_PSI, f["accelePsi"])
+    s.set(capi.BUF_X, f["X"]); s.set(capi.BUF_U, f["U"])
+    s.set(capi.BUF_LBFGS_DIR_XI, f["lbfgsDirXi"]); s.set(capi.BUF_LBFGS_DIR_PSI, f["lbfgsDirPsi"])
+    if fbe:
+        s.set(capi.BUF_LBFGS_CUR_YVEC_XI, f["fbeGradXi"]); s.set(capi.BUF_LBFGS_CUR_YVEC_PSI, f["fbeGradPsi"])
+    s.set(capi.BUF_PRIMAL_XI, f["primalX"]); s.set(capi.BUF_PRIMAL_PSI, f["primalU"])
+    val = s.computeValueFbe()
+    tau = s.computeLineSearchLbfgsUpdate(val) if fbe else s.computeLineSearchAmeLbfgsUpdate(val)
+    assert abs(val / f["fbeObjDual"][0] - 1) < 2e-6
+    assert abs(tau - f["tau"][0]) < 1e-12
+    assert rel_err(s.get(capi.BUF_ACC_XI), f["updateXi"]) < 1e-5
+    assert rel_err(s.get(capi.BUF_ACC_PSI), f["updatePsi"]) < 1e-5
+    assert rel_err(s.get(capi.BUF_RES_XI), f["updateResidualXi"]) < 2e-4
+    assert rel_err(s.get(capi.BUF_RES_PSI), f["updateResidualPsi"]) < 2e-4
+
+
+def test_fixture_dual_update(case):
+    name, s, f = case
+    s.set(capi.BUF_XI, f["acceleXi"]); s.set(capi.BUF_PSI, f["accelePsi"])
+    s.set(capi.BUF_ACC_XI, f["updateXi"]); s.set(capi.BUF_ACC_PSI, f["updatePsi"])
+    s.set(capi.BUF_RES_XI, f["updateResidualXi"]); s.set(capi.BUF_RES_PSI, f["updateResidualPsi"])
+    s.set(capi.BUF_LBFGS_CUR_YVEC_XI, f["lbfgsCurrentYvecXi"]); s.set(capi.BUF_LBFGS_CUR_YVEC_PSI, f["lbfgsCurrentYvecPsi"])
+    s.dualUpdate()
+    assert rel_err(s.get(capi.BUF_XI), f["finalUpdateXi"]) < 2e-6
+    assert rel_err(s.get(capi.BUF_PSI), f["finalUpdatePsi"]) < 2e-6
+    assert np.array_equal(s.get(capi.BUF_LBFGS_PREV_YVEC_XI), np.array(f["lbfgsCurrentYvecXi"], float))
+    assert np.array_equal(s.get(capi.BUF_PREV_XI), np.array(f["acceleXi"], float))
+    assert np.array_equal(s.get(capi.BUF_PREV_PSI), np.array(f["accelePsi"], float))
+    assert np.array_equal(s.get(capi.BUF_ACC_XI), s.get(capi.BUF_XI))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HIP path vs oracle on seeded problems
+# ---------------------------------------------------------------------------------------------------------------
+FBE_PAIRS = [(capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_XI, "xi"), (capi.BUF_PSI, "psi"), (capi.BUF_ACC_XI, "accXi"),
+             (capi.BUF_ACC_PSI, "accPsi"), (capi.BUF_PRIMAL_XI, "primalXi"), (capi.BUF_PRIMAL_PSI, "primalPsi"),
+             (capi.BUF_DUAL_XI, "dualXi"), (capi.BUF_DUAL_PSI, "dualPsi"), (capi.BUF_RES_XI, "resXi"), (capi.BUF_RES_PSI, "resPsi"),
+             (capi.BUF_PREV_XI, "prevXi"), (capi.BUF_PREV_PSI, "prevPsi"), (capi.BUF_LBFGS_DIR_XI, "dirXi"),
+             (capi.BUF_LBFGS_DIR_PSI, "dirPsi"), (capi.BUF_XDIR, "xdir"), (capi.BUF_UDIR, "udir"),
+             (capi.BUF_PRIMAL_XI_DIR, "primalXiDir"), (capi.BUF_PRIMAL_PSI_DIR, "primalPsiDir")]
+
+
+def cur_names(alg):
+    return ("gradXi", "gradPsi", "prevGradXi", "prevGradPsi") if alg == "globalFbeAlgorithm" else ("curResXi", "curResPsi", "prevResXi", "prevResPsi")
+
+
+def compare_fbe(s, o, alg, tol, what):
+    worst = {}
+    for bid, name in FBE_PAIRS:
+        worst[name] = relmax(s.get(bid), o.get(name))
+    cx, cp, px, pp = cur_names(alg)
+    for bid, name in ((capi.BUF_LBFGS_CUR_YVEC_XI, cx), (capi.BUF_LBFGS_CUR_YVEC_PSI, cp), (capi.BUF_LBFGS_PREV_YVEC_XI, px),
+                      (capi.BUF_LBFGS_PREV_YVEC_PSI, pp)):
+        worst[name] = relmax(s.get(bid), o.get(name))
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, "%s mismatch vs oracle: %s" % (what, bad)
+
+
+def make_pair(name, alg, structured=False, m=5, **kw):
+    p = synth.make_problem(name, **kw)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.set_algorithm(alg, m)
+    o.initialise(dh, ah)
+    o.fbe_reset()
+    s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured)
+    s.initialiseSmpcController(dh, ah)
+    s.setAlgorithm(alg, m)
+    return p, o, s
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("name,structured", [("tiny", False), ("small", False), ("small", True), ("odd", False), ("medium", True)])
+def test_loop_matches_oracle(name, structured, alg):
+    """algorithmGlobalFbe / algorithmNama: same step lengths, same primal infeasibilities, same iterates."""
+    p, o, s = make_pair(name, alg, structured)
+    iters = 12
+    ho, vo, to = o.fbe_nama(iters)
+    hs, vs, ts = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(iters)
+    assert np.array_equal(ts, to), (ts, to)
+    assert relmax(vs, vo) < REL_TOL
+    assert relmax(hs, ho) < 1e-7   # a signed arg-max entry: ties between equal |entries| may resolve to either sign
+    compare_fbe(s, o, alg, 1e-8, "%s %s after %d iterations" % (alg, name, iters))
+    assert s.lbfgsState()[:2] == o.lbfgs_state()[:2]
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_steps_match_oracle(alg):
+    """every step of one iteration, each fed by the previous one, compared after each call"""
+    p, o, s = make_pair("small", alg)
+    fbe = alg == "globalFbeAlgorithm"
+    for it in range(4):
+        o.solve_step(); s.solveStep()
+        o.prox(); s.proximalFunG()
+        o.residual(); s.computeFixedPointResidual()
+        if fbe:
+            o.gradient_fbe(); s.computeGradientFbe()
+        else:
+            o.nama_residual(); s.updateFixedPointResidualNamaAlgorithm()
+        compare_fbe(s, o, alg, REL_TOL, "it %d gradient" % it)
+        if it > 0:
+            vo, vs = o.value_fbe(), s.computeValueFbe()
+            assert abs(vs - vo) <= REL_TOL * abs(vo)
+            o.lbfgs_direction(); s.computeLbfgsDirection()
+            compare_fbe(s, o, alg, REL_TOL, "it %d lbfgs direction" % it)
+            co, mo, Ho = o.lbfgs_state()
+            cs, ms, Hs, rho = s.lbfgsState()
+            assert (cs, ms) == (co, mo) and abs(Hs - Ho) <= REL_TOL * abs(Ho)
+            assert relmax(rho, o.get("rho")) < REL_TOL
+            n = s.nodes * (2 * s.nx + s.nu)
+            nxi = s.nodes * 2 * s.nx
+            for which, nm in ((0, "matS"), (1, "matY")):
+                got = s.lbfgsColumn(which, cs)
+                ref = o.get(nm)[cs * n:(cs + 1) * n]
+                assert relmax(got[:nxi], ref[:nxi]) < REL_TOL and relmax(got[nxi:], ref[nxi:]) < REL_TOL
+            to = o.line_search_fbe(vo) if fbe else o.line_search_ame(vo)
+            ts = s.computeLineSearchLbfgsUpdate(vs) if fbe else s.computeLineSearchAmeLbfgsUpdate(vs)
+            assert ts == to
+            compare_fbe(s, o, alg, REL_TOL, "it %d line search" % it)
+        o.dual_update(); s.dualUpdate()
+        compare_fbe(s, o, alg, REL_TOL, "it %d dual update" % it)
+        assert abs(s.updatePrimalInfeasibity() - o.primal_infeasibility()) <= 1e-9 * max(1.0, abs(o.primal_infeasibility()))
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_soft_constraint_branch_value(alg):
+    """penalties small enough that the soft branch trips: the g terms of the FBE value are exercised"""
+    p, o, s = make_pair("small", alg, penalty_x=2.0, penalty_xs=1.0)
+    iters = 12
+    ho, vo, to = o.fbe_nama(iters)
+    hs, vs, ts = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(iters)
+    dx, ds = o.dist()
+    assert dx > 2.0 / float(p["config"]["stepSize"][0]) or ds > 1.0 / float(p["config"]["stepSize"][0]), "branch not exercised"
+    assert np.array_equal(ts, to)
+    assert relmax(vs, vo) < REL_TOL
+    compare_fbe(s, o, alg, 1e-8, "soft branch")
+
+
+def test_fbe_api_errors():
+    p = synth.make_problem("tiny")
+    s = capi.Solver(p["network"], p["tree"], p["config"])
+    with pytest.raises(capi.RapidNetError):
+        s.computeHessianOracalGlobalFbe()          # no algorithm selected
+    with pytest.raises(capi.RapidNetError):
+        s.setAlgorithm("namaAlgorithm", 0)         # bad buffer size
+    s.setAlgorithm("namaAlgorithm", 3)
+    with pytest.raises(capi.RapidNetError):
+        s.computeValueFbe()                        # before the factor step / affine terms
+    with pytest.raises(capi.RapidNetError):
+        s.setAlgorithm("globalFbeAlgorithm", 4)    # buffer size cannot change
+    with pytest.raises(capi.RapidNetError):
+        s.setCutStage(1)                           # FBE / NAMA are single-GPU
+    s.setAlgorithm("proximalAlgorithm")
