@@ -23,6 +23,16 @@
  *   SmpcController::dualUpdate          SmpcController.cu:854-864
  *   SmpcController::updatePrimalInfeasibity    SmpcController.cu:1480-1496
  *   SmpcController::algorithmApg        SmpcController.cu:1500-1525
+ * and, for the global-FBE / NAMA outer loops (second half of this file):
+ *   SmpcController::dualUpdate (FBE / NAMA branch)          SmpcController.cu:866-880
+ *   SmpcController::computeHessianOracalGlobalFbe           SmpcController.cu:884-1055
+ *   SmpcController::updateFixedPointResidualNamaAlgorithm   SmpcController.cu:1060-1072
+ *   SmpcController::computeGradientFbe                      SmpcController.cu:1077-1097
+ *   SmpcController::updateLbfgsBuffer / twoLoopRecursionLbfgs / computeLbfgsDirection  SmpcController.cu:1103-1237
+ *   SmpcController::computeLineSearchLbfgsUpdate / computeLineSearchAmeLbfgsUpdate     SmpcController.cu:1242-1414
+ *   SmpcController::computeValueFbe                         SmpcController.cu:1416-1476
+ *   SmpcController::algorithmGlobalFbe / algorithmNama      SmpcController.cu:1529-1586
+ *   pinned by src/test/testDataFiles/{smpcFbeTest,smpcNamaTest}.json, see tests/test_oracle_fbe_nama.py
  *
  * Third-party arithmetic the reference calls and that is absent from /root/reference: cuBLAS
  * (gemm/gemv/axpy/scal/nrm2/isamax, getrfBatched/getriBatched) from the CUDA toolkit 7.0/8.0.  These
@@ -36,6 +46,10 @@
  *   - SmpcController.cu:800/818 clobber devVecDiffXi on the soft-constraint branch; here the
  *     mathematically correct prox of gamma*dist(.,C) is computed for both halves.
  *   - XsUpper is "no upper bound" (the reference memsets bytes 0x7F, Engine.cu:454-455).
+ *   - FBE / NAMA: the L-BFGS buffers get one spare column (the reference indexes columns 1..m of m-column buffers,
+ *     SmpcController.cu:1146) and matY is zeroed completely at reset (the reference zeroes nu*nodes entries, :466);
+ *     the value of g at the prox point when the soft branch trips is gamma*dist(prox point, C) (the reference's
+ *     :798-808 reads a partially filled scratch vector).
  *
  * Build: gcc -O3 -march=native -fPIC -shared [-DORACLE_REAL=float] -o liboracle_f64.so apg_oracle.c -lm
  */
@@ -705,6 +719,7 @@ void oracle_fbe_reset(oracle_t *o) {
     else { memset(o->resXi, 0, nxi * sizeof(real)); memset(o->resPsi, 0, nps * sizeof(real)); }
     o->lbfgsCol = 0; o->lbfgsMem = 0; o->lbfgsSkip = 0; o->lbfgsH = 1;
     memset(o->matS, 0, (size_t)(o->lbfgsSize + 1) * n * sizeof(real));
+    memset(o->matY, 0, (size_t)(o->lbfgsSize + 1) * n * sizeof(real));
     memset(o->rho, 0, ((size_t)o->lbfgsSize + 1) * sizeof(real));
 }
 

@@ -41,6 +41,8 @@ void Engine::create(int precision, int device) {
     check(rn_set_parameters(ctx, ptrMySmpcConfig->getStepSize(), ptrMySmpcConfig->getPenaltyState(), ptrMySmpcConfig->getPenaltySafety()),
           "rn_set_parameters");
     check(rn_set_tree_errors(ctx, ptrMyScenarioTree->getErrorDemandArray(), ptrMyScenarioTree->getErrorPriceArray()), "rn_set_tree_errors");
+    if (!apgFlag)   // SmpcController::allocateGlobalFbeAlgorithm / allocateNamaAlgorithm / allocateLbfgsBuffer (SmpcController.cu:234-330)
+        check(rn_set_algorithm(ctx, globalFbeFlag ? RN_ALG_GLOBAL_FBE : RN_ALG_NAMA, (int)ptrMySmpcConfig->getLbfgsBufferSize()), "rn_set_algorithm");
 }
 
 Engine::~Engine() { if (ctx) rn_destroy(ctx); }

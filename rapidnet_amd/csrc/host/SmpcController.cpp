@@ -11,6 +11,7 @@ SmpcController::SmpcController(Forecaster *f, Engine *e, SmpcConfiguration *c)
     : ptrMyEngine(e), ptrMyForecaster(f), ptrMySmpcConfig(c), factorStepFlag(false), simulatorFlag(true), ownsObjects(false) {
     stepSize = c->getStepSize();
     vecPrimalInfs.assign(c->getMaxIterations() + 1, 0.0);
+    vecValueFbe.assign(c->getMaxIterations() + 1, 0.0); vecTau.assign(c->getMaxIterations() + 1, 0.0);
     lastControl.assign(c->getNU(), 0.0);
     economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
@@ -21,6 +22,7 @@ SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false),
     ptrMyEngine = new Engine(ptrMySmpcConfig);
     stepSize = ptrMySmpcConfig->getStepSize();
     vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
+    vecValueFbe.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0); vecTau.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
     lastControl.assign(ptrMySmpcConfig->getNU(), 0.0);
     economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
@@ -142,6 +144,43 @@ void SmpcController::dualUpdate() { check(rn_dual_update(ptrMyEngine->getContext
 real_t SmpcController::updatePrimalInfeasibity() {
     double v = 0;
     check(rn_update_primal_infeasibility(ptrMyEngine->getContext(), &v), "rn_update_primal_infeasibility");
+    return v;
+}
+uint_t SmpcController::algorithmGlobalFbe() {
+    if (!ptrMyEngine->getGlobalFbeFlag()) throw std::logic_error("algorithmGlobalFbe: the configuration selects another algorithm");
+    if (!factorStepFlag) initialiseSmpcController();
+    check(rn_algorithm_fbe_nama(ptrMyEngine->getContext(), ptrMySmpcConfig->getMaxIterations(), vecPrimalInfs.data(), vecValueFbe.data(), vecTau.data()),
+          "rn_algorithm_fbe_nama");
+    return 1;
+}
+uint_t SmpcController::algorithmNama() {
+    if (!ptrMyEngine->getNamaFlag()) throw std::logic_error("algorithmNama: the configuration selects another algorithm");
+    if (!factorStepFlag) initialiseSmpcController();
+    check(rn_algorithm_fbe_nama(ptrMyEngine->getContext(), ptrMySmpcConfig->getMaxIterations(), vecPrimalInfs.data(), vecValueFbe.data(), vecTau.data()),
+          "rn_algorithm_fbe_nama");
+    return 1;
+}
+void SmpcController::computeHessianOracalGlobalFbe() {
+    if (!factorStepFlag) initialiseSmpcController();          // SmpcController.cu:899-902
+    check(rn_compute_hessian_oracle(ptrMyEngine->getContext()), "rn_compute_hessian_oracle");
+}
+void SmpcController::updateFixedPointResidualNamaAlgorithm() { check(rn_update_fixed_point_residual_nama(ptrMyEngine->getContext()), "rn_update_fixed_point_residual_nama"); }
+void SmpcController::computeGradientFbe() { check(rn_compute_gradient_fbe(ptrMyEngine->getContext()), "rn_compute_gradient_fbe"); }
+void SmpcController::computeLbfgsDirection() { check(rn_compute_lbfgs_direction(ptrMyEngine->getContext()), "rn_compute_lbfgs_direction"); }
+real_t SmpcController::computeLineSearchLbfgsUpdate(real_t valueFbeY) {
+    double tau = 0;
+    check(rn_line_search_lbfgs_update(ptrMyEngine->getContext(), valueFbeY, &tau), "rn_line_search_lbfgs_update");
+    return tau;
+}
+real_t SmpcController::computeLineSearchAmeLbfgsUpdate(real_t valueFbeYvar) {
+    double tau = 0;
+    check(rn_line_search_ame_lbfgs_update(ptrMyEngine->getContext(), valueFbeYvar, &tau), "rn_line_search_ame_lbfgs_update");
+    return tau;
+}
+real_t SmpcController::computeValueFbe() {
+    if (!factorStepFlag) initialiseSmpcController();
+    double v = 0;
+    check(rn_compute_value_fbe(ptrMyEngine->getContext(), &v), "rn_compute_value_fbe");
     return v;
 }
 uint_t SmpcController::algorithmApg() {

@@ -27,6 +27,8 @@ public:
     real_t getSafetyKpi(uint_t simulationTime);             // :1841-1843
     void updateKpi(real_t *state, real_t *control);         // :1769-1802
     real_t *getPrimalInfeasibility() { return vecPrimalInfs.data(); }
+    real_t *getValueFbe() { return vecValueFbe.data(); }    // :1883
+    real_t *getVecTau() { return vecTau.data(); }
     ~SmpcController();
 
 protected:
@@ -37,6 +39,21 @@ protected:
     uint_t algorithmApg();                                  // :1500
     void computeFixedPointResidual();                       // :839
     real_t updatePrimalInfeasibity();                       // :1480
+    // global FBE / NAMA (selected by "algorithmName" of the controller configuration, Engine.cu:151-163)
+    uint_t algorithmGlobalFbe();                            // :1529
+    uint_t algorithmNama();                                 // :1559
+    void computeHessianOracalGlobalFbe();                   // :884
+    void updateFixedPointResidualNamaAlgorithm();           // :1060
+    void computeGradientFbe();                              // :1077
+    void computeLbfgsDirection();                           // :1234  (updateLbfgsBuffer :1103 + twoLoopRecursionLbfgs :1175)
+    real_t computeLineSearchLbfgsUpdate(real_t valueFbeY);  // :1242
+    real_t computeLineSearchAmeLbfgsUpdate(real_t valueFbeYvar);   // :1311
+    real_t computeValueFbe();                               // :1416
+    // lbfgsBufferCol / lbfgsBufferMemory / lbfgsBufferHessian / lbfgsBufferRho and the columns of devLbfgsBufferMatS / MatY
+    void getLbfgsState(int &col, int &mem, real_t &H, real_t *rho) { check(rn_lbfgs_state(ptrMyEngine->getContext(), 0, &col, &mem, &H, rho), "rn_lbfgs_state"); }
+    void setLbfgsState(int col, int mem, real_t H, real_t *rho) { check(rn_lbfgs_state(ptrMyEngine->getContext(), 1, &col, &mem, &H, rho), "rn_lbfgs_state"); }
+    void getLbfgsColumn(int which, int col, real_t *host, size_t n) { check(rn_lbfgs_column(ptrMyEngine->getContext(), 0, which, col, host, n), "rn_lbfgs_column"); }
+    void setLbfgsColumn(int which, int col, const real_t *host, size_t n) { check(rn_lbfgs_column(ptrMyEngine->getContext(), 1, which, col, const_cast<real_t *>(host), n), "rn_lbfgs_column"); }
     void getVector(int bufferId, real_t *host) { ptrMyEngine->getBuffer(bufferId, host); }
     void setVector(int bufferId, const real_t *host) { ptrMyEngine->setBuffer(bufferId, host); }
     void check(int rc, const char *what);
@@ -46,7 +63,7 @@ protected:
     SmpcConfiguration *ptrMySmpcConfig;
     real_t stepSize;
     bool factorStepFlag, simulatorFlag, ownsObjects;
-    std::vector<real_t> vecPrimalInfs, lastControl;
+    std::vector<real_t> vecPrimalInfs, vecValueFbe, vecTau, lastControl;
     real_t economicKpi, smoothKpi, safeKpi, networkKpi;
 };
 

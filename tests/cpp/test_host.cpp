@@ -3,7 +3,9 @@
 //   engine      : Testing::testEngineTesting (Testing.cu:340-477) against engineTest.json
 //   controller  : TestSmpcController::testExtrapolation / testSoveStep / testProximalStep / testFixedPointResidual /
 //                 testDualUpdate (src/test/TestSmpcController.cu:114-420) against smpcTest.json, same tolerance rule
-// usage: test_host <loaders|engine|controller|closedloop> <directory with the fixture JSON files>
+//   fbe / nama  : Testing::testSmpcFbeController / testSmpcNamaController (Testing.cu:536-590) against smpcFbeTest.json /
+//                 smpcNamaTest.json
+// usage: test_host <loaders|engine|controller|fbe|nama|closedloop|nullspace|warmstart> <directory with the fixture JSON files>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -150,6 +152,105 @@ public:
         CHECK(std::isfinite(h[0]) && std::isfinite(h[getSmpcConfiguration()->getMaxIterations() - 1]));
         CHECK(std::fabs(h[getSmpcConfiguration()->getMaxIterations() - 1]) < std::fabs(h[0]));
         std::cout << "primal infeasibility: first " << h[0] << " last " << h[getSmpcConfiguration()->getMaxIterations() - 1] << "\n";
+    }
+};
+
+// Testing::testSmpcFbeController / testSmpcNamaController (Testing.cu:536-590): the FBE / NAMA known-answer tests of
+// TestSmpcController.cu:403-1040 against smpcFbeTest.json / smpcNamaTest.json, same tolerance rule, same order
+class TestFbeNamaController : public SmpcController {
+public:
+    explicit TestFbeNamaController(const string &cfg) : SmpcController(cfg) {}
+    void run(const string &dir) {
+        const bool fbe = getEngine()->getGlobalFbeFlag();
+        CHECK(fbe != getEngine()->getNamaFlag() && !getEngine()->getApgFlag());
+        jsonlite::Document j(dir + (fbe ? "/smpcFbeTest.json" : "/smpcNamaTest.json"));
+        const uint_t nx = getDwnNetwork()->getNumTanks(), nu = getDwnNetwork()->getNumControls(), nodes = getScenarioTree()->getNumNodes();
+        const size_t nxi = (size_t)2 * nx * nodes, nps = (size_t)nu * nodes, nall = nxi + nps;
+        const int m = (int)getSmpcConfiguration()->getLbfgsBufferSize();
+        std::vector<real_t> a(nxi), b(nps), c(nodes * (size_t)nx), col(nall);
+        auto put = [&](int id, const char *key) { setVector(id, j[key].arr.data()); };
+        // testHessianOracalGlobalFbe (:403)
+        put(fbe ? RN_BUF_LBFGS_CUR_YVEC_XI : RN_BUF_RES_XI, "fixedPointResidualXi");
+        put(fbe ? RN_BUF_LBFGS_CUR_YVEC_PSI : RN_BUF_RES_PSI, "fixedPointResidualPsi");
+        computeHessianOracalGlobalFbe();
+        getVector(RN_BUF_UDIR, b.data()); CHECK(closeRef(b.data(), j[fbe ? "fbeHessianDirUdir" : "ameFixedPointDirUdir"], nps, "Udir"));
+        getVector(RN_BUF_XDIR, c.data()); CHECK(closeRef(c.data(), j[fbe ? "fbeHessianDirXdir" : "ameFixedPointDirXdir"], c.size(), "Xdir"));
+        if (fbe) {   // testFbeGradient (:458)
+            put(RN_BUF_RES_XI, "fixedPointResidualXi"); put(RN_BUF_RES_PSI, "fixedPointResidualPsi");
+            computeGradientFbe();
+            getVector(RN_BUF_LBFGS_CUR_YVEC_XI, a.data()); CHECK(closeRef(a.data(), j["fbeGradXi"], nxi, "fbeGradXi"));
+            getVector(RN_BUF_LBFGS_CUR_YVEC_PSI, b.data()); CHECK(closeRef(b.data(), j["fbeGradPsi"], nps, "fbeGradPsi"));
+        }
+        {   // testValueFbe (:683)
+            put(RN_BUF_RES_XI, "fixedPointResidualXi"); put(RN_BUF_RES_PSI, "fixedPointResidualPsi");
+            put(RN_BUF_ACC_XI, "acceleXi"); put(RN_BUF_ACC_PSI, "accelePsi"); put(RN_BUF_U, "U");
+            const real_t v = computeValueFbe();
+            CHECK(std::fabs((v - j["fbeObjDual"][0]) / j["fbeObjDual"][0] * 100) < 1e-1);
+        }
+        if (!fbe) {  // testUpdateFixedPointResidualNamaAlgorithm (:633)
+            put(RN_BUF_RES_XI, "fixedPointResidualXi"); put(RN_BUF_RES_PSI, "fixedPointResidualPsi");
+            updateFixedPointResidualNamaAlgorithm();
+            getVector(RN_BUF_LBFGS_CUR_YVEC_XI, a.data()); CHECK(closeRef(a.data(), j["lbfgsCurrentYvecXi"], nxi, "lbfgsCurrentYvecXi"));
+            getVector(RN_BUF_LBFGS_CUR_YVEC_PSI, b.data()); CHECK(closeRef(b.data(), j["lbfgsCurrentYvecPsi"], nps, "lbfgsCurrentYvecPsi"));
+        }
+        {   // testLbfgsDirection (:503)
+            put(RN_BUF_PREV_XI, "xi"); put(RN_BUF_PREV_PSI, "psi"); put(RN_BUF_XI, "acceleXi"); put(RN_BUF_PSI, "accelePsi");
+            put(RN_BUF_LBFGS_CUR_YVEC_XI, "lbfgsCurrentYvecXi"); put(RN_BUF_LBFGS_CUR_YVEC_PSI, "lbfgsCurrentYvecPsi");
+            put(RN_BUF_LBFGS_PREV_YVEC_XI, "lbfgsPreviousYvecXi"); put(RN_BUF_LBFGS_PREV_YVEC_PSI, "lbfgsPreviousYvecPsi");
+            CHECK(j["matS"].Size() == nall * m && j["matY"].Size() == nall * m);
+            for (int k = 0; k < m; k++) {
+                setLbfgsColumn(0, k, j["matS"].arr.data() + (size_t)k * nall, nall);
+                setLbfgsColumn(1, k, j["matY"].arr.data() + (size_t)k * nall, nall);
+            }
+            std::vector<real_t> rho(m + 1, 0.0);
+            for (int k = 0; k < m; k++) rho[k] = j["vecInvRho"][k] != 0 ? 1 / j["vecInvRho"][k] : 0;
+            setLbfgsState((int)j["colLbfgs"][0], (int)j["memLbfgs"][0], j["H"][0], rho.data());
+            computeLbfgsDirection();
+            int colNow, memNow; real_t H;
+            getLbfgsState(colNow, memNow, H, rho.data());
+            CHECK(std::fabs(H - j["updateH"][0]) < 1e-1 && colNow == (int)j["updateColLbfgs"][0]);
+            for (int k = 0; k < m; k++) CHECK(std::fabs(rho[k] - (j["updateVecInvRho"][k] != 0 ? 1 / j["updateVecInvRho"][k] : 0)) < 1e-1);
+            std::vector<real_t> S((size_t)m * nall), Y((size_t)m * nall);
+            for (int k = 0; k < m; k++) { getLbfgsColumn(0, k, S.data() + (size_t)k * nall, nall); getLbfgsColumn(1, k, Y.data() + (size_t)k * nall, nall); }
+            CHECK(closeRef(S.data(), j["updateMatS"], S.size(), "updateMatS")); CHECK(closeRef(Y.data(), j["updateMatY"], Y.size(), "updateMatY"));
+            getVector(RN_BUF_LBFGS_DIR_XI, a.data()); CHECK(closeRef(a.data(), j["lbfgsDirXi"], nxi, "lbfgsDirXi"));
+            getVector(RN_BUF_LBFGS_DIR_PSI, b.data()); CHECK(closeRef(b.data(), j["lbfgsDirPsi"], nps, "lbfgsDirPsi"));
+        }
+        {   // testFbeLineSearch (:841) / testAmeLineSearch (:748)
+            put(RN_BUF_RES_XI, "fixedPointResidualXi"); put(RN_BUF_RES_PSI, "fixedPointResidualPsi");
+            put(RN_BUF_ACC_XI, "acceleXi"); put(RN_BUF_ACC_PSI, "accelePsi"); put(RN_BUF_X, "X"); put(RN_BUF_U, "U");
+            put(RN_BUF_LBFGS_DIR_XI, "lbfgsDirXi"); put(RN_BUF_LBFGS_DIR_PSI, "lbfgsDirPsi");
+            if (fbe) { put(RN_BUF_LBFGS_CUR_YVEC_XI, "fbeGradXi"); put(RN_BUF_LBFGS_CUR_YVEC_PSI, "fbeGradPsi"); }
+            put(RN_BUF_PRIMAL_XI, "primalX"); put(RN_BUF_PRIMAL_PSI, "primalU");
+            const real_t v = computeValueFbe();
+            const real_t tau = fbe ? computeLineSearchLbfgsUpdate(v) : computeLineSearchAmeLbfgsUpdate(v);
+            CHECK(std::fabs((v - j["fbeObjDual"][0]) / j["fbeObjDual"][0] * 100) < 1e-1);
+            getVector(RN_BUF_ACC_XI, a.data()); CHECK(closeRef(a.data(), j["updateXi"], nxi, "updateXi"));
+            getVector(RN_BUF_ACC_PSI, b.data()); CHECK(closeRef(b.data(), j["updatePsi"], nps, "updatePsi"));
+            CHECK(std::fabs(tau - j["tau"][0]) < 1e-1);
+            getVector(RN_BUF_RES_XI, a.data()); CHECK(closeRef(a.data(), j["updateResidualXi"], nxi, "updateResidualXi"));
+            getVector(RN_BUF_RES_PSI, b.data()); CHECK(closeRef(b.data(), j["updateResidualPsi"], nps, "updateResidualPsi"));
+            std::cout << (fbe ? "fbe" : "nama") << " line search: value " << v << " tau " << tau << "\n";
+        }
+        {   // testFbeDualUpdate (:938)
+            put(RN_BUF_XI, "acceleXi"); put(RN_BUF_PSI, "accelePsi"); put(RN_BUF_ACC_XI, "updateXi"); put(RN_BUF_ACC_PSI, "updatePsi");
+            put(RN_BUF_RES_XI, "updateResidualXi"); put(RN_BUF_RES_PSI, "updateResidualPsi");
+            put(RN_BUF_LBFGS_CUR_YVEC_XI, "lbfgsCurrentYvecXi"); put(RN_BUF_LBFGS_CUR_YVEC_PSI, "lbfgsCurrentYvecPsi");
+            dualUpdate();
+            getVector(RN_BUF_XI, a.data()); CHECK(closeRef(a.data(), j["finalUpdateXi"], nxi, "finalUpdateXi"));
+            getVector(RN_BUF_PSI, b.data()); CHECK(closeRef(b.data(), j["finalUpdatePsi"], nps, "finalUpdatePsi"));
+            getVector(RN_BUF_LBFGS_PREV_YVEC_XI, a.data()); CHECK(closeAbs(a.data(), j["lbfgsCurrentYvecXi"].arr.data(), nxi, 1e-12, "previousYvecXi"));
+            getVector(RN_BUF_PREV_XI, a.data()); CHECK(closeAbs(a.data(), j["acceleXi"].arr.data(), nxi, 1e-12, "prevXi"));
+            getVector(RN_BUF_PREV_PSI, b.data()); CHECK(closeAbs(b.data(), j["accelePsi"].arr.data(), nps, 1e-12, "prevPsi"));
+            std::vector<real_t> a2(nxi);
+            getVector(RN_BUF_ACC_XI, a.data()); getVector(RN_BUF_XI, a2.data()); CHECK(closeAbs(a.data(), a2.data(), nxi, 1e-300 + 0.0 + 1e-12, "accelerated == xi"));
+        }
+        // the whole loop runs from a cold start and stays finite
+        CHECK((fbe ? algorithmGlobalFbe() : algorithmNama()) == 1);
+        const uint_t last = getSmpcConfiguration()->getMaxIterations() - 1;
+        CHECK(std::isfinite(getPrimalInfeasibility()[last]) && std::isfinite(getValueFbe()[last - 1]) && getVecTau()[0] == 1.0);
+        std::cout << (fbe ? "fbe" : "nama") << ": primal infeasibility first " << getPrimalInfeasibility()[0] << " last " << getPrimalInfeasibility()[last]
+                  << ", dual value " << getValueFbe()[0] << " -> " << getValueFbe()[last - 1] << "\n";
     }
 };
 
@@ -314,6 +415,11 @@ int main(int argc, char **argv) {
         else if (mode == "controller") {
             TestSmpcController t(dir + "/controllerConfig.json");
             t.getForecaster()->predictDemand(1);   // timeInst = 1, Testing.cu:500-502
+            t.getForecaster()->predictPrices(1);
+            t.run(dir);
+        } else if (mode == "fbe" || mode == "nama") {
+            TestFbeNamaController t(dir + (mode == "fbe" ? "/controllerFbeConfig.json" : "/controllerNamaConfig.json"));
+            t.getForecaster()->predictDemand(1);   // timeInst = 1, Testing.cu:540-542
             t.getForecaster()->predictPrices(1);
             t.run(dir);
         } else if (mode == "closedloop") testClosedLoop(dir);

@@ -41,6 +41,14 @@ def test_controller_known_answers_cpp():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fbe", "nama"])
+def test_fbe_nama_known_answers_cpp(mode):
+    """Testing::testSmpcFbeController / testSmpcNamaController re-run on the reference's own vectors."""
+    out = _run(mode)
+    assert "all checks passed" in out
+
+
+@pytest.mark.gpu
 def test_closed_loop_cpp():
     _run("closedloop")
 
