@@ -25,6 +25,13 @@ CONFIGS = {
     "small": (11, 5, 9, 6, 3, 8, [3, 2, 2]),
     "odd": (12, 7, 13, 5, 4, 7, [2, 3]),
     "medium": (13, 21, 38, 30, 6, 12, [4, 5]),
+    # edge shapes: branching that starts late (single-child crown nodes), a deep binary crown (127 crown nodes: the
+    # stage-by-stage crown kernels instead of the fused one), the shortest horizons, one wide fan-out
+    "late": (14, 4, 7, 5, 2, 9, [1, 1, 3, 1, 2]),
+    "deep": (15, 3, 6, 4, 2, 10, [2, 2, 2, 2, 2, 2, 2]),
+    "horizon1": (16, 3, 6, 4, 2, 1, []),
+    "horizon2": (17, 3, 6, 4, 2, 2, [3]),
+    "fan": (18, 4, 8, 6, 3, 4, [70]),
 }
 
 

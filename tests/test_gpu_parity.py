@@ -25,10 +25,10 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def make_pair(name, precision="f64", structured=False, **kw):
+def make_pair(name, precision="f64", structured=False, alias_operators=True, **kw):
     p = synth.make_problem(name, **kw)
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
+    o = Oracle(p["network"], p["tree"], p["config"], precision=precision, alias_operators=alias_operators)
     o.initialise(dh, ah)
     s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision, structured=structured)
     s.initialiseSmpcController(dh, ah)
@@ -170,6 +170,28 @@ def test_soft_constraint_branch():
     # step-wise prox on the same branch
     s.proximalFunG(); o.prox()
     assert relmax(s.get(capi.BUF_DUAL_XI), o.get("dualXi")) < REL_TOL
+
+
+# Tree shapes at the edge of (and beyond) what the reference can represent.  Its Omega/Theta pointer aliasing
+# (Engine.cu:210-221) keys on ScenarioTree::getFinalBranchNode (ScenarioTree.cu:147-156), which is only meaningful for
+# trees that branch in the leading stages and then chain: for late branching, for N = 1 and for trees that branch up to
+# the last stage it indexes before the start of devMatOmega.  The HIP path derives every block from the node's own
+# probability, so for those shapes the oracle is run with the aliasing off (same formulas, per-node blocks).
+EDGE_SHAPES = [("deep", True), ("fan", True), ("late", False), ("horizon1", False), ("horizon2", False)]
+
+
+@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("name,alias", EDGE_SHAPES)
+def test_edge_tree_shapes(name, alias, structured):
+    p, o, s = make_pair(name, structured=structured, alias_operators=alias)
+    for bid, oname in ((capi.BUF_UHAT, "uhat"), (capi.BUF_E, "e"), (capi.BUF_BETA, "beta"), (capi.BUF_ALPHA, "alpha")):
+        assert relmax(s.get(bid), o.get(oname)) < REL_TOL, oname
+    hist, ohist = s.algorithmApg(30), o.apg(30)
+    compare_all(s, o, REL_TOL, "%s (%s)" % (name, "structured" if structured else "dense"))
+    assert np.abs(hist - ohist).max() <= 1e-9 * max(np.abs(ohist).max(), 1.0)
+    u0 = s.controlAction(*synth.forecast_at(p["forecast"], 1), maxIterations=10)
+    o.update_state_control(); o.eliminate(*synth.forecast_at(p["forecast"], 1)); o.apg(10)
+    assert relmax(u0, o.get("u")[: o.nu]) < REL_TOL
 
 
 def test_control_action_and_uncertainty_flags():
