@@ -585,6 +585,170 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
     }
 }
 
+// Slab variant of the same product (the default).  k_gemm_shared re-reads its A fragments per 16-node tile and K
+// quarter and gathers its B operand in 32-byte pieces: the vector-memory pipe of the CU, not HBM or the MFMA pipe,
+// bounds it.  Here one workgroup owns a slab of 16 consecutive nodes: the slab's inputs (contiguous in memory,
+// in = [node][k]) are copied to LDS with fully coalesced loads, every wave owns whole 16-row tiles over the full K (no
+// split, no LDS reduction), B operands come from LDS (row stride = 4 mod 64 elements: conflict-free for ds_read_b32 and
+// ds_read_b64 in the MFMA operand pattern), only ceil(m/16) row tiles are computed (M stays stored 64-row padded), and
+// the workgroup has as many waves as divide the tile count evenly (6 for the 88- and 177-row operators).
+// fp64 note: v_mfma_f64_16x16x4 runs at 1/64 per cycle per SIMD (78 TFLOP/s chip-wide), so these products have an
+// MFMA floor of the same order as their HBM floor (4-5 us each on the 493-scenario tree).
+constexpr int SLAB_MAX_WAVES = 8;
+#ifndef RN_SLAB_ROTATE
+#define RN_SLAB_ROTATE 1
+#endif
+#ifndef RN_SLAB_KU
+#define RN_SLAB_KU 4   // k-steps whose operands a wave requests at once (measured: 4 beats 8 and 12 on the 493-scenario tree)
+#endif
+template <typename T>
+__device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, int k, int kp, int node0, int cnt, int wave, int nw, int lane) {
+    // 64 consecutive elements of one row per wave-instruction, SLAB_LD requests in flight per wave; zero fill up to kp / 16 rows
+    constexpr int SLAB_LD = 8;
+    const int cpr = (kp + 63) / 64;
+    const int nChunks = 16 * cpr;
+    for (int c0 = wave; c0 < nChunks; c0 += nw * SLAB_LD) {
+        T v[SLAB_LD];
+        int dst[SLAB_LD];
+#pragma unroll
+        for (int u = 0; u < SLAB_LD; u++) {
+            const int c = c0 + nw * u;
+            const int r = c / cpr, kk = (c - r * cpr) * 64 + lane;
+            const bool live = c < nChunks && r < cnt && kk < k;
+            v[u] = live ? in[(size_t)(node0 + r) * ldin + kk] : (T)0;
+            dst[u] = (c < nChunks && kk < SB) ? r * SB + kk : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SLAB_LD; u++) if (dst[u] >= 0) sB[dst[u]] = v[u];
+    }
+}
+// acc[j] = M[tile t0 + j*ts] * slab  for j < TG (tiles past `tiles` recompute tile t0; the caller drops them)
+template <typename T, int TG>
+__device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], const T *M, int mp, int t0, int ts, int tiles, int ksteps,
+                                          const T *sB, int SB, int lane) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    constexpr int KU = RN_SLAB_KU;
+    const int col = lane & 15, kq = lane >> 4;
+    const T *Ap[TG];
+#pragma unroll
+    for (int j = 0; j < TG; j++) {
+        const int t = t0 + ts * j;
+        Ap[j] = M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
+        acc[j] = acc_t{0, 0, 0, 0};
+    }
+    const T *Bp = sB + col * SB + kq;
+    for (int ks = 0; ks < ksteps; ks += KU) {
+        T av[KU][TG], bv[KU];
+#pragma unroll
+        for (int i = 0; i < KU; i++) {
+            const bool on = ks + i < ksteps;
+            const int kc = on ? ks + i : ksteps - 1;
+#pragma unroll
+            for (int j = 0; j < TG; j++) av[i][j] = Ap[j][(size_t)kc * 4 * mp];
+            bv[i] = on ? Bp[kc * 4] : (T)0;
+        }
+#pragma unroll
+        for (int i = 0; i < KU; i++)
+#pragma unroll
+            for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+    }
+}
+// auxiliary operands of the epilogue (m1_i or e_i), requested BEFORE the MFMA loop so that their latency hides behind it
+template <typename T, int EPI, int TG>
+__device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T &scale, const GemmArgs<T> &g, int t0, int ts, int node0, int lane) {
+    const int node = node0 + (lane & 15);
+    const int nodeC = node < g.nodes ? node : g.nodes - 1;
+    scale = 0;
+    if (EPI == EPI_V) scale = (T)(-0.5) / g.prob[nodeC];
+#pragma unroll
+    for (int j = 0; j < TG; j++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int gr = (t0 + ts * j) * 16 + Mfma16<T>::row(lane, reg);
+            auxv[j][reg] = (EPI != EPI_LV) ? g.aux[(size_t)nodeC * g.ldaux + (gr < g.m ? gr : g.m - 1)] : (T)0;
+        }
+}
+// epilogue of one pass; sOut != nullptr also keeps the results in LDS ([16][SO], the B operand of a following product)
+template <typename T, int EPI, int TG>
+__device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc)[TG], const T (&auxv)[TG][4], T scale, const GemmArgs<T> &g,
+                                           int t0, int ts, int tiles, int node0, int lane, T *sOut, int SO) {
+    const int col = lane & 15;
+    const int node = node0 + col;
+    const bool nodeOk = node < g.nodes;
+#pragma unroll
+    for (int j = 0; j < TG; j++) {
+        const int t = t0 + ts * j;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+            T r = acc[j][reg];
+            if (EPI == EPI_V) r = auxv[j][reg] + scale * r;
+            if (EPI == EPI_Z) r = auxv[j][reg] + r;
+            const bool live = t < tiles && gr < g.m;
+            if (live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
+            if (sOut && live) sOut[col * SO + gr] = nodeOk ? r : (T)0;
+        }
+    }
+}
+template <typename T, int EPI, int TG>
+__device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int SB, int node0, int t0, int nw, int tiles, int ksteps, int lane,
+                                          T *sOut, int SO) {
+    typename Mfma16<T>::acc_t acc[TG];
+    T auxv[TG][4], scale;
+    slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
+    slab_mfma<T, TG>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
+    slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
+}
+template <typename T, int EPI>
+__device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
+    const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
+    const int per = (tiles + nw - 1) / nw;               // tiles per wave
+    const int tg = per >= 3 ? 3 : per;
+    // when the tile count is not a multiple of the wave count some waves (= SIMDs) carry one tile more: rotate the
+    // assignment from workgroup to workgroup so that the workgroups sharing a CU do not load the same SIMDs
+#if RN_SLAB_ROTATE
+    const int b = blockIdx.x;
+    const int owner = (wave + b + (b >> 3) + (b >> 8)) % nw;
+#else
+    const int owner = wave;
+#endif
+    for (int t0 = owner; t0 < tiles; t0 += nw * tg) {
+        if (tg == 3) slab_pass<T, EPI, 3>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else if (tg == 2) slab_pass<T, EPI, 2>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else slab_pass<T, EPI, 1>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+    }
+}
+template <typename T, int EPI>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g, int SB) {
+    extern __shared__ unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int node0 = blockIdx.x * 16;
+    const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
+    slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
+    __syncthreads();
+    slab_product<T, EPI>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+}
+// v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
+// of the second product (gL.in is ignored; gL.k must equal gV.m)
+template <typename T>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV) {
+    extern __shared__ unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
+    T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int node0 = blockIdx.x * 16;
+    const int cnt = gV.nodes - node0 < 16 ? gV.nodes - node0 : 16;
+    slab_load<T>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane);
+    for (int i = threadIdx.x; i < 16 * SV; i += blockDim.x) sV[i] = (T)0;
+    __syncthreads();
+    slab_product<T, EPI_V>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
+    __syncthreads();
+    slab_product<T, EPI_LV>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
 // Utilities.cu:142-155) and the diagonal Hx products (:744-747):

@@ -16,6 +16,9 @@
 #include "../../include/rapidnet.h"
 #include "fbe_kernels.hpp"
 
+#ifndef RN_GEMM_SLAB
+#define RN_GEMM_SLAB 1   // 1: slab kernels (k_gemm_slab / fused k_gemm_vlv); 0: always the tile kernel k_gemm_shared
+#endif
 #ifndef RN_GEMM_KS
 #define RN_GEMM_KS 3   // k-steps whose operands a wave requests at once in k_gemm_shared (tuning knob)
 #endif
@@ -537,11 +540,50 @@ struct Ctx : CtxBase {
         const int nCP = STREAM_WAVES / std::min(nRB, STREAM_WAVES);
         return (size_t)(((ny + 3) & ~3) + (size_t)nCP * LDp) * sizeof(T);
     }
+    static int slab_stride(int kp) { return (kp + 59) / 64 * 64 + 4; }   // >= kp, = 4 (mod 64): conflict-free MFMA B reads
+    // waves per slab workgroup: the count in {4, 6, 8} that wastes the least SIMD time on idle tile slots
+    static int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) {
+        int best = 4; long bestCost = -1;
+#ifdef RN_SLAB_WAVES
+        return RN_SLAB_WAVES;
+#endif
+        for (int nw : {4, 6, 8}) {
+            const long cost = (long)nw * ((long)((tilesA + nw - 1) / nw) * kstepsA + (long)((tilesB + nw - 1) / nw) * kstepsB);
+            if (bestCost < 0 || cost < bestCost) { best = nw; bestCost = cost; }
+        }
+        return best;
+    }
     template <int EPI>
     void launch_gemm(const T *Mp, int m, int k, const T *in, int ldin, T *out, int ldout, const T *aux, int ldaux) {
         GemmArgs<T> g{Mp, m, k, pad16(m), pad4(k), in, ldin, out, ldout, aux, ldaux, d_prob, d.nodes};
+#if RN_GEMM_SLAB
+        const int SB = slab_stride(g.kp);
+        const size_t lds = (size_t)16 * SB * sizeof(T);
+        if (lds <= 64 * 1024) {   // slab kernel (default); falls back to the tile kernel when the slab does not fit
+            const int nw = slab_waves((m + 15) / 16, g.kp / 4, 0, 0);
+            hipLaunchKernelGGL((k_gemm_slab<T, EPI>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            return;
+        }
+#endif
         const int units = (g.mp / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);   // one 64 x 16 output tile per workgroup
         hipLaunchKernelGGL((k_gemm_shared<T, EPI, RN_GEMM_KS>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
+    }
+    // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
+    void launch_v_lv() {
+        const int nx = d.nx, nu = d.nu, nv = d.nv;
+#if RN_GEMM_SLAB
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes};
+        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), d_v, nv, d_lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
+        const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
+        const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
+        if (lds <= 64 * 1024) {
+            const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
+            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV);
+            return;
+        }
+#endif
+        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
+        launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
     // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
@@ -603,8 +645,7 @@ struct Ctx : CtxBase {
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
-        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
-        launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
+        launch_v_lv();
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
         if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
         else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
