@@ -730,6 +730,35 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g
     __syncthreads();
     slab_product<T, EPI>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
+// Structured operator mode, first product of the sweep: m2_i = [Bbt | L'] [a_i; b_i] with a_i = F_i' xi_i, b_i = G_i' psi_i
+// (F_i, G_i diagonal).  The slab of [a; b] is built in LDS straight from the duals (what k_struct_prep + a slab load
+// would do in two launches and one HBM round trip); a_i is also written out (the q recursion of k_up_chain needs it).
+template <typename T>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T> g, SweepArgs<T> a, int SB) {
+    extern __shared__ unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int node0 = blockIdx.x * 16;
+    const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
+    const int nx = a.nx, ny = a.ny, k = g.k;     // k = nx + nu
+    for (int r = wave; r < 16; r += nw) {         // one slab row (node) per wave and pass
+        const int node = node0 + (r < cnt ? r : 0);
+        const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+        const T *y = a.w + (size_t)node * ny;
+        const T sp = a.tr.sqrtp[node];
+        for (int t = lane; t < SB; t += 64) {
+            T val = 0;
+            if (r < cnt && t < k) {
+                if (t < nx) { val = sp * (dy[t] * y[t] + dy[nx + t] * y[nx + t]); a.qa[(size_t)node * nx + t] = val; }
+                else { const int j = t - nx; val = sp * dy[2 * nx + j] * y[2 * nx + j]; }
+            }
+            sB[r * SB + t] = val;
+        }
+    }
+    __syncthreads();
+    slab_product<T, EPI_LV>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+}
 // v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 template <typename T>

@@ -568,6 +568,24 @@ struct Ctx : CtxBase {
         const int units = (g.mp / (16 * GEMM_RT)) * ((d.nodes + 15) / 16);   // one 64 x 16 output tile per workgroup
         hipLaunchKernelGGL((k_gemm_shared<T, EPI, RN_GEMM_KS>), dim3(units), dim3(GEMM_THREADS), 0, stream, g);
     }
+    // structured mode, (1) of the sweep: a_i = F_i' xi_i, b_i = G_i' psi_i and m2_i = [Bbt | L'] [a_i; b_i]
+    void launch_prep_m2(const SweepArgs<T> &a) {
+        const int nx = d.nx, nu = d.nu, nv = d.nv;
+#if RN_GEMM_SLAB
+        GemmArgs<T> g{d_BLp, nv, nx + nu, pad16(nv), pad4(nx + nu), d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0, d_prob, d.nodes};
+        const int SB = slab_stride(g.kp);
+        const size_t lds = (size_t)16 * SB * sizeof(T);
+        if (lds <= 64 * 1024) {
+            const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
+            hipLaunchKernelGGL(k_gemm_prep_m2<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            return;
+        }
+#endif
+        const long long tot = (long long)d.nodes * (nx + nu);
+        const int blocks = (int)std::min<long long>(4096, (tot + 255) / 256);
+        hipLaunchKernelGGL(k_struct_prep<T>, dim3(blocks), dim3(256), 0, stream, a);
+        launch_gemm<EPI_LV>(d_BLp, nv, nx + nu, d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0);
+    }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
     void launch_v_lv() {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
@@ -610,10 +628,7 @@ struct Ctx : CtxBase {
         if (phase != 2) {
             e0 = prof_begin(0);
             if (structured) {
-                const long long tot = (long long)d.nodes * (nx + nu);
-                const int blocks = (int)std::min<long long>(4096, (tot + 255) / 256);
-                hipLaunchKernelGGL(k_struct_prep<T>, dim3(blocks), dim3(256), 0, stream, a);
-                launch_gemm<EPI_LV>(d_BLp, nv, nx + nu, d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0);
+                launch_prep_m2(a);
             } else hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
             prof_end(e0);
         }
