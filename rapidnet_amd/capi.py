@@ -64,7 +64,14 @@ def load():
         return _LIB
     path = lib_path()
     if not os.path.exists(path):
-        raise RuntimeError("librapidnet_hip.so is missing (%s); run __graft_entry__.build() -- there is no CPU fallback" % path)
+        # a fresh checkout: compile the HIP library in-tree (hipcc is part of the image); there is no CPU fallback
+        if os.environ.get("RAPIDNET_LIB"):
+            raise RuntimeError("$RAPIDNET_LIB names a missing library: %s" % path)
+        try:
+            _build.build_hip()
+        except Exception as e:
+            raise RuntimeError("librapidnet_hip.so is missing (%s) and could not be built (%s); run __graft_entry__.build() -- "
+                               "there is no CPU fallback" % (path, e))
     lib = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
     lib.rn_create.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree), ip, ip, C.POINTER(vp)]
