@@ -159,6 +159,11 @@ def main():
             ms, n = s.profileRead()
             s.profileEnable(0)
             bwd_bytes, dual_bytes = s.algorithmicBytes()
+            # what a do-nothing streaming kernel reaches on this very device (practical denominator beside the 8 TB/s spec)
+            try:
+                read_ceiling, copy_ceiling = s.measureHbm(2 << 30, 3)
+            except capi.RapidNetError:
+                read_ceiling, copy_ceiling = None, None
             names = ("stream_gemv" if not structured else "struct_prep+gemm_m2", "recursion+shared_gemms", "dual_update", "bookkeeping")
             for i, nm in enumerate(names):
                 classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
@@ -177,6 +182,8 @@ def main():
                 roofline = {"kernel": "k_dual_fused", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
                             "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"),
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
+                if copy_ceiling:
+                    roofline.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
             else:
                 avg_s = 1e-3 * ms[0] / max(n[0], 1)
                 achieved = bwd_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -184,6 +191,9 @@ def main():
                             "frac": achieved / 8000.0, "traffic": traffic.get("k_stream_gemv_bytes_per_launch"),
                             "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": 1e6 * avg_s, "launches_per_step": 1,
                             "dual_update": dual}
+                if read_ceiling:   # read-only stream vs a read-only probe; the dual update (5 read + 2 write streams) vs the copy probe
+                    roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
+                    dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
                "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}

@@ -212,6 +212,15 @@ int rn_profile_reset(rn_ctx *ctx);
 int rn_profile_read(rn_ctx *ctx, double ms[4], long launches[4]);
 /* algorithmic HBM bytes of ONE launch of the dominant kernels, as defined in DESIGN.md */
 int rn_algorithmic_bytes(const rn_ctx *ctx, double *backwardStageBytesTotal, double *dualUpdateBytes);
+/* streaming ceilings of THIS device measured with do-nothing kernels (16 B per lane per load, non-temporal): flat
+ * grid-stride read-only GB/s and copy GB/s (read + written bytes), best of `reps` passes over `bytes`.
+ * bench.py reports them beside the 8 TB/s spec peak as the practical denominator. */
+int rn_measure_hbm(rn_ctx *ctx, size_t bytes, int reps, double *readGBs, double *copyGBs);
+/* read-only probes in the solver's access shapes (tools/probe_hbm.py).  shape 0: n workgroups of 256 threads, each
+ * streaming its own contiguous pieceBytes ("one node"; chunks start strideBytes apart).  shape 1: n persistent workgroups
+ * in lockstep -- in every step workgroup w reads piece w of a contiguous n*pieceBytes window (pieceBytes <= 8192);
+ * strideBytes = total bytes to read.  `unroll` (1, 2, 4, 8) = steps in flight per thread. */
+int rn_measure_hbm_shape(rn_ctx *ctx, int shape, size_t pieceBytes, size_t strideBytes, int n, int unroll, int reps, double *readGBs);
 /* the context's stream as a hipStream_t (void* to keep HIP types out of this header) */
 void *rn_stream(rn_ctx *ctx);
 

@@ -30,7 +30,7 @@ SYMBOLS = [
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
-    "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
+    "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_compute_value_fbe",
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
 ]
@@ -115,6 +115,8 @@ def load():
     lib.rn_set_exchange_mode.argtypes = [vp, ip]
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
     lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
+    lib.rn_measure_hbm.argtypes = [vp, C.c_size_t, ip, dp, dp]
+    lib.rn_measure_hbm_shape.argtypes = [vp, ip, C.c_size_t, C.c_size_t, ip, ip, ip, dp]
     lib.rn_set_algorithm.argtypes = [vp, ip, ip]
     for f in ("rn_fbe_reset", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe", "rn_update_fixed_point_residual_nama",
               "rn_compute_lbfgs_direction"):
@@ -388,6 +390,19 @@ class Solver:
         n = np.zeros(4, dtype=np.int64)
         self._check(self.lib.rn_profile_read(self.h, ms.ctypes.data, n.ctypes.data))
         return ms, n
+
+    def measureHbm(self, nbytes=1 << 30, reps=3):
+        """(read-only GB/s, copy GB/s) of do-nothing flat streaming kernels on this device."""
+        r, c = C.c_double(0), C.c_double(0)
+        self._check(self.lib.rn_measure_hbm(self.h, int(nbytes), int(reps), C.addressof(r), C.addressof(c)))
+        return r.value, c.value
+
+    def measureHbmShape(self, shape, piece_bytes, n, unroll=4, reps=3, stride_or_total=None):
+        """read-only GB/s of a probe in one of the solver's access shapes (0: chunk per workgroup, 1: lockstep pieces)."""
+        r = C.c_double(0)
+        self._check(self.lib.rn_measure_hbm_shape(self.h, int(shape), int(piece_bytes), int(stride_or_total or piece_bytes), int(n),
+                                                  int(unroll), int(reps), C.addressof(r)))
+        return r.value
 
     def algorithmicBytes(self):
         a, b = C.c_double(0), C.c_double(0)

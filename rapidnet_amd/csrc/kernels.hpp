@@ -16,7 +16,7 @@
 
 namespace rn {
 
-constexpr int RPL = 4;          // rows of A per lane (16 B fp32 / 32 B fp64 per lane per column)
+constexpr int RPL = 4;          // the leading dimension LD of the per-node operator blocks is a multiple of RPL values
 constexpr int ELT_THREADS = 256;
 constexpr int ELT_MAX_BLOCKS = 1024;
 
@@ -73,19 +73,8 @@ struct SweepArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------
-// wide loads of RPL consecutive rows
-template <typename T> __device__ __forceinline__ void load_rows(const T *p, T (&a)[RPL]);
 typedef double nat_d2 __attribute__((ext_vector_type(2)));
 typedef float nat_f4 __attribute__((ext_vector_type(4)));
-template <> __device__ __forceinline__ void load_rows<double>(const double *p, double (&a)[RPL]) {
-    const nat_d2 lo = __builtin_nontemporal_load(reinterpret_cast<const nat_d2 *>(p));
-    const nat_d2 hi = __builtin_nontemporal_load(reinterpret_cast<const nat_d2 *>(p) + 1);
-    a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
-}
-template <> __device__ __forceinline__ void load_rows<float>(const float *p, float (&a)[RPL]) {
-    const nat_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nat_f4 *>(p));
-    a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
-}
 
 // out[r] = sum_j M[r + j*rows] * vec[j] for r < rows, computed by the whole block: thread (h, r) with
 // r = tid % RB, h = tid / RB sums columns j == h (mod H); partials are combined through `scratch` (>= H*RB).
@@ -130,114 +119,128 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 // ------------------------------------------------------------------------------------------------------
 // The dominant kernel.  Batched per-node mat-vec  [m1_i; m2_i] = A_i y_i  for ALL nodes of the tree in one
 // launch (SmpcController.cu:617-638 issues these as 4 cublasSgemmBatched per stage inside the sequential sweep;
-// they do not depend on the recursion, only the vector sums do -- see k_up_*).  One workgroup per node,
-// STREAM_THREADS/64 waves; wave w owns column phase cp = w / nRB of row block rb = w % nRB; lane l owns rows
-// rb*256 + 4l .. 4l+3 of every column of its phase (16 B fp32 / 32 B fp64 per lane per column, the whole wave
-// reads one contiguous LD*sizeof(T) column).  Loads are non-temporal (A is read once per iteration and is far
-// larger than the 256 MiB Infinity Cache) and double-buffered in groups of G columns so that ~2G columns per
-// wave are always in flight.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
+// they do not depend on the recursion, only the vector sums do -- see k_up_*).  One workgroup per node.
+//
+// Access shape (decided by measurement, tools/probe_hbm.py): a do-nothing reader with one workgroup per 376 KB node
+// block reaches 6.7-6.8 TB/s on MI355X when every wave-load is 64 lanes x 16 B = 1 KB CONTIGUOUS, and only 5.9 TB/s
+// when a lane fetches 32 adjacent bytes as two loads (each wave-load then touches 16 cache lines and uses half of
+// each) -- which is what "4 fp64 rows per lane" amounts to.  So the block is walked in 16-byte SLOTS: a column of A_i
+// (LD values) is SPC = LD*sizeof(T)/16 slots, a SPAN is G consecutive columns, and thread t owns slots t, t+256, ...
+// (NL of them) of every span: consecutive threads read consecutive 16 B, across column boundaries, and each thread always
+// meets the same rows, so its partial sums stay in registers.  G is chosen on the host so that a span nearly fills a
+// multiple of 256 slots (493-scenario tree, fp64: SPC = 98, G = 5 -> 490 of 512 slots, every lane busy in 96 % of the
+// loads).  Loads are non-temporal (A is read once per iteration and is far larger than the 256 MiB Infinity Cache) and
+// double-buffered in groups of D spans.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
 // HBM bytes per node: LD*ny*sizeof(T) + (ny + 2nv + nx)*sizeof(T).
 #ifndef RN_STREAM_THREADS
 #define RN_STREAM_THREADS 256
 #endif
-#ifndef RN_STREAM_G
-#define RN_STREAM_G 5
-#endif
-#ifndef RN_STREAM_BLOCKED
-#define RN_STREAM_BLOCKED 1
+#ifndef RN_STREAM_D
+#define RN_STREAM_D 4
 #endif
 #ifndef RN_STREAM_MINW
 #define RN_STREAM_MINW 3
 #endif
 constexpr int STREAM_THREADS = RN_STREAM_THREADS;
-constexpr int STREAM_WAVES = STREAM_THREADS / 64;
-constexpr int STREAM_G = RN_STREAM_G;   // columns per pipeline stage
+constexpr int STREAM_NLMAX = 4;   // slots per thread and span
 
-template <typename T>
-__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a) {
+template <typename T> struct Slot;
+template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
+template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4; };
+
+template <typename T, int NL>
+__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G) {
+    typedef typename Slot<T>::type VT;
+    constexpr int VPL = Slot<T>::N, D = RN_STREAM_D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny
-    T *sh_red = sh_y + ((a.ny + 3) & ~3);               // nCP * LDp
+    T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny (+ G of zero padding is not needed: guarded reads)
+    T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
     const int tid = threadIdx.x;
     const int node = blockIdx.x;
     const int nx = a.nx, nv = a.nv, ny = a.ny, LD = a.LD;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int nRB = (LD + 64 * RPL - 1) / (64 * RPL);                       // row blocks of 256 rows
-    const int nRBw = nRB < STREAM_WAVES ? nRB : STREAM_WAVES;
-    const int nCP = STREAM_WAVES / nRBw;                                     // column phases
-    const int LDp = (LD + 3) & ~3;
-    for (int rb0 = 0; rb0 < nRB; rb0 += nRBw) {
-        const int rb = rb0 + wave % nRBw, cp = wave / nRBw;
-        const int row = rb * 64 * RPL + lane * RPL;
-        const bool active = rb < nRB && cp < nCP && row < LD;
-        T part[RPL] = {0, 0, 0, 0};
-        const T *Ab = a.A + (size_t)node * ny * LD + (active ? row : 0);
-        // each column phase owns a CONTIGUOUS block of columns: one wave streams one contiguous region of A_i, so the
-        // 128-B lines straddling two columns are fetched once (interleaved phases re-fetched ~6 %, PMC FETCH_SIZE)
-#if RN_STREAM_BLOCKED
-        const int perPhase = (ny + nCP - 1) / nCP;
-        const int cBeg = cp * perPhase < ny ? cp * perPhase : ny, cStr = 1;
-        const int ncol = (cBeg + perPhase < ny ? cBeg + perPhase : ny) - cBeg;
-#else   // interleaved: the waves of a workgroup walk through A_i side by side (neighbouring columns at the same time)
-        const int cBeg = cp, cStr = nCP;
-        const int ncol = (ny - cp + nCP - 1) / nCP;
-#endif
-        const int nG = active ? ncol / STREAM_G : 0;
-        T bufA[STREAM_G][RPL], bufB[STREAM_G][RPL];
-#define RN_LOADG(buf, g_)                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) load_rows<T>(Ab + (size_t)(cBeg + ((g_) * STREAM_G + k) * cStr) * LD, buf[k]);
-        // the first group of A does not depend on y: put it in flight before the prologue
-        if (nG > 0) { RN_LOADG(bufA, 0) }
-        if (rb0 == 0) {
-            for (int c = tid; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
-            __syncthreads();
-            // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
-            const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
-            const T sp = a.tr.sqrtp[node];
-            for (int t = tid; t < nx; t += STREAM_THREADS) a.qa[(size_t)node * nx + t] = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
-        }
-        if (active) {
-#define RN_USEG(buf, g_)                                                                                               \
-    _Pragma("unroll") for (int k = 0; k < STREAM_G; k++) {                                                             \
-        const T yc = sh_y[cBeg + ((g_) * STREAM_G + k) * cStr];                                                        \
-        _Pragma("unroll") for (int r = 0; r < RPL; r++) part[r] += buf[k][r] * yc;                                     \
+    const int SPC = LD / VPL, spanSlots = G * SPC;
+    const long long blockSlots = (long long)ny * SPC;
+    const VT *__restrict__ Ab = reinterpret_cast<const VT *>(a.A + (size_t)node * ny * LD);
+    int off[NL], cj[NL];
+    T msk[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int q = tid + STREAM_THREADS * j;
+        const bool ok = q < spanSlots;
+        off[j] = ok ? q : spanSlots - 1;          // idle slots re-read the last slot of the span and multiply by zero
+        cj[j] = off[j] / SPC;
+        msk[j] = ok ? (T)1 : (T)0;
     }
-            if (nG > 0) {
-                int g = 0;
-                // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is
-                // consumed, group g+1 (and then g+2) is in flight
-                for (; g + 2 < nG; g += 2) {
-                    RN_LOADG(bufB, g + 1)
-                    RN_USEG(bufA, g)
-                    RN_LOADG(bufA, g + 2)
-                    RN_USEG(bufB, g + 1)
-                }
-                if (g + 1 < nG) {
-                    RN_LOADG(bufB, g + 1)
-                    RN_USEG(bufA, g)
-                    RN_USEG(bufB, g + 1)
-                } else {
-                    RN_USEG(bufA, g)
-                }
-            }
+    T part[NL][VPL];
+#pragma unroll
+    for (int j = 0; j < NL; j++)
+#pragma unroll
+        for (int e = 0; e < VPL; e++) part[j][e] = 0;
+    const int nFull = ny / G;                    // spans made of G whole columns
+    const int nGroups = nFull / D;
+    VT bufA[D][NL], bufB[D][NL];
+#define RN_LOADG(buf, g_)                                                                                              \
+    _Pragma("unroll") for (int d = 0; d < D; d++)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NL; j++)                                                                 \
+            buf[d][j] = __builtin_nontemporal_load(Ab + (size_t)((g_) * D + d) * spanSlots + off[j]);
+#define RN_USEG(buf, g_)                                                                                               \
+    _Pragma("unroll") for (int d = 0; d < D; d++)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NL; j++) {                                                               \
+            const T yc = sh_y[((g_) * D + d) * G + cj[j]] * msk[j];                                                    \
+            _Pragma("unroll") for (int e = 0; e < VPL; e++) part[j][e] += buf[d][j][e] * yc;                           \
+        }
+    // the first group of A does not depend on y: put it in flight before the prologue
+    if (nGroups > 0) { RN_LOADG(bufA, 0) }
+    for (int c = tid; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
+    __syncthreads();
+    {   // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
+        const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+        const T sp = a.tr.sqrtp[node];
+        for (int t = tid; t < nx; t += STREAM_THREADS) a.qa[(size_t)node * nx + t] = sp * (dy[t] * sh_y[t] + dy[nx + t] * sh_y[nx + t]);
+    }
+    if (nGroups > 0) {
+        int g = 0;
+        // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is consumed, group
+        // g+1 (and then g+2) is in flight
+        for (; g + 2 < nGroups; g += 2) {
+            RN_LOADG(bufB, g + 1)
+            RN_USEG(bufA, g)
+            RN_LOADG(bufA, g + 2)
+            RN_USEG(bufB, g + 1)
+        }
+        if (g + 1 < nGroups) {
+            RN_LOADG(bufB, g + 1)
+            RN_USEG(bufA, g)
+            RN_USEG(bufB, g + 1)
+        } else {
+            RN_USEG(bufA, g)
+        }
+    }
 #undef RN_LOADG
 #undef RN_USEG
-            for (int j = nG * STREAM_G; j < ncol; j++) {           // remainder columns
-                const int c = cBeg + j * cStr;
-                T m[RPL];
-                load_rows<T>(Ab + (size_t)c * LD, m);
-                const T yc = sh_y[c];
+    // remaining whole spans and the last, partial one (ny % G columns): guarded
+    for (int s = nGroups * D; s * G < ny; s++) {
 #pragma unroll
-                for (int r = 0; r < RPL; r++) part[r] += m[r] * yc;
-            }
+        for (int j = 0; j < NL; j++) {
+            const int c = s * G + cj[j];
+            const long long slot = (long long)s * spanSlots + off[j];
+            const bool live = msk[j] != (T)0 && c < ny && slot < blockSlots;
+            const VT v = __builtin_nontemporal_load(Ab + (live ? slot : 0));
+            const T yc = live ? sh_y[c] : (T)0;
 #pragma unroll
-            for (int r = 0; r < RPL; r++) sh_red[(size_t)cp * LDp + row + r] = part[r];
+            for (int e = 0; e < VPL; e++) part[j][e] += v[e] * yc;
         }
     }
+#pragma unroll
+    for (int j = 0; j < NL; j++)
+        if (msk[j] != (T)0) {
+#pragma unroll
+            for (int e = 0; e < VPL; e++) sh_red[(size_t)off[j] * VPL + e] = part[j][e];
+        }
     __syncthreads();
-    for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {
+    for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {    // slot q of a span = column q / SPC, rows (q % SPC) * VPL ...
         T s = sh_red[r];
-        for (int k = 1; k < nCP; k++) s += sh_red[(size_t)k * LDp + r];
+        for (int k = 1; k < G; k++) s += sh_red[(size_t)k * LD + r];
         a.my[(size_t)node * 2 * nv + r] = s;
     }
 }
@@ -1332,6 +1335,77 @@ __global__ void __launch_bounds__(ELT_THREADS) k_absmax(const T *res, long long 
         }
         partials[blockIdx.x] = p;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// HBM ceiling probes for bench.py / tools/probe_hbm.py (rn_measure_hbm*): what kernels that do nothing but stream reach
+// on THIS box -- the practical denominator next to the 8 TB/s spec.  16 B per lane per load, non-temporal.
+//   k_bw_read        flat: the whole grid sweeps one region, thread-interleaved (grid-stride)
+//   k_bw_read_chunks the streaming kernel's shape: one workgroup per contiguous chunk ("node"), 32 B per lane per step
+//   k_bw_read_lockstep  persistent workgroups; in step s of batch b workgroup w reads piece ((b*S + s)*W + w): all
+//                    workgroups together sweep one contiguous W*P-byte window per step
+#ifndef RN_PROBE_PAIRS
+#define RN_PROBE_PAIRS 0
+#endif
+__global__ void __launch_bounds__(256) k_bw_read(const nat_d2 *src, long long n, double *sink) {
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const nat_d2 v = __builtin_nontemporal_load(src + i);
+        acc += v[0] + v[1];
+    }
+    if (acc == 1.2345e-300) sink[blockIdx.x & 65535] = acc;   // keeps the loads alive without a store stream
+}
+template <int UNR>
+__global__ void __launch_bounds__(256) k_bw_read_chunks(const nat_d2 *src, long long chunk16, long long stride16, double *sink) {
+    const nat_d2 *p = src + (long long)blockIdx.x * stride16;
+    double acc = 0;
+    long long i = threadIdx.x;
+#if RN_PROBE_PAIRS   // lane reads 32 adjacent bytes as two loads (each wave-load touches 16 lines, half of every line)
+    i = 2 * threadIdx.x;
+    for (; i + 512 * (UNR - 1) + 1 < chunk16; i += 512 * UNR) {
+        nat_d2 v[UNR][2];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { v[u][0] = __builtin_nontemporal_load(p + i + 512 * u); v[u][1] = __builtin_nontemporal_load(p + i + 512 * u + 1); }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) acc += v[u][0][0] + v[u][0][1] + v[u][1][0] + v[u][1][1];
+    }
+    for (; i + 1 < chunk16; i += 512) { const nat_d2 a0 = __builtin_nontemporal_load(p + i), a1 = __builtin_nontemporal_load(p + i + 1); acc += a0[0] + a0[1] + a1[0] + a1[1]; }
+#else                // every wave-load is 1 KB contiguous (8 full lines); two loads per step, 4 KB apart
+    for (; i + 256 * (2 * UNR - 1) < chunk16; i += 512 * UNR) {
+        nat_d2 v[UNR][2];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { v[u][0] = __builtin_nontemporal_load(p + i + 512 * u); v[u][1] = __builtin_nontemporal_load(p + i + 512 * u + 256); }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) acc += v[u][0][0] + v[u][0][1] + v[u][1][0] + v[u][1][1];
+    }
+    for (; i < chunk16; i += 256) { const nat_d2 a0 = __builtin_nontemporal_load(p + i); acc += a0[0] + a0[1]; }
+#endif
+    if (acc == 1.2345e-300) sink[blockIdx.x & 65535] = acc;
+}
+template <int UNR>
+__global__ void __launch_bounds__(256) k_bw_read_lockstep(const nat_d2 *src, int piece16, int steps, int batches, double *sink) {
+    const long long W = gridDim.x;
+    double acc = 0;
+    const bool on = 2 * (int)threadIdx.x + 1 < piece16;
+    for (int b = 0; b < batches; b++) {
+        for (int s0 = 0; s0 < steps; s0 += UNR) {
+            nat_d2 v[UNR][2];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int s = s0 + u < steps ? s0 + u : steps - 1;
+                const nat_d2 *p = src + (((long long)b * steps + s) * W + blockIdx.x) * piece16 + 2 * threadIdx.x;
+                if (on) { v[u][0] = __builtin_nontemporal_load(p); v[u][1] = __builtin_nontemporal_load(p + 1); }
+                else { v[u][0] = nat_d2{0, 0}; v[u][1] = nat_d2{0, 0}; }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) acc += v[u][0][0] + v[u][0][1] + v[u][1][0] + v[u][1][1];
+        }
+    }
+    if (acc == 1.2345e-300) sink[blockIdx.x & 65535] = acc;
+}
+__global__ void __launch_bounds__(256) k_bw_copy(const nat_d2 *src, nat_d2 *dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 // ------------------------------------------------------------------------------------------------------

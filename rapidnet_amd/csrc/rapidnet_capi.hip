@@ -105,6 +105,8 @@ struct CtxBase {
     virtual int set_exchange_mode(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
+    virtual int measure_hbm(size_t, int, double *, double *) = 0;
+    virtual int measure_hbm_shape(int, size_t, size_t, int, int, int, double *) = 0;
     // global FBE / NAMA
     virtual int set_algorithm(int, int) = 0;
     virtual int fbe_reset() = 0;
@@ -534,11 +536,32 @@ struct Ctx : CtxBase {
     void *stream_handle() override { return (void *)stream; }
 
     // ---- the sweep ---------------------------------------------------------------------------------------
-    size_t stream_lds() const {
-        const int LDp = (LD + 3) & ~3;
-        const int nRB = (LD + 64 * RPL - 1) / (64 * RPL);
-        const int nCP = STREAM_WAVES / std::min(nRB, STREAM_WAVES);
-        return (size_t)(((ny + 3) & ~3) + (size_t)nCP * LDp) * sizeof(T);
+    // span of the streaming kernel: G columns = G*SPC 16-byte slots, NL slots per thread; the G that fills a multiple of
+    // STREAM_THREADS slots best (see k_stream_gemv)
+    void stream_shape(int *G, int *NL) const {
+        const int SPC = LD * (int)sizeof(T) / 16;
+        int bestG = 1, bestNL = (SPC + STREAM_THREADS - 1) / STREAM_THREADS; double bestU = -1;
+        for (int g = 1; g <= std::min(ny, 64); g++) {
+            const int slots = g * SPC, nl = (slots + STREAM_THREADS - 1) / STREAM_THREADS;
+            if (nl > STREAM_NLMAX) break;
+            const double u = (double)slots / ((double)nl * STREAM_THREADS);
+            if (u > bestU + 1e-9) { bestU = u; bestG = g; bestNL = nl; }
+        }
+        *G = bestG; *NL = bestNL;
+    }
+    size_t stream_lds(int G) const { return (size_t)(((ny + 3) & ~3) + (size_t)G * LD) * sizeof(T); }
+    int launch_stream(const SweepArgs<T> &a) {
+        int G, NL;
+        stream_shape(&G, &NL);
+        RN_CHECK(NL <= STREAM_NLMAX, RN_E_ARG, "k_stream_gemv: more than 4096 values per operator column are not supported (2*nv too large)");
+        const size_t lds = stream_lds(G);
+        switch (NL) {
+            case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G); break;
+            case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G); break;
+            case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G); break;
+            default: hipLaunchKernelGGL((k_stream_gemv<T, 4>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G); break;
+        }
+        return RN_OK;
     }
     static int slab_stride(int kp) { return (kp + 59) / 64 * 64 + 4; }   // >= kp, = 4 (mod 64): conflict-free MFMA B reads
     // waves per slab workgroup: the count in {4, 6, 8} that wastes the least SIMD time on idle tile slots
@@ -629,7 +652,7 @@ struct Ctx : CtxBase {
             e0 = prof_begin(0);
             if (structured) {
                 launch_prep_m2(a);
-            } else hipLaunchKernelGGL(k_stream_gemv<T>, dim3(d.nodes), dim3(STREAM_THREADS), stream_lds(), stream, a);
+            } else if (int rc = launch_stream(a)) return rc;
             prof_end(e0);
         }
         e1 = prof_begin(1);
@@ -1101,6 +1124,82 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         return write ? upload(d_cut, host, n) : download(host, d_cut, n);
     }
+    // streaming ceilings of this box: flat read-only and copy, `bytes` per pass (temporary buffers), best of `reps`
+    int measure_hbm(size_t bytes, int reps, double *readGBs, double *copyGBs) override {
+        RN_CHECK(bytes >= (1u << 20) && reps >= 1 && readGBs && copyGBs, RN_E_ARG, "rn_measure_hbm: bytes >= 1 MiB, reps >= 1");
+        RN_HIP(hipSetDevice(device));
+        void *a = nullptr, *b = nullptr; double *sink = nullptr;
+        RN_HIP(hipMalloc(&a, bytes));
+        if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); err = "rn_measure_hbm: out of memory"; return RN_E_HIP; }
+        if (hipMalloc((void **)&sink, 65536 * sizeof(double)) != hipSuccess) { (void)hipFree(a); (void)hipFree(b); err = "rn_measure_hbm: out of memory"; return RN_E_HIP; }
+        (void)hipMemsetAsync(a, 0, bytes, stream); (void)hipMemsetAsync(b, 0, bytes, stream);
+        const long long n = (long long)(bytes / 16);
+        const int blocks = 256 * 16;
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        double bestR = 0, bestC = 0;
+        for (int r = 0; r < reps + 1; r++) {   // first pass = warm-up
+            float ms = 0;
+            (void)hipEventRecord(e0, stream);
+            hipLaunchKernelGGL(k_bw_read, dim3(blocks), dim3(256), 0, stream, (const nat_d2 *)a, n, sink);
+            (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms > 0) bestR = std::max(bestR, (double)bytes / (ms * 1e-3) / 1e9);
+            (void)hipEventRecord(e0, stream);
+            hipLaunchKernelGGL(k_bw_copy, dim3(blocks), dim3(256), 0, stream, (const nat_d2 *)a, (nat_d2 *)b, n);
+            (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms > 0) bestC = std::max(bestC, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+        RN_HIP(hipGetLastError());
+        *readGBs = bestR; *copyGBs = bestC;
+        return RN_OK;
+    }
+    // read-only probes in the solver's shapes.  shape 0: n workgroups, each streaming its own contiguous pieceBytes
+    // (chunks start strideBytes apart).  shape 1: n persistent workgroups in lockstep, `steps` pieces of pieceBytes per
+    // batch, ceil(total/steps) batches; strideBytes = total bytes to read.
+    int measure_hbm_shape(int shape, size_t pieceBytes, size_t strideBytes, int n, int unroll, int reps, double *readGBs) override {
+        RN_CHECK((shape == 0 || shape == 1) && pieceBytes >= 1024 && pieceBytes % 32 == 0 && n >= 1 && reps >= 1 && readGBs, RN_E_ARG, "rn_measure_hbm_shape: bad argument");
+        RN_HIP(hipSetDevice(device));
+        size_t bytes, alloc; int steps = 0, batches = 0;
+        if (shape == 0) {
+            RN_CHECK(strideBytes >= pieceBytes && strideBytes % 32 == 0, RN_E_ARG, "rn_measure_hbm_shape: stride < chunk");
+            bytes = pieceBytes * (size_t)n; alloc = strideBytes * (size_t)n;
+        } else {
+            RN_CHECK(pieceBytes <= 8192, RN_E_ARG, "rn_measure_hbm_shape: lockstep pieces are at most 8192 B (256 threads x 32 B)");
+            steps = 48;
+            batches = (int)std::max<size_t>(1, strideBytes / (pieceBytes * (size_t)n * steps));
+            bytes = alloc = pieceBytes * (size_t)n * steps * batches;
+        }
+        void *a = nullptr; double *sink = nullptr;
+        RN_HIP(hipMalloc(&a, alloc));
+        if (hipMalloc((void **)&sink, 65536 * sizeof(double)) != hipSuccess) { (void)hipFree(a); err = "rn_measure_hbm_shape: out of memory"; return RN_E_HIP; }
+        (void)hipMemsetAsync(a, 0, alloc, stream);
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        double best = 0;
+        const long long c16 = (long long)(pieceBytes / 16), s16 = (long long)(strideBytes / 16);
+        for (int r = 0; r < reps + 1; r++) {
+            float ms = 0;
+            (void)hipEventRecord(e0, stream);
+            if (shape == 0) {
+                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_chunks<1>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
+                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_chunks<2>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
+                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_chunks<4>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
+                else hipLaunchKernelGGL(k_bw_read_chunks<8>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
+            } else {
+                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_lockstep<1>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
+                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_lockstep<2>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
+                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_lockstep<4>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
+                else hipLaunchKernelGGL(k_bw_read_lockstep<8>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
+            }
+            (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(a); (void)hipFree(sink);
+        RN_HIP(hipGetLastError());
+        *readGBs = best;
+        return RN_OK;
+    }
     int set_operator_mode(int mode) override {
         RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_operator_mode: 0 (dense per-node blocks) or 1 (structured)");
         RN_CHECK(!factored || mode == structured, RN_E_STATE, "rn_set_operator_mode must precede rn_factor_step");
@@ -1191,6 +1290,8 @@ int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, s
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
 int rn_set_exchange_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_exchange_mode(mode); }
+int rn_measure_hbm(rn_ctx *ctx, size_t bytes, int reps, double *r, double *c) { RN_GUARD(ctx); return ctx->impl->measure_hbm(bytes, reps, r, c); }
+int rn_measure_hbm_shape(rn_ctx *ctx, int shape, size_t pb, size_t sb, int n, int u, int reps, double *r) { RN_GUARD(ctx); return ctx->impl->measure_hbm_shape(shape, pb, sb, n, u, reps, r); }
 int rn_set_algorithm(rn_ctx *ctx, int alg, int m) { RN_GUARD(ctx); return ctx->impl->set_algorithm(alg, m); }
 int rn_fbe_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->fbe_reset(); }
 int rn_compute_hessian_oracle(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->hessian_oracle(); }
