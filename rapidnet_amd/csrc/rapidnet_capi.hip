@@ -1177,14 +1177,16 @@ struct Ctx : CtxBase {
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         double best = 0;
         const long long c16 = (long long)(pieceBytes / 16), s16 = (long long)(strideBytes / 16);
+        const char *pe = std::getenv("RAPIDNET_PROBE_LDS");   // occupancy experiments: dynamic LDS bytes per probe workgroup
+        const size_t plds = pe ? (size_t)std::strtoull(pe, nullptr, 10) : 0;
         for (int r = 0; r < reps + 1; r++) {
             float ms = 0;
             (void)hipEventRecord(e0, stream);
             if (shape == 0) {
-                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_chunks<1>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
-                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_chunks<2>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
-                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_chunks<4>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
-                else hipLaunchKernelGGL(k_bw_read_chunks<8>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, c16, s16, sink);
+                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_chunks<1>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
+                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_chunks<2>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
+                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_chunks<4>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
+                else hipLaunchKernelGGL(k_bw_read_chunks<8>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
             } else {
                 if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_lockstep<1>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
                 else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_lockstep<2>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
