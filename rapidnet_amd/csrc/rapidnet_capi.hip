@@ -1231,7 +1231,7 @@ struct Ctx : CtxBase {
 }  // namespace rn
 
 struct rn_ctx { rn::CtxBase *impl; };
-static std::string g_create_error;
+static thread_local std::string g_create_error;   // rn_create failure message of this thread (rn_last_error(NULL))
 
 #define RN_GUARD(ctx) if (!(ctx) || !(ctx)->impl) return RN_E_ARG
 

@@ -32,6 +32,9 @@ CONFIGS = {
     "horizon1": (16, 3, 6, 4, 2, 1, []),
     "horizon2": (17, 3, 6, 4, 2, 2, [3]),
     "fan": (18, 4, 8, 6, 3, 4, [70]),
+    # many inputs, few tanks: 2 nv = 580 rows per operator column (several 16-byte slots per thread in k_stream_gemv) and
+    # shared-operator products too large for the LDS slab kernels (tile-kernel fallback)
+    "tall": (19, 8, 300, 40, 10, 3, [2]),
 }
 
 

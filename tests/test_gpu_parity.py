@@ -177,7 +177,7 @@ def test_soft_constraint_branch():
 # trees that branch in the leading stages and then chain: for late branching, for N = 1 and for trees that branch up to
 # the last stage it indexes before the start of devMatOmega.  The HIP path derives every block from the node's own
 # probability, so for those shapes the oracle is run with the aliasing off (same formulas, per-node blocks).
-EDGE_SHAPES = [("deep", True), ("fan", True), ("late", False), ("horizon1", False), ("horizon2", False)]
+EDGE_SHAPES = [("deep", True), ("fan", True), ("tall", True), ("late", False), ("horizon1", False), ("horizon2", False)]
 
 
 @pytest.mark.parametrize("structured", [False, True])
