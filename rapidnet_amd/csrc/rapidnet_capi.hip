@@ -16,6 +16,9 @@
 #include "../../include/rapidnet.h"
 #include "fbe_kernels.hpp"
 
+#ifndef RN_FIXUP_BLOCKS
+#define RN_FIXUP_BLOCKS 64
+#endif
 #ifndef RN_GEMM_SLAB
 #define RN_GEMM_SLAB 1   // 1: slab kernels (k_gemm_slab / fused k_gemm_vlv); 0: always the tile kernel k_gemm_shared
 #endif
@@ -852,8 +855,10 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_decide_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS,
                                    d_hist, d_histParts, histCap);
                 a.finalizedEarly = 1;
-                if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-                else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+                // the fix-up almost always exits at once: a small grid (grid-stride inside) keeps that launch short
+                const int fixBlocks = std::min(eltBlocks, RN_FIXUP_BLOCKS);
+                if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
+                else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
             }
             prof_end(e3);
             // rotate: y_t := y+_{t-1} (old upd), y+_t := buffer just written; w_{t+1} becomes the sweep input
