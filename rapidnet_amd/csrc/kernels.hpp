@@ -764,13 +764,20 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
 }
 // v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
+// foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
+// owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
 template <typename T>
-__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV) {
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
     T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    if (foldRoot && blockIdx.x == 0) {
+        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();                   // same workgroup reads sk of node 0 back below (same CU, same L1)
+        __syncthreads();
+    }
     const int node0 = blockIdx.x * 16;
     const int cnt = gV.nodes - node0 < 16 ? gV.nodes - node0 : 16;
     slab_load<T>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane);
@@ -791,8 +798,13 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 //   x_i = x_anc + (e_i + B uhat_i) + bw_i,   bw_i = B w_i = bw_anc + (B L) v_i
 // so ONE GEMM gives [L v_i ; B L v_i] and ONE pass over the tree does both recursions (eb_i = e_i + B uhat_i is
 // iteration-invariant, computed with the affine terms).
+// foldCrown: the chain workgroup also walks the crown path above its chain (root -> ... -> parent of the chain top; the
+// crown nodes' inputs lvb / uhat / eb are all available, so this is a handful of independent loads and adds, no
+// dependent round trips) instead of reading u / x / bw of its parent from a crown launch of its own.  The workgroup
+// whose chain is the first descendant of a crown node writes that node's u, x, Hx.
+constexpr int CROWN_MAX_DEPTH = 8;
 template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a) {
+__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, int foldCrown) {
     const int s = blockIdx.x;
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage;
@@ -804,9 +816,44 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a) {
     const T *__restrict__ eb = a.eb;
     const T *__restrict__ dyAll = a.tr.dy;
     const int *__restrict__ cum = a.tr.stageCum;
+    // crown path, leaf-most first: anc[0] = parent of the chain top (stage top-1) ... anc[top-1] = root
+    int anc[CROWN_MAX_DEPTH];
+    bool writer[CROWN_MAX_DEPTH];
+    if (foldCrown) {
+        int n = ntop;
+        bool first = true;
+#pragma unroll
+        for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) {
+            if (dd < top) {
+                const int p = a.tr.parent[n];
+                first = first && (a.tr.childStart[p] == n);
+                anc[dd] = p; writer[dd] = first;
+                n = p;
+            } else { anc[dd] = 0; writer[dd] = false; }
+        }
+    }
     for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
-            T run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+            T run;
+            if (foldCrown) {
+                run = a.prevU[t] - a.prevUhat[t];
+                T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uh[dd] = uhat[(size_t)anc[dd] * nu + t]; }
+#pragma unroll
+                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                    if (dd < top) {
+                        const int k = top - 1 - dd;                       // stage of anc[dd]
+                        const T uv = uh[dd] + run + lv[dd];               // same association as down_crown_node
+                        run = uv - uh[dd];                                 // what a child reads back: u_par - uhat_par
+                        if (writer[dd]) {
+                            const T spc = a.tr.sqrtp[anc[dd]];
+                            a.u[(size_t)anc[dd] * nu + t] = uv;
+                            a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
+                        }
+                    }
+            } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
             for (int k = top; k < a.N; k += CHAIN_PF) {
                 T dv[CHAIN_PF], uh[CHAIN_PF], d0[CHAIN_PF];
 #pragma unroll
@@ -830,8 +877,31 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a) {
             }
         } else {
             const int j0 = t - nu;
-            T bw = par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0];
-            T xr = par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0];
+            T bw, xr;
+            if (foldCrown) {
+                bw = a.bw0[j0]; xr = a.curX[j0];
+                T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; ev[dd] = eb[(size_t)anc[dd] * nx + j0]; }
+#pragma unroll
+                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                    if (dd < top) {
+                        const int k = top - 1 - dd;
+                        bw = bw + lv[dd];
+                        xr = xr + ev[dd] + bw;
+                        if (writer[dd]) {
+                            const T spc = a.tr.sqrtp[anc[dd]];
+                            a.bw[(size_t)anc[dd] * nx + j0] = bw;
+                            a.x[(size_t)anc[dd] * nx + j0] = xr;
+                            a.hx[(size_t)anc[dd] * ny + j0] = spc * dyAll[(size_t)k * ny + j0] * xr;
+                            a.hx[(size_t)anc[dd] * ny + nx + j0] = spc * dyAll[(size_t)k * ny + nx + j0] * xr;
+                        }
+                    }
+            } else {
+                bw = par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0];
+                xr = par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0];
+            }
             for (int k = top; k < a.N; k += CHAIN_PF) {
                 T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
 #pragma unroll

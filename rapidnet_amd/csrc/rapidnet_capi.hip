@@ -19,6 +19,12 @@
 #ifndef RN_FIXUP_BLOCKS
 #define RN_FIXUP_BLOCKS 64
 #endif
+#ifndef RN_FOLD_CROWN_DOWN
+#define RN_FOLD_CROWN_DOWN 1
+#endif
+#ifndef RN_FOLD_ROOT
+#define RN_FOLD_ROOT 1
+#endif
 #ifndef RN_GEMM_SLAB
 #define RN_GEMM_SLAB 1   // 1: slab kernels (k_gemm_slab / fused k_gemm_vlv); 0: always the tile kernel k_gemm_shared
 #endif
@@ -612,8 +618,15 @@ struct Ctx : CtxBase {
         hipLaunchKernelGGL(k_struct_prep<T>, dim3(blocks), dim3(256), 0, stream, a);
         launch_gemm<EPI_LV>(d_BLp, nv, nx + nu, d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0);
     }
+    bool v_lv_is_slab() const {
+#if RN_GEMM_SLAB
+        return (size_t)16 * (slab_stride(pad4(d.nv + d.nx)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024;
+#else
+        return false;
+#endif
+    }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
-    void launch_v_lv() {
+    void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
         GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes};
@@ -622,7 +635,7 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV);
+            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
             return;
         }
 #endif
@@ -673,10 +686,13 @@ struct Ctx : CtxBase {
             RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
             return RN_OK;
         };
+        // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
+        // launch is the slab kernel and stage 0 is neither the whole crown nor the multi-GPU exchange stage
+        const bool foldRoot = RN_FOLD_ROOT && phase == 0 && cs >= 2 && !(a.cutSums && cutStage == 1) && v_lv_is_slab();
         {
             const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
             const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
-            for (int k = cs - 1; k >= 0; k--) {
+            for (int k = cs - 1; k >= (foldRoot ? 1 : 0); k--) {
                 if (phase == 2 && k > cutStage - 1) continue;          // done in phase 1
                 if (a.cutSums && k == cutStage - 1) {
                     if (int rc = all_reduce_cut(k)) return rc;
@@ -686,11 +702,16 @@ struct Ctx : CtxBase {
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
-        launch_v_lv();
+        launch_v_lv(a, foldRoot ? 1 : 0);
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
-        if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
-        else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
-        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch
+        // (not when sharded: a replicated crown node may have no chain on this rank, yet its Hx feeds the replicated duals)
+        const bool foldCrown = RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH && !a.cutSums;
+        if (!foldCrown) {
+            if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
+            else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
+        }
+        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a, foldCrown ? 1 : 0);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
