@@ -801,8 +801,12 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 // foldCrown: the chain workgroup also walks the crown path above its chain (root -> ... -> parent of the chain top; the
 // crown nodes' inputs lvb / uhat / eb are all available, so this is a handful of independent loads and adds, no
 // dependent round trips) instead of reading u / x / bw of its parent from a crown launch of its own.  The workgroup
-// whose chain is the first descendant of a crown node writes that node's u, x, Hx.
+// whose chain is the first descendant of a crown node writes that node's u, x, Hx (foldCrown = 1).  Sharded runs
+// (foldCrown = 2): a replicated crown node may have no chain on this rank, so workgroup 0 writes ALL crown nodes
+// (stage by stage, a few dozen nodes) and the path walks write nothing.
 constexpr int CROWN_MAX_DEPTH = 8;
+template <typename T>
+__device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads);
 template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, int foldCrown) {
     const int s = blockIdx.x;
@@ -827,7 +831,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
             if (dd < top) {
                 const int p = a.tr.parent[n];
                 first = first && (a.tr.childStart[p] == n);
-                anc[dd] = p; writer[dd] = first;
+                anc[dd] = p; writer[dd] = first && foldCrown == 1;
                 n = p;
             } else { anc[dd] = 0; writer[dd] = false; }
         }
@@ -925,6 +929,20 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     }
                 }
             }
+        }
+    }
+    if (foldCrown == 2 && blockIdx.x == 0) {   // all crown nodes, stage after stage (own stores -> barrier -> own loads)
+        const int per = nx + nu;
+        for (int k = 0; k < top; k++) {
+            const int nk = cum[k + 1] - cum[k];
+            const int lanesPerNode = per < CHAIN_THREADS ? ((per + 63) / 64) * 64 : CHAIN_THREADS;
+            const int nodesPerPass = CHAIN_THREADS / lanesPerNode;
+            for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
+                const int pos = p0 + threadIdx.x / lanesPerNode;
+                if (pos < nk && (int)threadIdx.x / lanesPerNode < nodesPerPass) down_crown_node<T>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
+            }
+            __threadfence_block();
+            __syncthreads();
         }
     }
 }

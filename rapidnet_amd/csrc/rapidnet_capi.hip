@@ -704,14 +704,15 @@ struct Ctx : CtxBase {
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
         launch_v_lv(a, foldRoot ? 1 : 0);
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
-        // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch
-        // (not when sharded: a replicated crown node may have no chain on this rank, yet its Hx feeds the replicated duals)
-        const bool foldCrown = RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH && !a.cutSums;
+        // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch.
+        // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
+        // because a replicated crown node may have no chain on this rank while its Hx still feeds the replicated duals
+        const int foldCrown = (RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH) ? (a.cutSums ? (h_stageCum[cs] <= 256 ? 2 : 0) : 1) : 0;
         if (!foldCrown) {
             if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
         }
-        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a, foldCrown ? 1 : 0);
+        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
