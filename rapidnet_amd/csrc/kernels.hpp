@@ -773,6 +773,23 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    // foldRoot = 2 (sharded, crown = root + the exchange stage): the exchange stage's step is just "beta + all-reduced
+    // children sums" per node (presummed); every workgroup does it for the stage-1 nodes of its own slab, workgroup 0 for
+    // all of them (the root needs them) -- identical values, so the overlapping stores are benign.
+    if (foldRoot == 2) {
+        const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
+        const int lo = blockIdx.x == 0 ? s1 : (s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16);
+        const int hi = blockIdx.x == 0 ? e1 : (e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16);
+        for (int node = lo; node < hi; node++) up_crown_node<T>(a, 1, node - s1, threadIdx.x, blockDim.x);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.distTail != nullptr) {   // optimistic exchange: dist^2 of the previous iteration
+            IterState *st = reinterpret_cast<IterState *>(a.iterState);
+            const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
+            st->distX = dX; st->distS = dS;
+            if (dX > a.thrX || dS > a.thrS) st->violated = 1;
+        }
+        if (lo < hi) __threadfence_block();
+        __syncthreads();
+    }
     if (foldRoot && blockIdx.x == 0) {
         up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
         __threadfence_block();                   // same workgroup reads sk of node 0 back below (same CU, same L1)

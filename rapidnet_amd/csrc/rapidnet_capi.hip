@@ -688,7 +688,9 @@ struct Ctx : CtxBase {
         };
         // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
         // launch is the slab kernel and stage 0 is neither the whole crown nor the multi-GPU exchange stage
-        const bool foldRoot = RN_FOLD_ROOT && phase == 0 && cs >= 2 && !(a.cutSums && cutStage == 1) && v_lv_is_slab();
+        // 2: sharded with a two-stage crown whose stage 1 is the exchange stage -- its (presummed) step is folded as well
+        int foldRoot = (RN_FOLD_ROOT && phase == 0 && cs >= 2 && !(a.cutSums && cutStage == 1) && v_lv_is_slab()) ? 1 : 0;
+        if (foldRoot && a.cutSums && cs == 2 && cutStage == 2) foldRoot = 2;
         {
             const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
             const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
@@ -697,12 +699,13 @@ struct Ctx : CtxBase {
                 if (a.cutSums && k == cutStage - 1) {
                     if (int rc = all_reduce_cut(k)) return rc;
                     if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
+                    if (foldRoot == 2) continue;                       // done by the v / Lv launch
                 }
                 hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
-        launch_v_lv(a, foldRoot ? 1 : 0);
+        launch_v_lv(a, foldRoot);
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
         // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch.
         // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
