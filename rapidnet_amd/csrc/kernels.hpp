@@ -1036,6 +1036,10 @@ struct DualArgs {
     int countCrown;
     int finalizedEarly;    // 1: k_decide_finalize already wrote hist[it] and advanced it; the fix-up must redo hist[it-1]
     double *hist, *histParts; int histCap;
+    // regen != 0: the scaled bounds are not read (2 of the 7 streams) but rebuilt as in k_expand_operators,
+    // lo = (sqrt(p_i) d_c) blo_c, hi = (sqrt(p_i) d_c) bhi_c (safety half: bhi_c), from tables that live in L1/L2
+    int regen;
+    const int *stageOf; const T *sqrtp, *dy, *blo, *bhi;
 };
 
 __device__ __forceinline__ void better(double &a, double &v, long long &i, double a2, double v2, long long i2) {
@@ -1084,9 +1088,22 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
     // column index of the first element of this thread's vector, advanced incrementally (no division in the loop)
     int c0 = (int)((gid * VN) % ny);
     const int cstep = (int)((stride * VN) % ny);
+    // node of the first element of this thread's vector, advanced together with the column (regen only)
+    int nd0 = (int)((gid * VN) / ny);
+    const int nstep = (int)((stride * VN) / ny);
     for (long long iv = gid; iv < nvec; iv += stride) {   // 16 bytes per lane per stream
         const VT hx = reinterpret_cast<const VT *>(a.hx)[iv], w = reinterpret_cast<const VT *>(a.w)[iv];
-        const VT lo = reinterpret_cast<const VT *>(a.lo)[iv], hi = reinterpret_cast<const VT *>(a.hi)[iv];
+        VT lo, hi;
+        if (a.regen) {
+            int cc = c0, nn = nd0;
+#pragma unroll
+            for (int e = 0; e < VN; e++) {
+                const T k = a.sqrtp[nn] * a.dy[(size_t)a.stageOf[nn] * ny + cc];
+                lo[e] = k * a.blo[cc];
+                hi[e] = (cc >= nx && cc < 2 * nx) ? a.bhi[cc] : k * a.bhi[cc];
+                if (++cc == ny) { cc = 0; nn++; }
+            }
+        } else { lo = reinterpret_cast<const VT *>(a.lo)[iv]; hi = reinterpret_cast<const VT *>(a.hi)[iv]; }
         const VT yp = reinterpret_cast<const VT *>(a.yprev)[iv];
         VT yn, wn, z, res;
         int c = c0;
@@ -1109,8 +1126,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
         reinterpret_cast<VT *>(a.ynew)[iv] = yn;
         reinterpret_cast<VT *>(a.wnext)[iv] = wn;
         if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[iv] = z; reinterpret_cast<VT *>(a.res)[iv] = res; }
-        c0 += cstep;
-        if (c0 >= ny) c0 -= ny;
+        c0 += cstep; nd0 += nstep;
+        if (c0 >= ny) { c0 -= ny; nd0++; }
     }
     for (long long i = nvec * VN + gid; i < a.n; i += stride) {   // at most VN-1 tail elements
         const int c = (int)(i % ny);

@@ -22,6 +22,9 @@
 #ifndef RN_FOLD_CROWN_DOWN
 #define RN_FOLD_CROWN_DOWN 1
 #endif
+#ifndef RN_DUAL_REGEN
+#define RN_DUAL_REGEN 1
+#endif
 #ifndef RN_FOLD_ROOT
 #define RN_FOLD_ROOT 1
 #endif
@@ -538,7 +541,8 @@ struct Ctx : CtxBase {
         // k_stream_gemv, one launch = the whole tree: A_i (2nv x ny, unpadded) read once + y_i read + m1,m2,a_i written
         const double s = sizeof(T), n = d.nodes;
         if (bwd) *bwd = structured ? 0.0 : n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
-        if (dual) *dual = 7.0 * (double)ntot() * s;
+        // k_dual_fused: Hx, w, y+prev read, y+, w_next written (+ the two scaled-bound streams unless they are regenerated)
+        if (dual) *dual = (RN_DUAL_REGEN ? 5.0 : 7.0) * (double)ntot() * s;
         return RN_OK;
     }
     int synchronize() override { RN_HIP(hipSetDevice(device)); RN_HIP(hipStreamSynchronize(stream)); return RN_OK; }
@@ -731,6 +735,7 @@ struct Ctx : CtxBase {
         a.crownElems = 0; a.countCrown = 1;
         a.finalizedEarly = 0; a.hist = d_hist; a.histParts = d_histParts; a.histCap = histCap;
         if (cutStage > 0) { a.crownElems = h_stageCum[cutStage] * ny; a.countCrown = (rank == 0); }
+        a.regen = RN_DUAL_REGEN; a.stageOf = d_stageOf; a.sqrtp = d_sqrtp; a.dy = d_dy; a.blo = d_blo; a.bhi = d_bhi;
         return a;
     }
     int ensure_tables(int upto) {  // lambda table and history capacity for iterations [0, upto]
