@@ -170,7 +170,7 @@ static int h_inverse(int n, std::vector<double> A, double *Ainv) {  // LU with p
 template <typename T>
 struct Ctx : CtxBase {
     rn_dims d{};
-    int ny = 0, LD = 0, device = 0;
+    int ny = 0, LD = 0, device = 0, numCUs = 256;
     hipStream_t stream = nullptr;
     bool factored = false, affine_ready = false;
     // host copies of the tree and of the shared factors (fp64)
@@ -299,6 +299,7 @@ struct Ctx : CtxBase {
         LD = (2 * d.nv + RPL - 1) / RPL * RPL;
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) numCUs = cu; }
         const int N = d.N, nodes = d.nodes;
         // validate and convert the tree (reference conventions -> 0-based parent/children ranges)
         h_stageCum.assign(tr->nodesPerStageCumul, tr->nodesPerStageCumul + N + 1);
@@ -577,14 +578,15 @@ struct Ctx : CtxBase {
         return RN_OK;
     }
     static int slab_stride(int kp) { return (kp + 59) / 64 * 64 + 4; }   // >= kp, = 4 (mod 64): conflict-free MFMA B reads
-    // waves per slab workgroup: the count in {4, 6, 8} that wastes the least SIMD time on idle tile slots
-    static int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) {
+    // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
+    // time on idle tile slots (throughput).  Few slabs (small or sharded trees: every workgroup has a CU to itself): the
+    // count with the shortest critical path per workgroup (latency).
+    int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) const {
+        const bool few = (d.nodes + 15) / 16 <= numCUs;
         int best = 4; long bestCost = -1;
-#ifdef RN_SLAB_WAVES
-        return RN_SLAB_WAVES;
-#endif
         for (int nw : {4, 6, 8}) {
-            const long cost = (long)nw * ((long)((tilesA + nw - 1) / nw) * kstepsA + (long)((tilesB + nw - 1) / nw) * kstepsB);
+            const long path = (long)((tilesA + nw - 1) / nw) * kstepsA + (long)((tilesB + nw - 1) / nw) * kstepsB;
+            const long cost = few ? path * 16 + nw : (long)nw * path;
             if (bestCost < 0 || cost < bestCost) { best = nw; bestCost = cost; }
         }
         return best;
