@@ -1040,6 +1040,13 @@ struct DualArgs {
     // lo = (sqrt(p_i) d_c) blo_c, hi = (sqrt(p_i) d_c) bhi_c (safety half: bhi_c), from tables that live in L1/L2
     int regen;
     const int *stageOf; const T *sqrtp, *dy, *blo, *bhi;
+    // decideHere (fix-up launch only): the trip decision and the bookkeeping of the iteration are done by THIS launch
+    // instead of a k_decide_finalize launch of their own: every workgroup folds the main pass's dist^2 partials itself
+    // (same order everywhere => same decision), workgroup 0 also folds the arg-max, writes the history entry and advances
+    // the iteration counter.  itHost = iteration index (the host's count; st->it is not read), mainPartials / nMain = the
+    // partials of the main pass; this launch writes its own partials to `partials`.
+    int decideHere, itHost, nMain;
+    const Partial *mainPartials;
 };
 
 __device__ __forceinline__ void better(double &a, double &v, long long &i, double a2, double v2, long long i2) {
@@ -1071,12 +1078,65 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
     constexpr int VN = VecOf<T>::N;
     __shared__ Partial sh_p[ELT_THREADS / 64];
     T scX = 0, scS = 0;
-    if (FIXUP) {
+    if (FIXUP && a.decideHere) {
+        __shared__ double dsx[ELT_THREADS / 64], dss[ELT_THREADS / 64];
+        __shared__ Partial dsh[ELT_THREADS / 64];
+        __shared__ double dec[3];   // tripped, scaleX, scaleS
+        double f2x = 0, f2s = 0, aX = -1, vX = 0, aP = -1, vP = 0;
+        long long iX = 0x7fffffffffffffffLL, iP = 0x7fffffffffffffffLL;
+        for (int b = threadIdx.x; b < a.nMain; b += ELT_THREADS) {
+            const Partial q = a.mainPartials[b];
+            f2x += q.d2x; f2s += q.d2s;
+            if (blockIdx.x == 0) { better(aX, vX, iX, q.absXi, q.valXi, q.idxXi); better(aP, vP, iP, q.absPsi, q.valPsi, q.idxPsi); }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            f2x += __shfl_down(f2x, off); f2s += __shfl_down(f2s, off);
+            if (blockIdx.x == 0) {
+                const double a2 = __shfl_down(aX, off), v2 = __shfl_down(vX, off);
+                const long long i2 = __shfl_down(iX, off);
+                better(aX, vX, iX, a2, v2, i2);
+                const double a3 = __shfl_down(aP, off), v3 = __shfl_down(vP, off);
+                const long long i3 = __shfl_down(iP, off);
+                better(aP, vP, iP, a3, v3, i3);
+            }
+        }
+        if ((threadIdx.x & 63) == 0) { dsx[threadIdx.x >> 6] = f2x; dss[threadIdx.x >> 6] = f2s; dsh[threadIdx.x >> 6] = Partial{0, 0, aX, vX, aP, vP, iX, iP}; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tx2 = dsx[0], ts2 = dss[0];
+            Partial p = dsh[0];
+            for (int k = 1; k < ELT_THREADS / 64; k++) {
+                tx2 += dsx[k]; ts2 += dss[k];
+                better(p.absXi, p.valXi, p.idxXi, dsh[k].absXi, dsh[k].valXi, dsh[k].idxXi);
+                better(p.absPsi, p.valPsi, p.idxPsi, dsh[k].absPsi, dsh[k].valPsi, dsh[k].idxPsi);
+            }
+            const double dX = sqrt(tx2), dS = sqrt(ts2);
+            const bool trX = dX > a.thrX, trS = dS > a.thrS;
+            dec[0] = (trX || trS) ? 1.0 : 0.0;
+            dec[1] = trX ? 1.0 - a.thrX / dX : 0.0;
+            dec[2] = trS ? 1.0 - a.thrS / dS : 0.0;
+            if (blockIdx.x == 0) {
+                a.st->distX = dX; a.st->distS = dS;
+                a.st->tripped = (trX || trS) ? 1 : 0;
+                a.st->scaleX = dec[1]; a.st->scaleS = dec[2];
+                const int it = a.itHost;
+                if (it < a.histCap) {
+                    a.hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
+                    a.histParts[4 * (size_t)it + 0] = p.absXi; a.histParts[4 * (size_t)it + 1] = p.valXi;
+                    a.histParts[4 * (size_t)it + 2] = p.absPsi; a.histParts[4 * (size_t)it + 3] = p.valPsi;
+                }
+                a.st->it = it + 1;
+            }
+        }
+        __syncthreads();
+        if (dec[0] == 0.0) return;   // common case: nothing to redo
+        scX = (T)dec[1]; scS = (T)dec[2];
+    } else if (FIXUP) {
         if (!a.st->tripped) return;   // common case: nothing to redo
         scX = (T)a.st->scaleX; scS = (T)a.st->scaleS;
     }
-    // the fix-up runs after the iteration counter has been advanced (single-GPU path: k_decide_finalize)
-    const int itIdx = (FIXUP && a.finalizedEarly) ? a.st->it - 1 : a.st->it;
+    // the fix-up runs after the iteration counter has been advanced (k_decide_finalize / the decision block above)
+    const int itIdx = a.decideHere ? a.itHost : ((FIXUP && a.finalizedEarly) ? a.st->it - 1 : a.st->it);
     const T ln = (T)a.lamNext[itIdx + 1];
     const T lambda = a.lambda, invLambda = a.invLambda;
     const int nx = a.nx, ny = a.ny;
@@ -1179,7 +1239,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
                     better(aX, vX, iX, q.absXi, q.valXi, q.idxXi);
                     better(aP, vP, iP, q.absPsi, q.valPsi, q.idxPsi);
                 }
-                const int it = a.st->it - 1;
+                const int it = a.decideHere ? a.itHost : a.st->it - 1;
                 if (it >= 0 && it < a.histCap) {
                     a.hist[it] = vX > vP ? vX : vP;
                     a.histParts[4 * (size_t)it + 0] = aX; a.histParts[4 * (size_t)it + 1] = vX;

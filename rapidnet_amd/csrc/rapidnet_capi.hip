@@ -207,7 +207,7 @@ struct Ctx : CtxBase {
     T *p_xi = nullptr, *p_upd = nullptr, *p_acc = nullptr, *p_acc_other = nullptr, *p_acc_view = nullptr;
     bool acc_ready = false;
     IterState *d_state = nullptr;
-    Partial *d_partials = nullptr;
+    Partial *d_partials = nullptr, *d_partials2 = nullptr;   // main pass / fix-up pass
     double *d_lam = nullptr, *d_hist = nullptr, *d_histParts = nullptr, *d_dist2 = nullptr;
     int lamCap = 0, histCap = 0;
     int h_it = 0;
@@ -367,7 +367,7 @@ struct Ctx : CtxBase {
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
         DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
-        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS) DA(d_dist2, 2)
+        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
 #undef DA
         std::vector<double> sq(nodes);
         for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
@@ -883,11 +883,9 @@ struct Ctx : CtxBase {
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
                 hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
-            } else {   // single GPU: decide + finalize in one launch; the (early-exit) fix-up redoes the history if it trips
-                hipLaunchKernelGGL(k_decide_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS,
-                                   d_hist, d_histParts, histCap);
+            } else {   // single GPU: the (small) fix-up launch also decides and does the bookkeeping (kernels.hpp, decideHere)
                 a.finalizedEarly = 1;
-                // the fix-up almost always exits at once: a small grid (grid-stride inside) keeps that launch short
+                a.decideHere = 1; a.itHost = h_it; a.nMain = eltBlocks; a.mainPartials = d_partials; a.partials = d_partials2;
                 const int fixBlocks = std::min(eltBlocks, RN_FIXUP_BLOCKS);
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
