@@ -121,26 +121,46 @@ __global__ void k_fbe_dual_update(T *gPrev, const T *g, T *yPrev, T *y, T *w, co
 
 // the two primal terms of SmpcController::computeValueFbe (SmpcController.cu:1451-1472):
 //   quad = sum_i p_i du_i' W du_i  with du_i = u_i - u_anc(i) (root: u_0 - prevU)   and   lin = sum_i p_i u_i' alpha_i
-// one workgroup per node (grid-stride), du staged in LDS, one row of W du per thread; partials[block][0..1]
+// W (nu x nu, dense in general) is shared by all nodes: a workgroup takes VALUE_TILE nodes at a time, stages their du in
+// LDS and lets thread t accumulate row t of W du for the whole tile, so every element of W fetched from L2 is used
+// VALUE_TILE times (the first version, one node at a time, spent 176 us per call on W loads).  partials[block][0..1]
 constexpr int VALUE_THREADS = 128;
+constexpr int VALUE_TILE = 16;
 template <typename T>
 __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const T *prevU, const int *parent, const T *prob, const T *W,
                                                               const T *alpha, int nu, int nodes, double *partials) {
     extern __shared__ unsigned char fbe_smem[];
-    T *du = reinterpret_cast<T *>(fbe_smem);
+    T *du = reinterpret_cast<T *>(fbe_smem);            // [VALUE_TILE][nu]
     __shared__ double sq[VALUE_THREADS / 64], sl[VALUE_THREADS / 64];
     double quad = 0, lin = 0;
-    for (int node = blockIdx.x; node < nodes; node += gridDim.x) {
-        const int par = parent[node];
-        const T p = prob[node];
-        for (int t = threadIdx.x; t < nu; t += VALUE_THREADS)
-            du[t] = u[(size_t)node * nu + t] - (par < 0 ? prevU[t] : u[(size_t)par * nu + t]);
+    const int tiles = (nodes + VALUE_TILE - 1) / VALUE_TILE;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int n0 = tile * VALUE_TILE;
+        const int cnt = nodes - n0 < VALUE_TILE ? nodes - n0 : VALUE_TILE;
+        for (int i = threadIdx.x; i < VALUE_TILE * nu; i += VALUE_THREADS) {
+            const int n = i / nu, t = i - n * nu;
+            T v = 0;
+            if (n < cnt) {
+                const int node = n0 + n, par = parent[node];
+                const T un = u[(size_t)node * nu + t];
+                v = un - (par < 0 ? prevU[t] : u[(size_t)par * nu + t]);
+                lin += (double)(prob[node] * un) * (double)alpha[(size_t)node * nu + t];
+            }
+            du[i] = v;
+        }
         __syncthreads();
         for (int t = threadIdx.x; t < nu; t += VALUE_THREADS) {
-            T wd = 0;
-            for (int j = 0; j < nu; j++) wd += W[t + (size_t)j * nu] * du[j];
-            quad += (double)(p * du[t]) * (double)wd;
-            lin += (double)(p * u[(size_t)node * nu + t]) * (double)alpha[(size_t)node * nu + t];
+            T wd[VALUE_TILE];
+#pragma unroll
+            for (int n = 0; n < VALUE_TILE; n++) wd[n] = 0;
+            for (int j = 0; j < nu; j++) {
+                const T wtj = W[t + (size_t)j * nu];
+#pragma unroll
+                for (int n = 0; n < VALUE_TILE; n++) wd[n] += wtj * du[n * nu + j];
+            }
+#pragma unroll
+            for (int n = 0; n < VALUE_TILE; n++)
+                if (n < cnt) quad += (double)(prob[n0 + n] * du[n * nu + t]) * (double)wd[n];
         }
         __syncthreads();
     }
