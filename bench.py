@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-only", action="store_true", help="skip the structured-mode pass (tuning sweeps)")
     ap.add_argument("--force-shard", action="store_true", help="debug: run the sharded code path (partition, RCCL communicator, cut all-reduce) even with one rank")
+    ap.add_argument("--emulate-world", type=int, default=0, help="debug/timing only: with one rank, run rank 0's shard of an N-rank partition through the sharded code path (one-rank communicator; iterates are NOT the solution, the other ranks' sums are missing)")
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
     return ap.parse_args()
@@ -86,7 +87,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
-    sharded = world > 1 or args.force_shard
+    sharded = world > 1 or args.force_shard or args.emulate_world > 0
+    # stdout carries exactly ONE line, the JSON: libraries that write to fd 1 on their own (RCCL prints a version banner
+    # when a communicator is created) go to stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if sharded:
         import torch
         import torch.distributed as dist  # rendezvous, barrier and max-over-ranks only; the data path is RCCL in C
@@ -106,7 +112,7 @@ def main():
     tree = problem["tree"]
     if sharded:
         cut_stage = partition.default_cut_stage(problem["tree"])
-        tree, _ = partition.local_tree(problem["tree"], rank, world, cut_stage)
+        tree, _ = partition.local_tree(problem["tree"], rank, args.emulate_world if (world == 1 and args.emulate_world > 0) else world, cut_stage)
     uid = None
     if sharded:
         box = [capi.comm_unique_id() if rank == 0 else None]
@@ -225,6 +231,7 @@ def main():
                 "ms_per_controlStep_500it": head["ms_per_controlStep_500it_derived"],
                 "ms_per_controlStep_500it_measured": head["ms_per_controlStep_500it_measured"],
                 "parallelism": "1 GPU" if not sharded else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
+            "local_nodes": int(tree["nodes"][0]),
             "roofline": roofline, "kernel_classes": classes,
         }
         if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates
@@ -233,7 +240,10 @@ def main():
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.workload, nodes_full)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

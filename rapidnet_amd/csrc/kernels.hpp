@@ -380,6 +380,52 @@ __device__ __forceinline__ void up_crown_node(const SweepArgs<T> &a, int stage, 
         }
     }
 }
+// Exchange stage of a sharded run, nodes [lo, hi) of `stage` (= cutStage - 1): the children sums are the all-reduced
+// payload, so a node is 'beta + payload' -- (node, component) pairs are dealt flat to the threads and the loads of UP_FLAT
+// pairs are requested together (one or two round trips for the whole stage instead of one per node).
+constexpr int UP_FLAT = 3;
+template <typename T>
+__device__ __forceinline__ void up_crown_presummed_flat(const SweepArgs<T> &a, int stage, int lo, int hi, int tid, int nthreads) {
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
+    const int s0 = a.tr.stageCum[stage];
+    const int total = (hi - lo) * per;
+    for (int i0 = tid; i0 < total; i0 += nthreads * UP_FLAT) {
+        T c0[UP_FLAT], c1[UP_FLAT], b0[UP_FLAT], b1[UP_FLAT];
+#pragma unroll
+        for (int u = 0; u < UP_FLAT; u++) {
+            const int i = i0 + u * nthreads;
+            const bool on = i < total;
+            const int node = lo + (on ? i / per : 0), t = on ? i % per : 0, pos = node - s0;
+            if (t < nv) {
+                c0[u] = a.cutSums[(size_t)pos * w + t]; c1[u] = 0;
+                b0[u] = a.beta[(size_t)node * nv + t]; b1[u] = a.my[(size_t)node * 2 * nv + nv + t];
+            } else {
+                const int j0 = t - nv;
+                c0[u] = a.cutSums[(size_t)pos * w + nv + j0]; c1[u] = a.cutSums[(size_t)pos * w + nv + nx + j0];
+                b0[u] = a.qa[(size_t)node * nx + j0]; b1[u] = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UP_FLAT; u++) {
+            const int i = i0 + u * nthreads;
+            if (i < total) {
+                const int node = lo + i / per, t = i % per;
+                if (t < nv) {                                        // same association as up_crown_node
+                    const T sv = b0[u] + c0[u];
+                    const T rho = sv + b1[u];
+                    a.sk[(size_t)node * per + t] = a.structured ? rho : sv;
+                    a.rkq[(size_t)node * w + t] = rho;
+                } else {
+                    const int j0 = t - nv;
+                    const T kap = c0[u] + c1[u];
+                    a.sk[(size_t)node * per + nv + j0] = kap;
+                    a.rkq[(size_t)node * w + nv + j0] = kap;
+                    a.rkq[(size_t)node * w + nv + nx + j0] = c1[u] + b0[u];
+                }
+            }
+        }
+    }
+}
 // one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
 // loads of a node are in flight at once, partial sums are folded through LDS
 template <typename T>
@@ -780,7 +826,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
         const int lo = blockIdx.x == 0 ? s1 : (s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16);
         const int hi = blockIdx.x == 0 ? e1 : (e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16);
-        for (int node = lo; node < hi; node++) up_crown_node<T>(a, 1, node - s1, threadIdx.x, blockDim.x);
+        if (lo < hi) up_crown_presummed_flat<T>(a, 1, lo, hi, threadIdx.x, blockDim.x);
         if (blockIdx.x == 0 && threadIdx.x == 0 && a.distTail != nullptr) {   // optimistic exchange: dist^2 of the previous iteration
             IterState *st = reinterpret_cast<IterState *>(a.iterState);
             const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
@@ -819,8 +865,9 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 // crown nodes' inputs lvb / uhat / eb are all available, so this is a handful of independent loads and adds, no
 // dependent round trips) instead of reading u / x / bw of its parent from a crown launch of its own.  The workgroup
 // whose chain is the first descendant of a crown node writes that node's u, x, Hx (foldCrown = 1).  Sharded runs
-// (foldCrown = 2): a replicated crown node may have no chain on this rank, so workgroup 0 writes ALL crown nodes
-// (stage by stage, a few dozen nodes) and the path walks write nothing.
+// (foldCrown = 2): a replicated crown node may have no chain on this rank, so the crown nodes are dealt round-robin
+// to the workgroups, each of which walks root -> its node once more and writes it; the chain's own path walk writes
+// nothing.  (First version: workgroup 0 wrote all of them stage by stage -- 18 dependent passes, 42 us instead of 20.)
 constexpr int CROWN_MAX_DEPTH = 8;
 template <typename T>
 __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads);
@@ -948,18 +995,48 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
             }
         }
     }
-    if (foldCrown == 2 && blockIdx.x == 0) {   // all crown nodes, stage after stage (own stores -> barrier -> own loads)
-        const int per = nx + nu;
-        for (int k = 0; k < top; k++) {
-            const int nk = cum[k + 1] - cum[k];
-            const int lanesPerNode = per < CHAIN_THREADS ? ((per + 63) / 64) * 64 : CHAIN_THREADS;
-            const int nodesPerPass = CHAIN_THREADS / lanesPerNode;
-            for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
-                const int pos = p0 + threadIdx.x / lanesPerNode;
-                if (pos < nk && (int)threadIdx.x / lanesPerNode < nodesPerPass) down_crown_node<T>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
+    if (foldCrown == 2) {
+        // sharded runs: crown node j is written by workgroup j mod gridDim, which walks root -> j itself (every input
+        // of the path is already there: independent loads, then a short running sum with down_crown_node's association)
+        const int nCrown = cum[top];
+        for (int j = blockIdx.x; j < nCrown; j += gridDim.x) {
+            const int kj = a.tr.stageOf[j];
+            int pth[CROWN_MAX_DEPTH];              // pth[0] = j, pth[kj] = root
+            {
+                int n = j;
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) { pth[dd] = n; if (dd < kj) n = a.tr.parent[n]; }
             }
-            __threadfence_block();
-            __syncthreads();
+            const T spj = a.tr.sqrtp[j];
+            for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
+                if (t < nu) {
+                    T run = a.prevU[t] - a.prevUhat[t];
+                    T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
+#pragma unroll
+                    for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = uhat[(size_t)pth[dd] * nu + t]; }
+                    T uv = 0;
+#pragma unroll
+                    for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                        if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
+                    a.u[(size_t)j * nu + t] = uv;
+                    a.hx[(size_t)j * ny + 2 * nx + t] = spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv;
+                } else {
+                    const int j0 = t - nu;
+                    T bw = a.bw0[j0], xr = a.curX[j0];
+                    T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
+#pragma unroll
+                    for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = eb[(size_t)pth[dd] * nx + j0]; }
+#pragma unroll
+                    for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                        if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
+                    a.bw[(size_t)j * nx + j0] = bw;
+                    a.x[(size_t)j * nx + j0] = xr;
+                    a.hx[(size_t)j * ny + j0] = spj * dyAll[(size_t)kj * ny + j0] * xr;
+                    a.hx[(size_t)j * ny + nx + j0] = spj * dyAll[(size_t)kj * ny + nx + j0] * xr;
+                }
+            }
         }
     }
 }
