@@ -18,7 +18,10 @@ namespace rn {
 
 constexpr int RPL = 4;          // the leading dimension LD of the per-node operator blocks is a multiple of RPL values
 constexpr int ELT_THREADS = 256;
-constexpr int ELT_MAX_BLOCKS = 1024;
+#ifndef RN_ELT_MAX_BLOCKS
+#define RN_ELT_MAX_BLOCKS 1024
+#endif
+constexpr int ELT_MAX_BLOCKS = RN_ELT_MAX_BLOCKS;
 
 template <typename T> struct Vec4 { T v[4]; };
 
@@ -383,7 +386,7 @@ __device__ __forceinline__ void up_crown_node(const SweepArgs<T> &a, int stage, 
 // Exchange stage of a sharded run, nodes [lo, hi) of `stage` (= cutStage - 1): the children sums are the all-reduced
 // payload, so a node is 'beta + payload' -- (node, component) pairs are dealt flat to the threads and the loads of UP_FLAT
 // pairs are requested together (one or two round trips for the whole stage instead of one per node).
-constexpr int UP_FLAT = 3;
+constexpr int UP_FLAT = 6;
 template <typename T>
 __device__ __forceinline__ void up_crown_presummed_flat(const SweepArgs<T> &a, int stage, int lo, int hi, int tid, int nthreads) {
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
@@ -424,6 +427,120 @@ __device__ __forceinline__ void up_crown_presummed_flat(const SweepArgs<T> &a, i
                 }
             }
         }
+    }
+}
+// Sharded runs with a two-stage crown (root + exchange stage): the ROOT's step straight from the exchange stage's inputs,
+// rho_c = (beta_c + payload_c) + m2_c etc. recomputed per child instead of read back -- bitwise the values
+// up_crown_presummed_flat stores, summed in up_crown_node's order -- so that the root does not wait for a store -> barrier
+// -> load round trip behind the exchange stage (both steps cost one batch of independent loads).
+template <typename T>
+__device__ __forceinline__ void up_root_from_presummed(const SweepArgs<T> &a, int tid, int nthreads) {
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
+    const int c0 = a.tr.childStart[0], nc = a.tr.childCount[0], s1 = a.tr.stageCum[1];
+    for (int t = tid; t < per; t += nthreads) {
+        if (t < nv) {
+            T sum = 0;
+            for (int c = 0; c < nc; c += CHAIN_PF) {
+                T cs[CHAIN_PF], bs[CHAIN_PF], ms[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int ch = c0 + (c + j < nc ? c + j : 0);
+                    cs[j] = a.cutSums[(size_t)(ch - s1) * w + t]; bs[j] = a.beta[(size_t)ch * nv + t]; ms[j] = a.my[(size_t)ch * 2 * nv + nv + t];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) if (c + j < nc) sum += (bs[j] + cs[j]) + ms[j];
+            }
+            const T sv = a.beta[t] + sum;
+            const T rho = sv + a.my[nv + t];
+            a.sk[t] = a.structured ? rho : sv;
+            a.rkq[t] = rho;
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int c = 0; c < nc; c += CHAIN_PF) {
+                T ck[CHAIN_PF], cq[CHAIN_PF], qs[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int ch = c0 + (c + j < nc ? c + j : 0);
+                    ck[j] = a.cutSums[(size_t)(ch - s1) * w + nv + j0]; cq[j] = a.cutSums[(size_t)(ch - s1) * w + nv + nx + j0];
+                    qs[j] = a.qa[(size_t)ch * nx + j0];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++)
+                    if (c + j < nc) { const T kc = ck[j] + cq[j], qc = cq[j] + qs[j]; kap += kc + qc; q += qc; }
+            }
+            a.sk[nv + j0] = kap;
+            a.rkq[nv + j0] = kap;
+            a.rkq[nv + nx + j0] = q + a.qa[j0];
+        }
+    }
+}
+// The same two steps (exchange stage + root) by ONE workgroup in one batch of loads: the (child, component) pairs of the
+// root's children are dealt flat to all threads, every child's rho / kappa / q goes to global memory (what
+// up_crown_presummed_flat stores) and to LDS, and after one barrier thread t folds the children's values in ascending
+// order (up_crown_node's association).  sh: nc * (nv + 2 nx) reals.
+template <typename T>
+__device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int tid, int nthreads) {
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
+    const int c0n = a.tr.childStart[0], nc = a.tr.childCount[0], s1 = a.tr.stageCum[1];
+    const int total = nc * per;
+    // the root's own terms, requested with the first batch
+    T rb = 0, rm = 0;
+    if (tid < nv) { rb = a.beta[tid]; rm = a.my[nv + tid]; } else if (tid < per) rb = a.qa[tid - nv];
+    for (int i0 = tid; i0 < total; i0 += nthreads * UP_FLAT) {
+        T c0[UP_FLAT], c1[UP_FLAT], b0[UP_FLAT], b1[UP_FLAT];
+#pragma unroll
+        for (int u = 0; u < UP_FLAT; u++) {
+            const int i = i0 + u * nthreads;
+            const bool on = i < total;
+            const int c = on ? i / per : 0, t = on ? i % per : 0, node = c0n + c, pos = node - s1;
+            if (t < nv) {
+                c0[u] = a.cutSums[(size_t)pos * w + t]; c1[u] = 0;
+                b0[u] = a.beta[(size_t)node * nv + t]; b1[u] = a.my[(size_t)node * 2 * nv + nv + t];
+            } else {
+                const int j0 = t - nv;
+                c0[u] = a.cutSums[(size_t)pos * w + nv + j0]; c1[u] = a.cutSums[(size_t)pos * w + nv + nx + j0];
+                b0[u] = a.qa[(size_t)node * nx + j0]; b1[u] = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UP_FLAT; u++) {
+            const int i = i0 + u * nthreads;
+            if (i < total) {
+                const int c = i / per, t = i % per, node = c0n + c;
+                if (t < nv) {
+                    const T sv = b0[u] + c0[u];
+                    const T rho = sv + b1[u];
+                    a.sk[(size_t)node * per + t] = a.structured ? rho : sv;
+                    a.rkq[(size_t)node * w + t] = rho;
+                    sh[(size_t)c * w + t] = rho;
+                } else {
+                    const int j0 = t - nv;
+                    const T kap = c0[u] + c1[u], q = c1[u] + b0[u];
+                    a.sk[(size_t)node * per + nv + j0] = kap;
+                    a.rkq[(size_t)node * w + nv + j0] = kap;
+                    a.rkq[(size_t)node * w + nv + nx + j0] = q;
+                    sh[(size_t)c * w + nv + j0] = kap + q;
+                    sh[(size_t)c * w + nv + nx + j0] = q;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nv) {
+        T sum = 0;
+        for (int c = 0; c < nc; c++) sum += sh[(size_t)c * w + tid];
+        const T sv = rb + sum;
+        const T rho = sv + rm;
+        a.sk[tid] = a.structured ? rho : sv;
+        a.rkq[tid] = rho;
+    } else if (tid < per) {
+        const int j0 = tid - nv;
+        T kap = 0, q = 0;
+        for (int c = 0; c < nc; c++) { kap += sh[(size_t)c * w + nv + j0]; q += sh[(size_t)c * w + nv + nx + j0]; }
+        a.sk[nv + j0] = kap;
+        a.rkq[nv + j0] = kap;
+        a.rkq[nv + nx + j0] = q + rb;
     }
 }
 // one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
@@ -498,15 +615,34 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_all(SweepArgs<T> a, 
         __syncthreads();
     }
 }
-// multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload)
+// multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload).
+// Optimistic exchange: one more workgroup (blockIdx = number of cut parents, when fin.partials != nullptr) does the
+// bookkeeping of the PREVIOUS iteration's fused dual update -- folds its partials, writes the history entry, advances the
+// iteration counter and puts the rank-local dist^2 into the payload's tail -- which would otherwise be a launch of its own
+// (k_finalize_optimistic) on the critical path of every iteration.
+struct Partial;
+struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; };
 template <typename T>
-__global__ void k_cut_partial_sums(SweepArgs<T> a, T *out) {
+__device__ void finalize_optimistic_body(const Partial *partials, int nblocks, IterState *st, T *tail, double *hist, double *histParts, int histCap);
+constexpr int CUT_THREADS = 256;   // = ELT_THREADS (the bookkeeping block's reduction is written for it)
+template <typename T>
+__global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a, T *out, int nParents, FinArgs fin) {
+    if ((int)blockIdx.x >= nParents) {
+        finalize_optimistic_body<T>(fin.partials, fin.nblocks, fin.st, reinterpret_cast<T *>(fin.tail), fin.hist, fin.histParts, fin.histCap);
+        return;
+    }
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
     const int w = a.nv + 2 * a.nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     for (int t = threadIdx.x; t < w; t += blockDim.x) {
         T s = 0;
-        for (int c = 0; c < nc; c++) s += a.rkq[(size_t)(c0 + c) * w + t];
+        for (int c = 0; c < nc; c += CHAIN_PF) {            // same summation order as one child after the other
+            T r[CHAIN_PF];
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) r[j] = (c + j < nc) ? a.rkq[(size_t)(c0 + c + j) * w + t] : (T)0;
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) if (c + j < nc) s += r[j];
+        }
         out[(size_t)blockIdx.x * w + t] = s;
     }
 }
@@ -643,7 +779,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
 // the workgroup has as many waves as divide the tile count evenly (6 for the 88- and 177-row operators).
 // fp64 note: v_mfma_f64_16x16x4 runs at 1/64 per cycle per SIMD (78 TFLOP/s chip-wide), so these products have an
 // MFMA floor of the same order as their HBM floor (4-5 us each on the 493-scenario tree).
-constexpr int SLAB_MAX_WAVES = 8;
+#ifndef RN_SLAB_MAX_WAVES
+#define RN_SLAB_MAX_WAVES 8
+#endif
+constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #ifndef RN_SLAB_ROTATE
 #define RN_SLAB_ROTATE 1
 #endif
@@ -672,11 +811,10 @@ __device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, 
     }
 }
 // acc[j] = M[tile t0 + j*ts] * slab  for j < TG (tiles past `tiles` recompute tile t0; the caller drops them)
-template <typename T, int TG>
+template <typename T, int TG, int KU>
 __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], const T *M, int mp, int t0, int ts, int tiles, int ksteps,
                                           const T *sB, int SB, int lane) {
     typedef typename Mfma16<T>::acc_t acc_t;
-    constexpr int KU = RN_SLAB_KU;
     const int col = lane & 15, kq = lane >> 4;
     const T *Ap[TG];
 #pragma unroll
@@ -739,17 +877,21 @@ __device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc
         }
     }
 }
-template <typename T, int EPI, int TG>
+template <typename T, int EPI, int TG, int KU>
 __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int SB, int node0, int t0, int nw, int tiles, int ksteps, int lane,
                                           T *sOut, int SO) {
     typename Mfma16<T>::acc_t acc[TG];
     T auxv[TG][4], scale;
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
-    slab_mfma<T, TG>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
+    slab_mfma<T, TG, KU>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
     slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
 }
-template <typename T, int EPI>
-__device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
+// KU = k-steps whose operands a wave requests at once.  Many slabs per CU (whole tree): the L2 operand stream bounds the
+// products and 4 is best; few slabs (sharded or small trees, a workgroup alone on its CU): the dependent round trips of
+// one wave bound them, so the depth is raised (SLAB_KU_DEEP) -- chosen by the host (`deep`).
+constexpr int SLAB_KU_DEEP = 10;
+template <typename T, int EPI, int KU>
+__device__ __forceinline__ void slab_product_ku(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
     const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
     const int per = (tiles + nw - 1) / nw;               // tiles per wave
     const int tg = per >= 3 ? 3 : per;
@@ -762,12 +904,18 @@ __device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, 
     const int owner = wave;
 #endif
     for (int t0 = owner; t0 < tiles; t0 += nw * tg) {
-        if (tg == 3) slab_pass<T, EPI, 3>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
-        else if (tg == 2) slab_pass<T, EPI, 2>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
-        else slab_pass<T, EPI, 1>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        if (tg == 3) slab_pass<T, EPI, 3, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else if (tg == 2) slab_pass<T, EPI, 2, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else slab_pass<T, EPI, 1, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
     }
 }
-template <typename T, int EPI>
+// DEEP is a template parameter of the kernels (two instantiations each): the deep variant needs ~160 VGPRs, which
+// would cost the throughput variant a wave of occupancy if both lived in one kernel
+template <typename T, int EPI, int DEEP>
+__device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
+    slab_product_ku<T, EPI, DEEP ? SLAB_KU_DEEP : RN_SLAB_KU>(g, sB, SB, node0, wave, nw, lane, sOut, SO);
+}
+template <typename T, int EPI, int DEEP>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -777,12 +925,12 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g
     const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
     slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
     __syncthreads();
-    slab_product<T, EPI>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI, DEEP>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // Structured operator mode, first product of the sweep: m2_i = [Bbt | L'] [a_i; b_i] with a_i = F_i' xi_i, b_i = G_i' psi_i
 // (F_i, G_i diagonal).  The slab of [a; b] is built in LDS straight from the duals (what k_struct_prep + a slab load
 // would do in two launches and one HBM round trip); a_i is also written out (the q recursion of k_up_chain needs it).
-template <typename T>
+template <typename T, int DEEP>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T> g, SweepArgs<T> a, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -806,13 +954,20 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
         }
     }
     __syncthreads();
-    slab_product<T, EPI_LV>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI_LV, DEEP>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
-template <typename T>
+// RN_KTIMING builds (tools/ktiming.py): phase stamps of a few workgroups, 100 MHz wall clock, read back by rn_debug_ktiming
+#ifdef RN_KTIMING
+__device__ unsigned long long g_ktiming[8 * 16];
+#define RN_KT(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x == gridDim.x - 1 ? 3 : (int)blockIdx.x; if (b_ < 4) g_ktiming[b_ * 16 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define RN_KT(slot) do { } while (0)
+#endif
+template <typename T, int DEEP>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
@@ -820,35 +975,52 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     // foldRoot = 2 (sharded, crown = root + the exchange stage): the exchange stage's step is just "beta + all-reduced
-    // children sums" per node (presummed); every workgroup does it for the stage-1 nodes of its own slab, workgroup 0 for
-    // all of them (the root needs them) -- identical values, so the overlapping stores are benign.
+    // children sums" per node (presummed); every workgroup does it for the stage-1 nodes of its own slab, and workgroup 0
+    // derives the root's step from the same inputs (up_root_from_presummed).
+    RN_KT(0);
     if (foldRoot == 2) {
         const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
-        const int lo = blockIdx.x == 0 ? s1 : (s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16);
-        const int hi = blockIdx.x == 0 ? e1 : (e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16);
-        if (lo < hi) up_crown_presummed_flat<T>(a, 1, lo, hi, threadIdx.x, blockDim.x);
+        const int lo = s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16;
+        const int hi = e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16;
+        // workgroup 0 does both steps in one batch of loads when the children's values fit in the (still unused) slab
+        // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
+        // has swept the caches and TLBs
+        if (blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
+            up_crown2_wg0<T>(a, sB, threadIdx.x, blockDim.x);
+        } else {
+            if (blockIdx.x == 0) up_root_from_presummed<T>(a, threadIdx.x, blockDim.x);
+            if (lo < hi) up_crown_presummed_flat<T>(a, 1, lo, hi, threadIdx.x, blockDim.x);
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0 && a.distTail != nullptr) {   // optimistic exchange: dist^2 of the previous iteration
             IterState *st = reinterpret_cast<IterState *>(a.iterState);
             const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
             st->distX = dX; st->distS = dS;
             if (dX > a.thrX || dS > a.thrS) st->violated = 1;
         }
-        if (lo < hi) __threadfence_block();
+        if (lo < hi || blockIdx.x == 0) __threadfence_block();   // the workgroup reads its own sk rows back below (same CU, same L1)
         __syncthreads();
     }
-    if (foldRoot && blockIdx.x == 0) {
+    RN_KT(1);
+    if (foldRoot == 1 && blockIdx.x == 0) {
         up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
         __threadfence_block();                   // same workgroup reads sk of node 0 back below (same CU, same L1)
         __syncthreads();
     }
+    RN_KT(2);
     const int node0 = blockIdx.x * 16;
     const int cnt = gV.nodes - node0 < 16 ? gV.nodes - node0 : 16;
     slab_load<T>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane);
     for (int i = threadIdx.x; i < 16 * SV; i += blockDim.x) sV[i] = (T)0;
     __syncthreads();
-    slab_product<T, EPI_V>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
+    RN_KT(3);
+    slab_product<T, EPI_V, DEEP>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
     __syncthreads();
-    slab_product<T, EPI_LV>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+    RN_KT(4);
+    slab_product<T, EPI_LV, DEEP>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+#ifdef RN_KTIMING
+    __syncthreads();
+    RN_KT(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1149,6 +1321,13 @@ __device__ __forceinline__ DualOut<T> dual_elem(T hx, T w, T lo, T hi, T yp, T l
     return o;
 }
 
+#ifndef RN_DUAL_U
+#define RN_DUAL_U 1
+#endif
+#ifndef RN_DUAL_NT
+#define RN_DUAL_NT 0
+#endif
+constexpr int DUAL_U = RN_DUAL_U;
 template <typename T, bool MATERIALIZE, bool FIXUP>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
     typedef typename VecOf<T>::type VT;
@@ -1228,43 +1407,63 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
     // node of the first element of this thread's vector, advanced together with the column (regen only)
     int nd0 = (int)((gid * VN) / ny);
     const int nstep = (int)((stride * VN) / ny);
-    for (long long iv = gid; iv < nvec; iv += stride) {   // 16 bytes per lane per stream
-        const VT hx = reinterpret_cast<const VT *>(a.hx)[iv], w = reinterpret_cast<const VT *>(a.w)[iv];
-        VT lo, hi;
-        if (a.regen) {
-            int cc = c0, nn = nd0;
+    // 16 bytes per lane per stream; DUAL_U grid-stride positions per trip with all their loads requested up front
+    for (long long iv0 = gid; iv0 < nvec; iv0 += (long long)DUAL_U * stride) {
+        VT hxv[DUAL_U], wv[DUAL_U], ypv[DUAL_U];
 #pragma unroll
-            for (int e = 0; e < VN; e++) {
-                const T k = a.sqrtp[nn] * a.dy[(size_t)a.stageOf[nn] * ny + cc];
-                lo[e] = k * a.blo[cc];
-                hi[e] = (cc >= nx && cc < 2 * nx) ? a.bhi[cc] : k * a.bhi[cc];
-                if (++cc == ny) { cc = 0; nn++; }
-            }
-        } else { lo = reinterpret_cast<const VT *>(a.lo)[iv]; hi = reinterpret_cast<const VT *>(a.hi)[iv]; }
-        const VT yp = reinterpret_cast<const VT *>(a.yprev)[iv];
-        VT yn, wn, z, res;
-        int c = c0;
-#pragma unroll
-        for (int e = 0; e < VN; e++) {
-            const bool isBox = c < nx, isXi = c < 2 * nx;
-            const T sc = FIXUP ? (isBox ? scX : (isXi ? scS : (T)0)) : (T)0;
-            const DualOut<T> o = dual_elem<T, FIXUP>(hx[e], w[e], lo[e], hi[e], yp[e], lambda, invLambda, ln, sc);
-            yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
-            const long long i = iv * VN + e;
-            const double dd = (a.countCrown || i >= a.crownElems) ? (double)o.diff * (double)o.diff : 0.0;
-            d2x += isBox ? dd : 0.0;
-            d2s += (isXi && !isBox) ? dd : 0.0;
-            const double ar = fabs((double)o.res);
-            if (isXi) { if (ar > absXi) { absXi = ar; valXi = (double)o.res; idxXi = i; } }
-            else { if (ar > absPsi) { absPsi = ar; valPsi = (double)o.res; idxPsi = i; } }
-            if (++c == ny) c = 0;
+        for (int u = 0; u < DUAL_U; u++) {
+            const long long ivu = iv0 + u * stride;
+            const long long ix = ivu < nvec ? ivu : iv0;
+#if RN_DUAL_NT
+            hxv[u] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(a.hx) + ix);
+            wv[u] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(a.w) + ix);
+            ypv[u] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(a.yprev) + ix);
+#else
+            hxv[u] = reinterpret_cast<const VT *>(a.hx)[ix]; wv[u] = reinterpret_cast<const VT *>(a.w)[ix];
+            ypv[u] = reinterpret_cast<const VT *>(a.yprev)[ix];
+#endif
         }
-        // plain (cached) stores: non-temporal ones make this kernel no faster and the next kernel, which re-reads w, slower
-        reinterpret_cast<VT *>(a.ynew)[iv] = yn;
-        reinterpret_cast<VT *>(a.wnext)[iv] = wn;
-        if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[iv] = z; reinterpret_cast<VT *>(a.res)[iv] = res; }
-        c0 += cstep; nd0 += nstep;
-        if (c0 >= ny) { c0 -= ny; nd0++; }
+#pragma unroll
+        for (int u = 0; u < DUAL_U; u++) {
+            const long long iv = iv0 + u * stride;
+            if (iv < nvec) {
+                const VT hx = hxv[u], w = wv[u], yp = ypv[u];
+                VT lo, hi;
+                if (a.regen) {
+                    int cc = c0, nn = nd0;
+#pragma unroll
+                    for (int e = 0; e < VN; e++) {
+                        const T k = a.sqrtp[nn] * a.dy[(size_t)a.stageOf[nn] * ny + cc];
+                        lo[e] = k * a.blo[cc];
+                        hi[e] = (cc >= nx && cc < 2 * nx) ? a.bhi[cc] : k * a.bhi[cc];
+                        if (++cc == ny) { cc = 0; nn++; }
+                    }
+                } else { lo = reinterpret_cast<const VT *>(a.lo)[iv]; hi = reinterpret_cast<const VT *>(a.hi)[iv]; }
+                VT yn, wn, z, res;
+                int c = c0;
+#pragma unroll
+                for (int e = 0; e < VN; e++) {
+                    const bool isBox = c < nx, isXi = c < 2 * nx;
+                    const T sc = FIXUP ? (isBox ? scX : (isXi ? scS : (T)0)) : (T)0;
+                    const DualOut<T> o = dual_elem<T, FIXUP>(hx[e], w[e], lo[e], hi[e], yp[e], lambda, invLambda, ln, sc);
+                    yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
+                    const long long i = iv * VN + e;
+                    const double dd = (a.countCrown || i >= a.crownElems) ? (double)o.diff * (double)o.diff : 0.0;
+                    d2x += isBox ? dd : 0.0;
+                    d2s += (isXi && !isBox) ? dd : 0.0;
+                    const double ar = fabs((double)o.res);
+                    if (isXi) { if (ar > absXi) { absXi = ar; valXi = (double)o.res; idxXi = i; } }
+                    else { if (ar > absPsi) { absPsi = ar; valPsi = (double)o.res; idxPsi = i; } }
+                    if (++c == ny) c = 0;
+                }
+                // plain (cached) stores: non-temporal ones make this kernel no faster and the next kernel, which re-reads w, slower
+                reinterpret_cast<VT *>(a.ynew)[iv] = yn;
+                reinterpret_cast<VT *>(a.wnext)[iv] = wn;
+                if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[iv] = z; reinterpret_cast<VT *>(a.res)[iv] = res; }
+            }
+            c0 += cstep; nd0 += nstep;
+            if (c0 >= ny) { c0 -= ny; nd0++; }
+        }
     }
     for (long long i = nvec * VN + gid; i < a.n; i += stride) {   // at most VN-1 tail elements
         const int c = (int)(i % ny);
@@ -1405,8 +1604,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials,
 // correction; this kernel folds the block partials, stores the rank-local dist^2 of THIS iteration in the tail of the
 // cut payload (it rides on the NEXT iteration's all-reduce), writes the rank-local history entry and advances `it`.
 template <typename T>
-__global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Partial *partials, int nblocks, IterState *st, T *tail,
-                                                                     double *hist, double *histParts, int histCap) {
+__device__ void finalize_optimistic_body(const Partial *partials, int nblocks, IterState *st, T *tail, double *hist, double *histParts, int histCap) {
     __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
     __shared__ Partial sh[ELT_THREADS / 64];
     double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
@@ -1446,6 +1644,11 @@ __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Parti
         }
         st->it = it + 1;
     }
+}
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Partial *partials, int nblocks, IterState *st, T *tail,
+                                                                     double *hist, double *histParts, int histCap) {
+    finalize_optimistic_body<T>(partials, nblocks, st, tail, hist, histParts, histCap);
 }
 // after the all-reduce: the tail holds the tree-global dist^2 of the previous iteration
 template <typename T>

@@ -192,6 +192,7 @@ struct Ctx : CtxBase {
     T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
     int structured = 0, warmStart = 0;
     int optimistic = 1;      // multi-GPU: 1 = one collective per iteration + verification, 0 = exact two-collective path
+    bool pendingFin = false; // optimistic exchange: the previous iteration's bookkeeping has not been launched yet (it rides in the next k_cut_partial_sums)
     bool carryTail = false;  // the cut payload carries 2 extra reals (rank-local dist^2 of the previous iteration)
     T *d_ck[3] = {nullptr, nullptr, nullptr};   // checkpoint of (y, y+, w) for the exact fallback
     long fallbacks = 0;
@@ -581,10 +582,12 @@ struct Ctx : CtxBase {
     // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
     // time on idle tile slots (throughput).  Few slabs (small or sharded trees: every workgroup has a CU to itself): the
     // count with the shortest critical path per workgroup (latency).
+    int slab_deep() const { return (d.nodes + 15) / 16 <= numCUs ? 1 : 0; }   // few slabs: see SLAB_KU_DEEP
     int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) const {
         const bool few = (d.nodes + 15) / 16 <= numCUs;
         int best = 4; long bestCost = -1;
-        for (int nw : {4, 6, 8}) {
+        for (int nw : {4, 6, 8, 12, 16}) {
+            if (nw > SLAB_MAX_WAVES || (nw > 8 && !few)) continue;
             const long path = (long)((tilesA + nw - 1) / nw) * kstepsA + (long)((tilesB + nw - 1) / nw) * kstepsB;
             const long cost = few ? path * 16 + nw : (long)nw * path;
             if (bestCost < 0 || cost < bestCost) { best = nw; bestCost = cost; }
@@ -599,7 +602,8 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {   // slab kernel (default); falls back to the tile kernel when the slab does not fit
             const int nw = slab_waves((m + 15) / 16, g.kp / 4, 0, 0);
-            hipLaunchKernelGGL((k_gemm_slab<T, EPI>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            if (slab_deep()) hipLaunchKernelGGL((k_gemm_slab<T, EPI, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            else hipLaunchKernelGGL((k_gemm_slab<T, EPI, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
             return;
         }
 #endif
@@ -615,7 +619,8 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
-            hipLaunchKernelGGL(k_gemm_prep_m2<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            if (slab_deep()) hipLaunchKernelGGL((k_gemm_prep_m2<T, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            else hipLaunchKernelGGL((k_gemm_prep_m2<T, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
             return;
         }
 #endif
@@ -641,7 +646,8 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            if (slab_deep()) hipLaunchKernelGGL((k_gemm_vlv<T, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            else hipLaunchKernelGGL((k_gemm_vlv<T, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
             return;
         }
 #endif
@@ -684,7 +690,11 @@ struct Ctx : CtxBase {
         const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
         auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
             if (phase == 2) return RN_OK;              // payload already summed by the caller
-            hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k)), dim3(128), 0, stream, a, d_cut);
+            // optimistic exchange: the bookkeeping of the previous iteration's dual update rides in this launch
+            FinArgs fin{};
+            if (pendingFin) fin = FinArgs{d_partials, eltBlocks, d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap};
+            hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
+            pendingFin = false;
             if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
             const int rc = g_nccl.AllReduce(d_cut, d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
@@ -811,16 +821,20 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            if (int rc = launch_sweep()) { carryTail = false; return rc; }
+            if (int rc = launch_sweep()) { carryTail = false; pendingFin = false; return rc; }
             DualArgs<T> a = dual_args();
             const hipEvent_t *e2 = prof_begin(2);
             if (k == n - 1) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             prof_end(e2);
-            const hipEvent_t *e3 = prof_begin(3);
-            hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_cut + tail,
-                               d_hist, d_histParts, histCap);
-            prof_end(e3);
+            // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
+            // batch gets a launch of its own
+            if (k == n - 1) {
+                const hipEvent_t *e3 = prof_begin(3);
+                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_cut + tail,
+                                   d_hist, d_histParts, histCap);
+                prof_end(e3);
+            } else pendingFin = true;
             std::swap(p_xi, p_upd);
             p_acc_view = p_acc;
             std::swap(p_acc, p_acc_other);
@@ -1345,3 +1359,10 @@ int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->im
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
 
 }  // extern "C"
+
+#ifdef RN_KTIMING
+// debug builds only (not part of include/rapidnet.h): phase stamps of the instrumented kernels, 8 workgroups x 16 slots
+extern "C" int rn_debug_ktiming(unsigned long long *out128) {
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rn::g_ktiming), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : 1;
+}
+#endif
