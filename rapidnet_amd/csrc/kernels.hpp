@@ -128,21 +128,28 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 // block reaches 6.7-6.8 TB/s on MI355X when every wave-load is 64 lanes x 16 B = 1 KB CONTIGUOUS, and only 5.9 TB/s
 // when a lane fetches 32 adjacent bytes as two loads (each wave-load then touches 16 cache lines and uses half of
 // each) -- which is what "4 fp64 rows per lane" amounts to.  So the block is walked in 16-byte SLOTS: a column of A_i
-// (LD values) is SPC = LD*sizeof(T)/16 slots, a SPAN is G consecutive columns, and thread t owns slots t, t+256, ...
+// (LD values) is SPC = LD*sizeof(T)/16 slots, a SPAN is G consecutive columns, and thread t owns slots t, t+512, ...
 // (NL of them) of every span: consecutive threads read consecutive 16 B, across column boundaries, and each thread always
-// meets the same rows, so its partial sums stay in registers.  G is chosen on the host so that a span nearly fills a
-// multiple of 256 slots (493-scenario tree, fp64: SPC = 98, G = 5 -> 490 of 512 slots, every lane busy in 96 % of the
-// loads).  Loads are non-temporal (A is read once per iteration and is far larger than the 256 MiB Infinity Cache) and
-// double-buffered in groups of D spans.  Also emits a_i = F_i' xi_i (F_i is diagonal: Utilities.cu:33-58).
+// meets the same rows, so its partial sums stay in registers.  G is chosen on the host (Ctx::stream_shape) so that a
+// span is a whole number of 128-byte lines: with spans that end inside a line (first version: G = 5, 490 of 512 slots
+// busy) the two wave-loads sharing that line are issued a group apart and the non-temporal stream fetches it twice --
+// FETCH_SIZE showed 4.35 GB per launch against 4.09 GB algorithmic; with G = 8 (784 slots = 98 lines, NL = 2, 77 % of
+// the lanes busy) it is 4.14 GB and the kernel 6 % faster.  Loads are non-temporal (A is read once per iteration and is
+// far larger than the 256 MiB Infinity Cache) and double-buffered in groups of D spans (one 8-wave workgroup per CU
+// with 10 x 16 B per lane in flight measured best: 512 threads, D = 5).  Also emits a_i = F_i' xi_i (F_i is diagonal:
+// Utilities.cu:33-58).
 // HBM bytes per node: LD*ny*sizeof(T) + (ny + 2nv + nx)*sizeof(T).
 #ifndef RN_STREAM_THREADS
-#define RN_STREAM_THREADS 256
+#define RN_STREAM_THREADS 512
 #endif
 #ifndef RN_STREAM_D
-#define RN_STREAM_D 4
+#define RN_STREAM_D 5
+#endif
+#ifndef RN_STREAM_D_WIDE
+#define RN_STREAM_D_WIDE 3     // spans of a group when a thread owns 3 or 4 slots per span (register budget)
 #endif
 #ifndef RN_STREAM_MINW
-#define RN_STREAM_MINW 3
+#define RN_STREAM_MINW 2
 #endif
 constexpr int STREAM_THREADS = RN_STREAM_THREADS;
 constexpr int STREAM_NLMAX = 4;   // slots per thread and span
@@ -154,7 +161,7 @@ template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4
 template <typename T, int NL>
 __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G) {
     typedef typename Slot<T>::type VT;
-    constexpr int VPL = Slot<T>::N, D = RN_STREAM_D;
+    constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny (+ G of zero padding is not needed: guarded reads)
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
@@ -877,21 +884,28 @@ __device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc
         }
     }
 }
+// RN_KTIMING builds (tools/ktiming.py): phase stamps of a few workgroups, 100 MHz wall clock, read back by rn_debug_ktiming
+#ifdef RN_KTIMING
+__device__ unsigned long long g_ktiming[8 * 16];
+#define RN_KT(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x == gridDim.x - 1 ? 3 : (int)blockIdx.x; if (b_ < 4) g_ktiming[b_ * 16 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define RN_KT(slot) do { } while (0)
+#endif
 template <typename T, int EPI, int TG, int KU>
 __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int SB, int node0, int t0, int nw, int tiles, int ksteps, int lane,
                                           T *sOut, int SO) {
     typename Mfma16<T>::acc_t acc[TG];
     T auxv[TG][4], scale;
+    RN_KT(EPI == EPI_V ? 6 : 10);
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
+    RN_KT(EPI == EPI_V ? 7 : 11);
     slab_mfma<T, TG, KU>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
+    RN_KT(EPI == EPI_V ? 8 : 12);
     slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
+    RN_KT(EPI == EPI_V ? 9 : 13);
 }
-// KU = k-steps whose operands a wave requests at once.  Many slabs per CU (whole tree): the L2 operand stream bounds the
-// products and 4 is best; few slabs (sharded or small trees, a workgroup alone on its CU): the dependent round trips of
-// one wave bound them, so the depth is raised (SLAB_KU_DEEP) -- chosen by the host (`deep`).
-constexpr int SLAB_KU_DEEP = 10;
-template <typename T, int EPI, int KU>
-__device__ __forceinline__ void slab_product_ku(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
+template <typename T, int EPI>
+__device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
     const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
     const int per = (tiles + nw - 1) / nw;               // tiles per wave
     const int tg = per >= 3 ? 3 : per;
@@ -903,19 +917,14 @@ __device__ __forceinline__ void slab_product_ku(const GemmArgs<T> &g, const T *s
 #else
     const int owner = wave;
 #endif
+    constexpr int KU = RN_SLAB_KU;
     for (int t0 = owner; t0 < tiles; t0 += nw * tg) {
         if (tg == 3) slab_pass<T, EPI, 3, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
         else if (tg == 2) slab_pass<T, EPI, 2, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
         else slab_pass<T, EPI, 1, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
     }
 }
-// DEEP is a template parameter of the kernels (two instantiations each): the deep variant needs ~160 VGPRs, which
-// would cost the throughput variant a wave of occupancy if both lived in one kernel
-template <typename T, int EPI, int DEEP>
-__device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
-    slab_product_ku<T, EPI, DEEP ? SLAB_KU_DEEP : RN_SLAB_KU>(g, sB, SB, node0, wave, nw, lane, sOut, SO);
-}
-template <typename T, int EPI, int DEEP>
+template <typename T, int EPI>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -925,12 +934,12 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g
     const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
     slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
     __syncthreads();
-    slab_product<T, EPI, DEEP>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // Structured operator mode, first product of the sweep: m2_i = [Bbt | L'] [a_i; b_i] with a_i = F_i' xi_i, b_i = G_i' psi_i
 // (F_i, G_i diagonal).  The slab of [a; b] is built in LDS straight from the duals (what k_struct_prep + a slab load
 // would do in two launches and one HBM round trip); a_i is also written out (the q recursion of k_up_chain needs it).
-template <typename T, int DEEP>
+template <typename T>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T> g, SweepArgs<T> a, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -954,20 +963,13 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
         }
     }
     __syncthreads();
-    slab_product<T, EPI_LV, DEEP>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI_LV>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
-// RN_KTIMING builds (tools/ktiming.py): phase stamps of a few workgroups, 100 MHz wall clock, read back by rn_debug_ktiming
-#ifdef RN_KTIMING
-__device__ unsigned long long g_ktiming[8 * 16];
-#define RN_KT(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x == gridDim.x - 1 ? 3 : (int)blockIdx.x; if (b_ < 4) g_ktiming[b_ * 16 + (slot)] = wall_clock64(); } } while (0)
-#else
-#define RN_KT(slot) do { } while (0)
-#endif
-template <typename T, int DEEP>
+template <typename T>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
@@ -1013,10 +1015,10 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     for (int i = threadIdx.x; i < 16 * SV; i += blockDim.x) sV[i] = (T)0;
     __syncthreads();
     RN_KT(3);
-    slab_product<T, EPI_V, DEEP>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
+    slab_product<T, EPI_V>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
     __syncthreads();
     RN_KT(4);
-    slab_product<T, EPI_LV, DEEP>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI_LV>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
 #ifdef RN_KTIMING
     __syncthreads();
     RN_KT(5);

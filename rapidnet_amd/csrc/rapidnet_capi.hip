@@ -551,17 +551,28 @@ struct Ctx : CtxBase {
     void *stream_handle() override { return (void *)stream; }
 
     // ---- the sweep ---------------------------------------------------------------------------------------
-    // span of the streaming kernel: G columns = G*SPC 16-byte slots, NL slots per thread; the G that fills a multiple of
-    // STREAM_THREADS slots best (see k_stream_gemv)
+    // span of the streaming kernel: G columns = G*SPC 16-byte slots, NL slots per thread.  Preferred: spans that are whole
+    // 128-byte lines (G*SPC*16 % 128 == 0) -- otherwise every span boundary splits a cache line between two wave-loads
+    // that are issued at different times, and the non-temporal stream fetches that line twice (measured with
+    // FETCH_SIZE: 4.35 GB per launch with G = 5, 4.14 GB with G = 8 on the 493-scenario tree, 6 % of the kernel's time)
+    // -- with at most 2 slots per thread, then the best lane utilisation, then the larger span.  Without a line-aligned
+    // candidate: the G that fills a multiple of STREAM_THREADS slots best.
     void stream_shape(int *G, int *NL) const {
         const int SPC = LD * (int)sizeof(T) / 16;
-        int bestG = 1, bestNL = (SPC + STREAM_THREADS - 1) / STREAM_THREADS; double bestU = -1;
+        int bestG = 0, bestNL = 0, bestClass = -1; double bestU = -1;
         for (int g = 1; g <= std::min(ny, 64); g++) {
             const int slots = g * SPC, nl = (slots + STREAM_THREADS - 1) / STREAM_THREADS;
             if (nl > STREAM_NLMAX) break;
+            const bool aligned = ((long long)slots * 16) % 128 == 0;
+            const int cls = aligned ? (nl <= 2 ? 2 : 1) : 0;
             const double u = (double)slots / ((double)nl * STREAM_THREADS);
-            if (u > bestU + 1e-9) { bestU = u; bestG = g; bestNL = nl; }
+            const bool tie = std::fabs(u - bestU) <= 1e-9;
+            if (cls > bestClass || (cls == bestClass && (u > bestU + 1e-9 || (tie && cls > 0)))) { bestClass = cls; bestU = u; bestG = g; bestNL = nl; }
         }
+        if (bestG == 0) { bestG = 1; bestNL = (SPC + STREAM_THREADS - 1) / STREAM_THREADS; }
+#ifdef RN_STREAM_G   // tuning builds: force the span
+        bestG = RN_STREAM_G; bestNL = (bestG * SPC + STREAM_THREADS - 1) / STREAM_THREADS;
+#endif
         *G = bestG; *NL = bestNL;
     }
     size_t stream_lds(int G) const { return (size_t)(((ny + 3) & ~3) + (size_t)G * LD) * sizeof(T); }
@@ -582,7 +593,6 @@ struct Ctx : CtxBase {
     // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
     // time on idle tile slots (throughput).  Few slabs (small or sharded trees: every workgroup has a CU to itself): the
     // count with the shortest critical path per workgroup (latency).
-    int slab_deep() const { return (d.nodes + 15) / 16 <= numCUs ? 1 : 0; }   // few slabs: see SLAB_KU_DEEP
     int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) const {
         const bool few = (d.nodes + 15) / 16 <= numCUs;
         int best = 4; long bestCost = -1;
@@ -602,8 +612,7 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {   // slab kernel (default); falls back to the tile kernel when the slab does not fit
             const int nw = slab_waves((m + 15) / 16, g.kp / 4, 0, 0);
-            if (slab_deep()) hipLaunchKernelGGL((k_gemm_slab<T, EPI, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
-            else hipLaunchKernelGGL((k_gemm_slab<T, EPI, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            hipLaunchKernelGGL((k_gemm_slab<T, EPI>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
             return;
         }
 #endif
@@ -619,8 +628,7 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
-            if (slab_deep()) hipLaunchKernelGGL((k_gemm_prep_m2<T, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
-            else hipLaunchKernelGGL((k_gemm_prep_m2<T, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            hipLaunchKernelGGL(k_gemm_prep_m2<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
             return;
         }
 #endif
@@ -646,8 +654,7 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            if (slab_deep()) hipLaunchKernelGGL((k_gemm_vlv<T, 1>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
-            else hipLaunchKernelGGL((k_gemm_vlv<T, 0>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
             return;
         }
 #endif

@@ -20,6 +20,7 @@ CONFIGS = {
     "barcelona31": (1, 63, 114, 88, 17, 24, [31]),       # configs[1]: K=31, nodes=714
     "barcelona493": (2, 63, 114, 88, 17, 24, [17, 29]),  # configs[2]/[3]: K=493, nodes=10864 (headline)
     "wide4096": (4, 200, 360, 280, 54, 24, [16, 16, 16]),  # configs[4]: K=4096, nodes=86289
+    "wide256": (4, 200, 360, 280, 54, 24, [16, 16]),     # the wide network on a 256-scenario tree (10 GB of blocks in fp32): tuning probe
     # small shapes for parity tests
     "tiny": (10, 3, 6, 4, 2, 6, [2, 2]),
     "small": (11, 5, 9, 6, 3, 8, [3, 2, 2]),

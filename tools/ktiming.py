@@ -43,4 +43,8 @@ for b, name in enumerate(("wg0", "wg1", "wg2", "last")):
     print("%-5s start +%6.2f us | phases (us):" % (name, (row[0] - base) / 100.0), " ".join("%6.2f" % ((row[i + 1] - row[i]) / 100.0) for i in range(5)),
           "| total %6.2f" % ((row[5] - row[0]) / 100.0))
 print("phases: exchange-stage step | root step | slab load | product v | product [Lv;BLv]")
+for b, name in enumerate(("wg0", "wg1", "wg2", "last")):
+    r = t[b]
+    print("%-5s wave 0, product v: aux issue %5.2f  mfma loop %5.2f  epilogue %5.2f | product Lv: aux %5.2f  mfma loop %5.2f  epilogue %5.2f   (last pass of the wave)" % (
+        name, (r[7] - r[6]) / 100, (r[8] - r[7]) / 100, (r[9] - r[8]) / 100, (r[11] - r[10]) / 100, (r[12] - r[11]) / 100, (r[13] - r[12]) / 100))
 s.close()
