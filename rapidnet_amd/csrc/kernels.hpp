@@ -1,9 +1,9 @@
 // kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the APG solve path.
 //
 // Data layout in HBM (T = float | double), chosen for coalesced 16-byte-per-lane streaming:
-//   A      [node][ny][LD]   per-node operator block: column c (c indexes y = [xi_box | xi_safe | psi]) holds
+//   A      [node][ny][LD]   per-node operator block (node stride padded to whole 128-byte lines): column c (c indexes y = [xi_box | xi_safe | psi]) holds
 //                           rows 0..nv-1 = [Phi_i | Psi_i](:,c)  and rows nv..2nv-1 = [D_i | Ftil_i](:,c),
-//                           zero padded to LD = roundup(2nv, 4).  One pass over A_i yields both mat-vecs of
+//                           zero padded to whole 16-byte slots (fp64: LD = 2nv).  One pass over A_i yields both mat-vecs of
 //                           SmpcController::solveStep's backward sweep (SmpcController.cu:617-638).
 //   y-like [node][ny]       dual vectors, ny = 2nx+nu: xi (2nx) and psi (nu) of a node are adjacent.
 //   x,u,v,q,rt,beta,uhat,e  [node][dim], nodes numbered breadth-first so a stage is one contiguous slab.
@@ -16,7 +16,6 @@
 
 namespace rn {
 
-constexpr int RPL = 4;          // the leading dimension LD of the per-node operator blocks is a multiple of RPL values
 constexpr int ELT_THREADS = 256;
 #ifndef RN_ELT_MAX_BLOCKS
 #define RN_ELT_MAX_BLOCKS 1024
@@ -49,6 +48,7 @@ template <typename T>
 struct SweepArgs {
     TreeDev<T> tr;
     int nx, nu, nv, ny, LD, N, nodes;
+    size_t strideA;   // values between consecutive nodes' blocks in A
     int chainStage;   // c*: first stage from which the tree is K parallel chains (no branching at or after it)
     int K;            // nodes per stage in the chain region
     const T *A;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     const int nx = a.nx, nv = a.nv, ny = a.ny, LD = a.LD;
     const int SPC = LD / VPL, spanSlots = G * SPC;
     const long long blockSlots = (long long)ny * SPC;
-    const VT *__restrict__ Ab = reinterpret_cast<const VT *>(a.A + (size_t)node * ny * LD);
+    const VT *__restrict__ Ab = reinterpret_cast<const VT *>(a.A + (size_t)node * a.strideA);
     int off[NL], cj[NL];
     T msk[NL];
 #pragma unroll
@@ -1883,6 +1883,7 @@ template <typename T>
 struct ExpandArgs {
     TreeDev<T> tr;
     int nx, nu, nv, ny, LD, nodes;
+    size_t strideA;
     const T *T1, *T2, *Bbt, *Lt;
     T *A;
     // scaled bounds in y order
@@ -1903,7 +1904,7 @@ __global__ void k_expand_operators(ExpandArgs<T> a) {
         if (c < 2 * a.nx) { const int j = c % a.nx; m1 = a.T1 + (size_t)j * a.nv; m2 = a.Bbt + (size_t)j * a.nv; }
         else { const int j = c - 2 * a.nx; m1 = a.T2 + (size_t)j * a.nv; m2 = a.Lt + (size_t)j * a.nv; }
         if (!a.skipBlocks) {
-            T *col = a.A + ((size_t)node * a.ny + c) * a.LD;
+            T *col = a.A + (size_t)node * a.strideA + (size_t)c * a.LD;
             for (int r = threadIdx.x; r < a.LD; r += blockDim.x)
                 col[r] = r < a.nv ? s1 * m1[r] : (r < 2 * a.nv ? s2 * m2[r - a.nv] : (T)0);
         }

@@ -171,6 +171,7 @@ template <typename T>
 struct Ctx : CtxBase {
     rn_dims d{};
     int ny = 0, LD = 0, device = 0, numCUs = 256;
+    size_t strideA = 0;      // values between the operator blocks of consecutive nodes (>= ny * LD, whole cache lines)
     hipStream_t stream = nullptr;
     bool factored = false, affine_ready = false;
     // host copies of the tree and of the shared factors (fp64)
@@ -276,7 +277,7 @@ struct Ctx : CtxBase {
     SweepArgs<T> sweep_args() const {
         SweepArgs<T> a{};
         a.tr = tree_dev();
-        a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD; a.N = d.N; a.nodes = d.nodes;
+        a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD; a.strideA = strideA; a.N = d.N; a.nodes = d.nodes;
         a.cutSums = (cutStage > 0) ? d_cut : nullptr;
         a.cutStage = cutStage;
         a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
@@ -297,7 +298,12 @@ struct Ctx : CtxBase {
         RN_CHECK(d.nx > 0 && d.nu > 0 && d.nv > 0 && d.nd > 0 && d.N > 0 && d.K > 0 && d.nodes > 0, RN_E_ARG, "rn_create: non-positive dimension");
         RN_CHECK(d.nv <= d.nu, RN_E_ARG, "rn_create: nv must not exceed nu");
         ny = 2 * d.nx + d.nu;
-        LD = (2 * d.nv + RPL - 1) / RPL * RPL;
+        {   // columns are whole 16-byte slots, node blocks whole 128-byte lines (k_stream_gemv walks a block in slots and
+            // its spans are only line-aligned if the block is)
+            const int vps = 16 / (int)sizeof(T), vpl = 128 / (int)sizeof(T);
+            LD = (2 * d.nv + vps - 1) / vps * vps;
+            strideA = ((size_t)ny * LD + vpl - 1) / vpl * vpl;
+        }
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) numCUs = cu; }
@@ -447,11 +453,11 @@ struct Ctx : CtxBase {
         UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
 #undef UP
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
-            if (int rc = dalloc(&d_A, (size_t)d.nodes * ny * LD)) return rc;
+            if (int rc = dalloc(&d_A, (size_t)d.nodes * strideA)) return rc;
         }
         RN_HIP(hipMemsetAsync(d_my, 0, (size_t)d.nodes * 2 * nv * sizeof(T), stream));   // structured mode never writes m1
         ExpandArgs<T> ea{};
-        ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.nodes = d.nodes;
+        ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.strideA = strideA; ea.nodes = d.nodes;
         ea.T1 = d_T1; ea.T2 = d_T2; ea.Bbt = d_Bbt; ea.Lt = d_Lt; ea.A = d_A; ea.skipBlocks = structured; ea.blo = d_blo; ea.bhi = d_bhi; ea.lo = d_lo; ea.hi = d_hi;
         const int colChunks = std::min(ny, 8);
         hipLaunchKernelGGL(k_expand_operators<T>, dim3(d.nodes, colChunks), dim3(LD >= 192 ? 256 : (LD >= 96 ? 128 : 64)), 0, stream, ea);
@@ -1147,7 +1153,7 @@ struct Ctx : CtxBase {
             return RN_OK;
         }
         std::vector<double> blk((size_t)ny * LD);
-        if (int rc = download(blk.data(), d_A + (size_t)node * ny * LD, (size_t)ny * LD)) return rc;
+        if (int rc = download(blk.data(), d_A + (size_t)node * strideA, (size_t)ny * LD)) return rc;
         for (int c = 0; c < cols; c++) for (int r = 0; r < nv; r++) host[r + (size_t)c * nv] = blk[(size_t)(c0 + c) * LD + r0 + r];
         return RN_OK;
     }
