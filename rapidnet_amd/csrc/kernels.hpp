@@ -1653,11 +1653,15 @@ __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Parti
     finalize_optimistic_body<T>(partials, nblocks, st, tail, hist, histParts, histCap);
 }
 // after the all-reduce: the tail holds the tree-global dist^2 of the previous iteration
+// vote != nullptr: the rank's verdict for the whole batch (1 = a threshold was exceeded somewhere) is left there for one
+// more sum all-reduce, so that every rank takes the same replay decision even if an all-reduce algorithm ever delivered
+// results that differ in the last bit between ranks (a rank replaying alone would wait for collectives nobody else issues)
 template <typename T>
-__global__ void k_check_dist(const T *tail, IterState *st, double thrX, double thrS) {
+__global__ void k_check_dist(T *tail, IterState *st, double thrX, double thrS, T *vote) {
     const double dX = sqrt((double)tail[0]), dS = sqrt((double)tail[1]);
     st->distX = dX; st->distS = dS;
     if (dX > thrX || dS > thrS) st->violated = 1;
+    if (vote) *vote = st->violated ? (T)1 : (T)0;
 }
 
 // multi-GPU variant of k_decide: fold the local partials to (d2x, d2s), all-reduce those two numbers, then decide

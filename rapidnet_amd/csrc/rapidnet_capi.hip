@@ -857,12 +857,19 @@ struct Ctx : CtxBase {
         if (n > 0) {   // the last iteration's distances: one 2-element all-reduce per BATCH
             const int rc = g_nccl.AllReduce(d_cut + tail, d_cut + tail, 2, sizeof(T) == 8 ? 8 : 7, 0, comm, stream);
             RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist tail) failed");
-            hipLaunchKernelGGL(k_check_dist<T>, dim3(1), dim3(1), 0, stream, d_cut + tail, d_state, penX / stepSize, penXs / stepSize);
+            // the ranks agree on the verdict (sum of the per-rank flags): one more 1-element all-reduce per BATCH
+            hipLaunchKernelGGL(k_check_dist<T>, dim3(1), dim3(1), 0, stream, d_cut + tail, d_state, penX / stepSize, penXs / stepSize, d_cut + tail);
+            const int rc2 = g_nccl.AllReduce(d_cut + tail, d_cut + tail, 1, sizeof(T) == 8 ? 8 : 7, 0, comm, stream);
+            RN_CHECK(rc2 == 0, RN_E_COMM, "ncclAllReduce(verdict) failed");
         }
         RN_HIP(hipGetLastError());
         int violated = 0;
-        RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
-        RN_HIP(hipStreamSynchronize(stream));
+        if (n > 0) {
+            T votes = 0;
+            RN_HIP(hipMemcpyAsync(&votes, d_cut + tail, sizeof(T), hipMemcpyDeviceToHost, stream));
+            RN_HIP(hipStreamSynchronize(stream));
+            violated = votes > (T)0 ? 1 : 0;
+        } else RN_HIP(hipStreamSynchronize(stream));
         if (violated) {   // replay the batch exactly
             fallbacks++;
             p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
