@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--dense-only", action="store_true", help="skip the structured-mode pass (tuning sweeps)")
     ap.add_argument("--force-shard", action="store_true", help="debug: run the sharded code path (partition, RCCL communicator, cut all-reduce) even with one rank")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug/timing only: with one rank, run rank 0's shard of an N-rank partition through the sharded code path (one-rank communicator; iterates are NOT the solution, the other ranks' sums are missing)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"], help="sharded runs: 'rccl' = the library's own ncclAllReduce on the solver's stream (default); 'torch' = step-wise fallback, the cut payload is all-reduced through torch.distributed (slow; used automatically if the library's communicator cannot be created)")
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
     return ap.parse_args()
@@ -113,19 +114,66 @@ def main():
     if sharded:
         cut_stage = partition.default_cut_stage(problem["tree"])
         tree, _ = partition.local_tree(problem["tree"], rank, args.emulate_world if (world == 1 and args.emulate_world > 0) else world, cut_stage)
-    uid = None
+    uid, uid_error = None, ""
     if sharded:
-        box = [capi.comm_unique_id() if rank == 0 else None]
+        box = [None, ""]
+        if rank == 0 and args.exchange == "rccl":
+            try:
+                box[0] = capi.comm_unique_id()
+            except Exception as e:   # every rank must learn about it, or the others wait in the communicator set-up
+                box[1] = "rn_comm_unique_id: %s" % e
         dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        uid, uid_error = box
+    fallback_reason = [None]
 
     def run_mode(structured, steps, warmup, profile_steps, new_uid=None):
+        if sharded:
+            import torch
         s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
         if sharded:
-            s.commInit(rank, world, new_uid)
+            # the library's RCCL communicator; if any rank cannot create it, ALL ranks fall back to the step-wise exchange
+            ok, err = 1, ""
+            if args.exchange == "torch":
+                ok, err = 0, "--exchange torch"
+            elif new_uid is None:
+                ok, err = 0, uid_error or "no unique id"
+            else:
+                try:
+                    s.commInit(rank, world, new_uid)
+                except capi.RapidNetError as e:
+                    ok, err = 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                fallback_reason[0] = err or "a peer rank could not create the communicator"
+                s.close()
+                s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
+                s.commInit(rank, world, None)
             s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
+        theta = [1.0, 1.0]
+        n_cut = 0
+        if sharded and fallback_reason[0]:
+            nps = problem["tree"]["nodesPerStage"]
+            n_cut = int(nps[cut_stage - 1]) * (s.nv + 2 * s.nx)
+
+        def iterate(n):
+            """n APG iterations.  Normal path: ONE library call, no host sync inside.  Fallback: the protected step methods
+            with the cut payload all-reduced through torch.distributed (exact unless the soft-constraint branch trips)."""
+            if not (sharded and fallback_reason[0]):
+                s.apgIterate(n, history=False)
+                return
+            for _ in range(n):
+                lam = theta[1] * (1.0 / theta[0] - 1.0)
+                theta[0], theta[1] = theta[1], 0.5 * (np.sqrt(theta[1] ** 4 + 4 * theta[1] ** 2) - theta[1] ** 2)
+                s.dualExtrapolationStep(lam)
+                s.debugSweepPhase(1)
+                payload = torch.from_numpy(s.debugCutBuffer(n_cut)).cuda()
+                dist.all_reduce(payload)
+                s.debugCutBuffer(n_cut, payload.cpu().numpy())
+                s.debugSweepPhase(2)
+                s.proximalFunG(); s.computeFixedPointResidual(); s.dualUpdate()
 
         def barrier():
             s.synchronize()
@@ -135,10 +183,10 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        s.apgIterate(warmup, history=False)
+        iterate(warmup)
         barrier()
         t0 = time.perf_counter()
-        s.apgIterate(steps, history=False)
+        iterate(steps)
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -230,7 +278,8 @@ def main():
                 "operator_storage": "structured (shared operators, no per-node blocks)" if args.structured else "dense per-node blocks (reference storage model)",
                 "ms_per_controlStep_500it": head["ms_per_controlStep_500it_derived"],
                 "ms_per_controlStep_500it_measured": head["ms_per_controlStep_500it_measured"],
-                "parallelism": "1 GPU" if not sharded else "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage},
+                "parallelism": "1 GPU" if not sharded else ("subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage if not fallback_reason[0]
+                                                            else "subtree sharding below stage %d, FALLBACK exchange through torch.distributed, step-wise (%s)" % (cut_stage, fallback_reason[0]))},
             "local_nodes": int(tree["nodes"][0]),
             "roofline": roofline, "kernel_classes": classes,
         }
