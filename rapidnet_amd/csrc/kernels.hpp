@@ -287,7 +287,10 @@ __global__ void k_struct_prep(SweepArgs<T> a) {
 // Chain region (stages >= c*, every node has exactly one child at the same position): one workgroup per
 // scenario chain, thread t owns one component and walks from the leaf to the chain top.
 constexpr int CHAIN_THREADS = 256;
-constexpr int CHAIN_PF = 12;
+#ifndef RN_CHAIN_PF
+#define RN_CHAIN_PF 12
+#endif
+constexpr int CHAIN_PF = RN_CHAIN_PF;
 constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the recursion itself is a running sum)
 template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a) {
