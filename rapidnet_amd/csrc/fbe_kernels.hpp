@@ -126,41 +126,93 @@ __global__ void k_fbe_dual_update(T *gPrev, const T *g, T *yPrev, T *y, T *w, co
 // VALUE_TILE times (the first version, one node at a time, spent 176 us per call on W loads).  partials[block][0..1]
 constexpr int VALUE_THREADS = 128;
 constexpr int VALUE_TILE = 16;
+#ifndef RN_VALUE_JB
+#define RN_VALUE_JB 8
+#endif
+constexpr int VALUE_JB = RN_VALUE_JB;
+constexpr int VALUE_RPW = VALUE_TILE / (VALUE_THREADS / 64);   // node rows per wave
+constexpr int VALUE_TC = 2;                                      // 64-wide column chunks requested together
 template <typename T>
 __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const T *prevU, const int *parent, const T *prob, const T *W,
                                                               const T *alpha, int nu, int nodes, double *partials) {
-    extern __shared__ unsigned char fbe_smem[];
-    T *du = reinterpret_cast<T *>(fbe_smem);            // [VALUE_TILE][nu]
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fbe_smem[];
+    T *du = reinterpret_cast<T *>(fbe_smem);            // [nu][VALUE_TILE]: the tile's values of one column are contiguous
     __shared__ double sq[VALUE_THREADS / 64], sl[VALUE_THREADS / 64];
     double quad = 0, lin = 0;
     const int tiles = (nodes + VALUE_TILE - 1) / VALUE_TILE;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int n0 = tile * VALUE_TILE;
         const int cnt = nodes - n0 < VALUE_TILE ? nodes - n0 : VALUE_TILE;
-        for (int i = threadIdx.x; i < VALUE_TILE * nu; i += VALUE_THREADS) {
-            const int n = i / nu, t = i - n * nu;
-            T v = 0;
-            if (n < cnt) {
-                const int node = n0 + n, par = parent[node];
-                const T un = u[(size_t)node * nu + t];
-                v = un - (par < 0 ? prevU[t] : u[(size_t)par * nu + t]);
-                lin += (double)(prob[node] * un) * (double)alpha[(size_t)node * nu + t];
+        {   // du of the tile -> LDS: every wave takes VALUE_RPW whole node rows; the parents of all its rows are requested
+            // first, then every u / u_parent / alpha value of the rows in one batch (two dependent round trips per tile
+            // instead of three per element as in the first version)
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            int nodeOf[VALUE_RPW], par[VALUE_RPW];
+            T pb[VALUE_RPW];
+#pragma unroll
+            for (int r = 0; r < VALUE_RPW; r++) {
+                const int n = wave * VALUE_RPW + r;
+                nodeOf[r] = n < cnt ? n0 + n : -1;
+                const int nc = n < cnt ? n0 + n : n0;
+                par[r] = parent[nc]; pb[r] = prob[nc];
             }
-            du[i] = v;
+            for (int t0 = lane; t0 < nu; t0 += 64 * VALUE_TC) {
+                T un[VALUE_TC][VALUE_RPW], up[VALUE_TC][VALUE_RPW], al[VALUE_TC][VALUE_RPW];
+#pragma unroll
+                for (int c = 0; c < VALUE_TC; c++) {
+                    const int t = t0 + 64 * c < nu ? t0 + 64 * c : t0;
+#pragma unroll
+                    for (int r = 0; r < VALUE_RPW; r++) {
+                        const int nc = nodeOf[r] >= 0 ? nodeOf[r] : n0;
+                        un[c][r] = u[(size_t)nc * nu + t];
+                        up[c][r] = par[r] < 0 ? prevU[t] : u[(size_t)par[r] * nu + t];
+                        al[c][r] = alpha[(size_t)nc * nu + t];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < VALUE_TC; c++) {
+                    const int t = t0 + 64 * c;
+                    if (t < nu) {
+#pragma unroll
+                        for (int r = 0; r < VALUE_RPW; r++) {
+                            const bool live = nodeOf[r] >= 0;
+                            du[t * VALUE_TILE + wave * VALUE_RPW + r] = live ? un[c][r] - up[c][r] : (T)0;
+                            if (live) lin += (double)(pb[r] * un[c][r]) * (double)al[c][r];
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nu; t += VALUE_THREADS) {
             T wd[VALUE_TILE];
 #pragma unroll
             for (int n = 0; n < VALUE_TILE; n++) wd[n] = 0;
-            for (int j = 0; j < nu; j++) {
-                const T wtj = W[t + (size_t)j * nu];
+            // VALUE_JB columns of W requested together: with one load per trip the loop is a chain of 114 L2 round trips
+            // per tile (measured 100 us per call); the summation order over j is unchanged
+            for (int j0 = 0; j0 < nu; j0 += VALUE_JB) {
+                T wv[VALUE_JB];
 #pragma unroll
-                for (int n = 0; n < VALUE_TILE; n++) wd[n] += wtj * du[n * nu + j];
+                for (int jj = 0; jj < VALUE_JB; jj++) wv[jj] = W[t + (size_t)(j0 + jj < nu ? j0 + jj : nu - 1) * nu];
+#pragma unroll
+                for (int jj = 0; jj < VALUE_JB; jj++) {
+                    if (j0 + jj < nu) {
+                        // the tile's du values of column j are 16-byte aligned and contiguous: VALUE_TILE / VN wide LDS reads
+                        const VT *dj = reinterpret_cast<const VT *>(du + (size_t)(j0 + jj) * VALUE_TILE);
+#pragma unroll
+                        for (int q = 0; q < VALUE_TILE / VN; q++) {
+                            const VT dv = dj[q];
+#pragma unroll
+                            for (int e = 0; e < VN; e++) wd[q * VN + e] += wv[jj] * dv[e];
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int n = 0; n < VALUE_TILE; n++)
-                if (n < cnt) quad += (double)(prob[n0 + n] * du[n * nu + t]) * (double)wd[n];
+                if (n < cnt) quad += (double)(prob[n0 + n] * du[t * VALUE_TILE + n]) * (double)wd[n];
         }
         __syncthreads();
     }
