@@ -24,6 +24,8 @@ struct DotArgs {
     double *partials;   // [blocks][DOT_MAX]
 };
 // up to DOT_MAX dot products <a_j, b_j> over the same index range in ONE pass; fp64 accumulation, fixed reduction
+// order (a last-block-folds variant that saves the k_dots_finish launch was measured: the per-block agent-scope release
+// makes k_dots 2.5x and k_value_terms 4x slower on this multi-XCD part -- two launches it stays);
 // order (thread-strided partial sums -> wave shuffle -> LDS -> one partial per block), so a repeat is bitwise equal
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
@@ -31,7 +33,22 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
     double acc[DOT_MAX];
 #pragma unroll
     for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
-    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < g.n; i += (long long)gridDim.x * ELT_THREADS) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    unsigned long long misal = 0;   // columns of the L-BFGS buffers start at multiples of n values: 16-byte aligned only if n allows
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) if (j < g.cnt) misal |= (unsigned long long)g.a[j] | (unsigned long long)g.b[j];
+    const long long nvec = (misal & 15ull) ? 0 : g.n / VN;
+    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * ELT_THREADS) {   // 16-byte loads
+#pragma unroll
+        for (int j = 0; j < DOT_MAX; j++)
+            if (j < g.cnt) {
+                const VT av = reinterpret_cast<const VT *>(g.a[j])[i], bv = reinterpret_cast<const VT *>(g.b[j])[i];
+#pragma unroll
+                for (int e = 0; e < VN; e++) acc[j] += (double)av[e] * (double)bv[e];
+            }
+    }
+    for (long long i = nvec * VN + (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < g.n; i += (long long)gridDim.x * ELT_THREADS) {
 #pragma unroll
         for (int j = 0; j < DOT_MAX; j++)
             if (j < g.cnt) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
