@@ -789,6 +789,9 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
 // the workgroup has as many waves as divide the tile count evenly (6 for the 88- and 177-row operators).
 // fp64 note: v_mfma_f64_16x16x4 runs at 1/64 per cycle per SIMD (78 TFLOP/s chip-wide), so these products have an
 // MFMA floor of the same order as their HBM floor (4-5 us each on the 493-scenario tree).
+#ifndef RN_CROWN2_FALLBACK
+#define RN_CROWN2_FALLBACK 0
+#endif
 #ifndef RN_SLAB_MAX_WAVES
 #define RN_SLAB_MAX_WAVES 8
 #endif
@@ -990,7 +993,8 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         // workgroup 0 does both steps in one batch of loads when the children's values fit in the (still unused) slab
         // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
         // has swept the caches and TLBs
-        if (blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
+        // (RN_CROWN2_FALLBACK builds force the two-function path below, which otherwise only very wide crowns take)
+        if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
             up_crown2_wg0<T>(a, sB, threadIdx.x, blockDim.x);
         } else {
             if (blockIdx.x == 0) up_root_from_presummed<T>(a, threadIdx.x, blockDim.x);
