@@ -1,0 +1,42 @@
+"""bench.py's output contract, checked on the GPU box: exactly ONE JSON line on stdout carrying the driver's fields, the
+`roofline` object of the dominant kernel and the `cpu_baseline` object (a short run: 20 timed steps)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d" % len(lines)
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "apg_iterations_per_sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "barcelona493" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_stream_gemv"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.5 < r["frac"] < 1.0, "the streaming kernel should sit between 50 % and 100 % of the HBM peak"
+    # achieved = algorithmic bytes per launch / average launch time; the PMC traffic may not be far above the algorithmic bytes
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] < 1.05 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "iterations/s" and c["value"] > 0
+    assert d["value"] > 10 * c["value"]                  # north_star: >= 10x the host-CPU baseline at 1 GPU
