@@ -236,7 +236,11 @@ int rn_set_cut_stage(rn_ctx *ctx, int stage);
  *   1 (default) optimistic: the prox runs as a pure projection, every rank's dist^2 of iteration t rides in the tail of
  *     iteration t+1's cut all-reduce and is checked on the device -- ONE collective per iteration; if a threshold is
  *     ever exceeded the batch is replayed from a checkpoint with mode 0, so the result is exact either way;
- *   0 exact: a second 2-element all-reduce per iteration before the trip decision. */
+ *   0 exact: a second 2-element all-reduce per iteration before the trip decision.
+ * Single-GPU contexts use the same switch: with 1 (default) a batch of >= 16 iterations runs the prox as a pure projection,
+ * the bookkeeping of iteration t (history entry, distance check) rides in a launch of iteration t+1 instead of a decision
+ * launch of its own, and the batch is replayed from a checkpoint through the exact path if a distance ever exceeded its
+ * threshold; with 0 every iteration decides before the next one starts.  Results are identical. */
 int rn_set_exchange_mode(rn_ctx *ctx, int mode);
 /* static tree data a shard cannot derive from its local children: for every cut parent i (stage-1 nodes of the cut, in
  * stage order) E_i = sum over ALL children c of p_c * errorDemand_c (nd reals) and P_i = sum_c p_c.  They replace the

@@ -287,13 +287,23 @@ __global__ void k_struct_prep(SweepArgs<T> a) {
 // Chain region (stages >= c*, every node has exactly one child at the same position): one workgroup per
 // scenario chain, thread t owns one component and walks from the leaf to the chain top.
 constexpr int CHAIN_THREADS = 256;
+static_assert(CHAIN_THREADS == ELT_THREADS, "the bookkeeping workgroup of k_up_chain folds with ELT_THREADS threads");
 #ifndef RN_CHAIN_PF
 #define RN_CHAIN_PF 12
 #endif
 constexpr int CHAIN_PF = RN_CHAIN_PF;
 constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the recursion itself is a running sum)
+// Bookkeeping of the PREVIOUS iteration's fused dual update (optimistic modes: no decision launch of its own): folds the
+// partials, writes the history entry, advances the iteration counter, and either puts the rank-local dist^2 into the
+// all-reduce payload's tail (sharded: checked after the collective) or checks it against the thresholds right away
+// (thrX >= 0: single GPU).  Rides as one extra workgroup in k_cut_partial_sums (sharded) or k_up_chain (single GPU).
+struct Partial;
+struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; double thrX, thrS; };
 template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a) {
+__device__ void finalize_optimistic_body(const FinArgs &fin);
+template <typename T>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
+    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
     const int s = blockIdx.x;                      // chain = position within the stage
     const int nv = a.nv, nx = a.nx;
     const int top = a.chainStage;
@@ -630,15 +640,11 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_all(SweepArgs<T> a, 
 // bookkeeping of the PREVIOUS iteration's fused dual update -- folds its partials, writes the history entry, advances the
 // iteration counter and puts the rank-local dist^2 into the payload's tail -- which would otherwise be a launch of its own
 // (k_finalize_optimistic) on the critical path of every iteration.
-struct Partial;
-struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; };
-template <typename T>
-__device__ void finalize_optimistic_body(const Partial *partials, int nblocks, IterState *st, T *tail, double *hist, double *histParts, int histCap);
 constexpr int CUT_THREADS = 256;   // = ELT_THREADS (the bookkeeping block's reduction is written for it)
 template <typename T>
 __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a, T *out, int nParents, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
-        finalize_optimistic_body<T>(fin.partials, fin.nblocks, fin.st, reinterpret_cast<T *>(fin.tail), fin.hist, fin.histParts, fin.histCap);
+        finalize_optimistic_body<T>(fin);
         return;
     }
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
@@ -1613,7 +1619,12 @@ __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials,
 // correction; this kernel folds the block partials, stores the rank-local dist^2 of THIS iteration in the tail of the
 // cut payload (it rides on the NEXT iteration's all-reduce), writes the rank-local history entry and advances `it`.
 template <typename T>
-__device__ void finalize_optimistic_body(const Partial *partials, int nblocks, IterState *st, T *tail, double *hist, double *histParts, int histCap) {
+__device__ void finalize_optimistic_body(const FinArgs &fin) {
+    const Partial *partials = fin.partials;
+    const int nblocks = fin.nblocks, histCap = fin.histCap;
+    IterState *st = fin.st;
+    T *tail = reinterpret_cast<T *>(fin.tail);
+    double *hist = fin.hist, *histParts = fin.histParts;
     __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
     __shared__ Partial sh[ELT_THREADS / 64];
     double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
@@ -1644,7 +1655,12 @@ __device__ void finalize_optimistic_body(const Partial *partials, int nblocks, I
             better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
             better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
         }
-        tail[0] = (T)tx2; tail[1] = (T)ts2;
+        if (tail) { tail[0] = (T)tx2; tail[1] = (T)ts2; }
+        if (fin.thrX >= 0) {   // single GPU: the distances are complete -- verify the projection-only prox right here
+            const double dX = sqrt(tx2), dS = sqrt(ts2);
+            st->distX = dX; st->distS = dS;
+            if (dX > fin.thrX || dS > fin.thrS) st->violated = 1;
+        }
         const int it = st->it;
         if (it < histCap) {
             hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
@@ -1656,8 +1672,8 @@ __device__ void finalize_optimistic_body(const Partial *partials, int nblocks, I
 }
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Partial *partials, int nblocks, IterState *st, T *tail,
-                                                                     double *hist, double *histParts, int histCap) {
-    finalize_optimistic_body<T>(partials, nblocks, st, tail, hist, histParts, histCap);
+                                                                     double *hist, double *histParts, int histCap, double thrX, double thrS) {
+    finalize_optimistic_body<T>(FinArgs{partials, nblocks, st, (void *)tail, hist, histParts, histCap, thrX, thrS});
 }
 // after the all-reduce: the tail holds the tree-global dist^2 of the previous iteration
 // vote != nullptr: the rank's verdict for the whole batch (1 = a threshold was exceeded somewhere) is left there for one

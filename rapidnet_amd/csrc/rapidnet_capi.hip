@@ -22,6 +22,9 @@
 #ifndef RN_FOLD_CROWN_DOWN
 #define RN_FOLD_CROWN_DOWN 1
 #endif
+#ifndef RN_OPT_LOCAL_MIN
+#define RN_OPT_LOCAL_MIN 16   // shortest rn_apg_iterate batch that takes the optimistic single-GPU path
+#endif
 #ifndef RN_DUAL_REGEN
 #define RN_DUAL_REGEN 1
 #endif
@@ -698,14 +701,20 @@ struct Ctx : CtxBase {
         }
         e1 = prof_begin(1);
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
-        if (phase != 2) hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a);
+        if (phase != 2) {
+            // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
+            FinArgs fin{};
+            const bool ride = pendingFin && !a.cutSums;
+            if (ride) { fin = FinArgs{d_partials, eltBlocks, d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
+            hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+        }
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
         const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
         auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
             if (phase == 2) return RN_OK;              // payload already summed by the caller
             // optimistic exchange: the bookkeeping of the previous iteration's dual update rides in this launch
             FinArgs fin{};
-            if (pendingFin) fin = FinArgs{d_partials, eltBlocks, d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap};
+            if (pendingFin) fin = FinArgs{d_partials, eltBlocks, d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
             pendingFin = false;
             if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
@@ -845,7 +854,7 @@ struct Ctx : CtxBase {
             if (k == n - 1) {
                 const hipEvent_t *e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_cut + tail,
-                                   d_hist, d_histParts, histCap);
+                                   d_hist, d_histParts, histCap, -1.0, -1.0);
                 prof_end(e3);
             } else pendingFin = true;
             std::swap(p_xi, p_upd);
@@ -888,12 +897,74 @@ struct Ctx : CtxBase {
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
+    // Single GPU, optimistic bookkeeping: the same idea without a collective.  The fused dual update runs the prox as a
+    // pure projection; instead of a decision launch after every iteration (the 64-workgroup fix-up launch, ~5 us that
+    // almost always exits at once) the fold of its partials, the history entry and the distance check of iteration t ride
+    // in k_up_chain of iteration t+1 as one more workgroup.  If a threshold was exceeded anywhere in the batch, the batch
+    // is replayed from its checkpoint through the exact path -- the result is exact either way.
+    int apg_iterate_optimistic_local(int n, double *primalInfs) {
+        const int first = h_it;
+        const size_t bytes = (size_t)ntot() * sizeof(T);
+        for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
+        if (int rc = ensure_tables(h_it + n)) return rc;
+        RN_HIP(hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream));
+        T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
+        const bool s_ready = acc_ready;
+        RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
+        for (int k = 0; k < n; k++) {
+            if (!acc_ready) {
+                hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
+                acc_ready = true;
+            }
+            if (int rc = launch_sweep()) { pendingFin = false; return rc; }
+            DualArgs<T> a = dual_args();
+            const hipEvent_t *e2 = prof_begin(2);
+            if (k == n - 1) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            prof_end(e2);
+            if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
+                const hipEvent_t *e3 = prof_begin(3);
+                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, (T *)nullptr,
+                                   d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize);
+                prof_end(e3);
+            } else pendingFin = true;
+            std::swap(p_xi, p_upd);
+            p_acc_view = p_acc;
+            std::swap(p_acc, p_acc_other);
+            h_it++;
+        }
+        RN_HIP(hipGetLastError());
+        int violated = 0;
+        RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        if (violated) {   // replay the batch exactly
+            fallbacks++;
+            p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
+            RN_HIP(hipMemcpyAsync(p_xi, d_ck[0], bytes, hipMemcpyDeviceToDevice, stream));
+            RN_HIP(hipMemcpyAsync(p_upd, d_ck[1], bytes, hipMemcpyDeviceToDevice, stream));
+            RN_HIP(hipMemcpyAsync(p_acc, d_ck[2], bytes, hipMemcpyDeviceToDevice, stream));
+            h_it = first;
+            RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
+            RN_HIP(hipStreamSynchronize(stream));
+            const int keep = optimistic;
+            optimistic = 0;
+            const int rc = apg_iterate(n, primalInfs);
+            optimistic = keep;
+            return rc;
+        }
+        if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        return RN_OK;
+    }
     int set_exchange_mode(int mode) override { RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic"); optimistic = mode; return RN_OK; }
     int apg_iterate(int n, double *primalInfs) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
         RN_HIP(hipSetDevice(device));
         if (comm && cutStage > 0 && optimistic && n > 0) return apg_iterate_optimistic(n, primalInfs);
+        // single GPU: worth a checkpoint (3 vector copies) and a read-back per batch once the batch is long enough
+        if (!comm && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN) return apg_iterate_optimistic_local(n, primalInfs);
         const int first = h_it;
         if (int rc = ensure_tables(h_it + n)) return rc;
         for (int k = 0; k < n; k++) {
