@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="barcelona493", help="named config of rapidnet_amd.synth.CONFIGS")
     ap.add_argument("--precision", default=None, help="f64 | f32 (default: f64, f32 for wide4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=20, help="timed iterations of the CPU baseline (after 2 warm-ups)")
     ap.add_argument("--dense-only", action="store_true", help="skip the structured-mode pass (tuning sweeps)")
     ap.add_argument("--force-shard", action="store_true", help="debug: run the sharded code path (partition, RCCL communicator, cut all-reduce) even with one rank")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug/timing only: with one rank, run rank 0's shard of an N-rank partition through the sharded code path (one-rank communicator; iterates are NOT the solution, the other ranks' sums are missing)")
@@ -43,39 +44,72 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(problem_name, nodes_full):
-    """The CPU oracle ("port" of the reference's sweep, 1 thread) on a bounded sample of the same workload:
-    the same network and horizon with a 2 x 29 tree (58 of the 493 scenarios, 1 279 nodes).  Per-node work is
-    uniform, so iterations/s of the full tree = sample rate x nodes_sample / nodes_full."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(problem_name, problem, precision, timed_iterations=20):
+    """The CPU oracle ("port" of the reference's sweep: oracle/apg_oracle.c, 1 thread pinned to one core) timed on THIS
+    workload: the same network, tree, forecasts, step size and precision as the GPU run (SURVEY.md section 8(d),
+    BASELINE.md section 2): 2 warm-up iterations, then `timed_iterations` iterations timed one by one; value = 1 / median.
+    A workload whose dense per-node blocks do not fit in host memory (wide4096: 160 GB in fp32) is timed on a bounded
+    sub-tree of the same network instead and scaled by node count -- the JSON says so."""
     from oracle import oracle as oracle_mod
     from oracle.oracle import Oracle
     from rapidnet_amd import synth
 
+    oracle_mod.build(force=True, march="native", variant="_native")   # the host's full ISA, in a file of its own
+    nx, nu, nd = (int(problem["network"][k][0]) for k in ("nx", "nu", "nd"))
+    nv, nodes_full = int(problem["config"]["nv"][0]), int(problem["tree"]["nodes"][0])
+    s = 8 if precision == "f64" else 4
+    oracle_bytes = float(nodes_full) * s * (4.0 * nv * nx + 2.0 * nv * nu + 2.0 * nx * nx + nu * nu + 12.0 * (2 * nx + nu))
     try:
-        oracle_mod.build(force=True, march="native")  # time the baseline with the host's full ISA
-    except Exception:
-        pass
-    idx, nx, nu, nd, ne, N, branching = synth.CONFIGS[problem_name]
-    sample_branching = [2, 29] if problem_name == "barcelona493" else branching
-    synth.CONFIGS["_cpu_sample"] = (idx, nx, nu, nd, ne, N, sample_branching)
-    p = synth.make_problem("_cpu_sample", step_size=1e-6)
-    o = Oracle(p["network"], p["tree"], p["config"])
-    dh, ah = synth.forecast_at(p["forecast"], 0)
-    o.initialise(dh, ah)
-    o.apg_reset()
-    th = o.apg_continue(2, [1.0, 1.0])
-    iters, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 12.0:
-        th = o.apg_continue(5, th)
-        iters += 5
-    dt = time.perf_counter() - t0
-    rate_sample = iters / dt
+        host_mem = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        host_mem = 64 << 30
+    scaled = oracle_bytes > 0.45 * host_mem
+    p, note = problem, ""
+    if scaled:
+        idx, _, _, _, ne, N, branching = synth.CONFIGS[problem_name]
+        sample_branching = list(branching[:-1]) if len(branching) > 1 else [2]
+        synth.CONFIGS["_cpu_sample"] = (idx, nx, nu, nd, ne, N, sample_branching)
+        p = synth.make_problem("_cpu_sample", step_size=float(problem["config"]["stepSize"][0]))
+        note = "; the full tree's blocks (%.0f GB) do not fit in host memory: timed on the %s sub-tree and scaled by nodes" % (
+            oracle_bytes / 1e9, "x".join(map(str, sample_branching)))
+    cores = sorted(os.sched_getaffinity(0))
+    core = cores[len(cores) // 2]
+    os.sched_setaffinity(0, {core})
+    try:
+        t0 = time.perf_counter()
+        o = Oracle(p["network"], p["tree"], p["config"], precision=precision, variant="_native")
+        dh, ah = synth.forecast_at(p["forecast"], 0)
+        o.initialise(dh, ah)
+        t_factor = time.perf_counter() - t0
+        o.apg_reset()
+        th = o.apg_continue(2, [1.0, 1.0])
+        per_it = []
+        for _ in range(timed_iterations):
+            t1 = time.perf_counter()
+            th = o.apg_continue(1, th)
+            per_it.append(time.perf_counter() - t1)
+    finally:
+        os.sched_setaffinity(0, set(cores))
+    med = float(np.median(per_it))
+    rate = 1.0 / med * (o.nodes / float(nodes_full))
     return {
-        "value": rate_sample * o.nodes / nodes_full, "unit": "iterations/s", "cores": 1, "kind": "port",
-        "sample": "%d iterations in %.1f s of oracle/apg_oracle.c (gcc -O3 -march=native, 1 thread) on the same network, "
-                  "N=%d, %s tree (%d nodes); scaled by nodes %d/%d to the full workload" % (
-                      iters, dt, N, "x".join(map(str, sample_branching)), o.nodes, o.nodes, nodes_full),
-        "sample_iterations_per_s": rate_sample, "host_cpus": os.cpu_count(),
+        "value": rate, "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": "%d timed iterations (after 2 warm-ups) of oracle/apg_oracle.c (gcc -O3 -march=native, 1 thread pinned to core %d) on %s, "
+                  "%s, %d nodes, step size %.6g: median %.1f ms, min %.1f, max %.1f; factor step + affine terms %.1f s (not timed)%s" % (
+                      timed_iterations, core, "the bench workload itself (same network, tree, forecasts)" if not scaled else "a sub-tree of the bench workload",
+                      precision, o.nodes, float(p["config"]["stepSize"][0]), 1e3 * med, 1e3 * min(per_it), 1e3 * max(per_it), t_factor, note),
+        "ms_per_iteration_median": 1e3 * med, "ms_per_controlStep_500it": 500.0 * 1e3 * med * (float(nodes_full) / o.nodes),
+        "scaled_by_nodes": bool(scaled), "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
     }
 
 
@@ -225,16 +259,27 @@ def main():
             dual = {"achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
                     "avg_launch_us": 1e6 * dual_s}
             dual["frac"] = dual["achieved"] / 8000.0
-            traffic = {}
+            # HBM traffic from the PMC counters is NOT measured by this run (rocprofv3 --pmc needs passes of its own): it is
+            # carried over from profiles/traffic.json, and only if that file was collected on this workload with exactly
+            # the kernel sources this run executes; traffic_source says where the number comes from
+            traffic, traffic_source = {}, {"measured_in_this_run": False, "file": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and args.workload == "barcelona493" and precision == "f64" and not sharded:
-                try:   # PMC counters were collected on exactly this workload (profiles/traffic.json says how)
-                    traffic = json.load(open(tpath))
+                try:
+                    from rapidnet_amd import build as _b
+
+                    t = json.load(open(tpath))
+                    cur = _b.kernel_sources_sha256()
+                    traffic_source = {"measured_in_this_run": False, "file": "profiles/traffic.json", "collected_at_commit": t.get("collected_at_commit"),
+                                      "kernels_sha256": t.get("kernels_sha256"), "matches_current_kernels": t.get("kernels_sha256") == cur,
+                                      "how": t.get("source")}
+                    if t.get("kernels_sha256") == cur:
+                        traffic = t
                 except Exception:
                     traffic = {}
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
                 roofline = {"kernel": "k_dual_fused", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
-                            "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"),
+                            "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
                 if copy_ceiling:
                     roofline.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
@@ -242,7 +287,7 @@ def main():
                 avg_s = 1e-3 * ms[0] / max(n[0], 1)
                 achieved = bwd_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
                 roofline = {"kernel": "k_stream_gemv", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                            "frac": achieved / 8000.0, "traffic": traffic.get("k_stream_gemv_bytes_per_launch"),
+                            "frac": achieved / 8000.0, "traffic": traffic.get("k_stream_gemv_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": 1e6 * avg_s, "launches_per_step": 1,
                             "dual_update": dual}
                 if read_ceiling:   # read-only stream vs a read-only probe; the dual update (5 read + 2 write streams) vs the copy probe
@@ -288,7 +333,7 @@ def main():
                                                                "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if not args.no_cpu_baseline and not sharded:
-            out["cpu_baseline"] = cpu_baseline(args.workload, nodes_full)
+            out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -11,3 +11,7 @@ g++ -std=c++11 -O1 -w -fPIC -shared -I"$ref" \
     -x c++ "$ref/DwnNetwork.cu" "$ref/ScenarioTree.cu" "$ref/Forecaster.cu" "$ref/SmpcConfiguration.cu" \
     -x c++ "$here/ref_loader_shim.cpp" -o "$here/_ref/libref_loaders.so"
 echo "built $here/_ref/libref_loaders.so"
+# heap-padding preload for the child process that runs the reference's loaders (their constructor overruns two heap
+# blocks by 4 bytes, ScenarioTree.cu:66-75); see oracle/malloc_pad.c
+gcc -O1 -fPIC -shared "$here/malloc_pad.c" -o "$here/_ref/libmalloc_pad.so"
+echo "built $here/_ref/libmalloc_pad.so"

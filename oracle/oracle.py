@@ -22,30 +22,33 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
-def build(force=False, march=None):
-    """Compile apg_oracle.c into liboracle_f64.so / liboracle_f32.so next to this file.
+def build(force=False, march=None, variant=""):
+    """Compile apg_oracle.c into liboracle_f64<variant>.so / liboracle_f32<variant>.so next to this file.
 
-    Default -march=x86-64-v3 so that a library built in one container runs on another host; bench.py's
-    cpu_baseline leg rebuilds with march="native" on the machine it times."""
+    Default -march=x86-64-v3 so that a library built in one container runs on another host.  bench.py's cpu_baseline
+    leg builds a SEPARATE pair (variant="_native", -march=native) on the machine it times, so the portable test oracle
+    is never overwritten by a host-specific binary."""
     march = march or os.environ.get("ORACLE_MARCH", "x86-64-v3")
     src = os.path.join(_HERE, "apg_oracle.c")
     for tag, define in (("f64", []), ("f32", ["-DORACLE_REAL=float"])):
-        out = os.path.join(_HERE, "liboracle_%s.so" % tag)
+        out = os.path.join(_HERE, "liboracle_%s%s.so" % (tag, variant))
         if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-            cmd = ["gcc", "-O3", "-march=" + march, "-fPIC", "-shared", "-std=c99"] + define + ["-o", out, src, "-lm"]
+            tmp = out + ".tmp.%d" % os.getpid()
+            cmd = ["gcc", "-O3", "-march=" + march, "-fPIC", "-shared", "-std=c99"] + define + ["-o", tmp, src, "-lm"]
             subprocess.check_call(cmd)
+            os.replace(tmp, out)
     return _HERE
 
 
-def _lib(precision):
-    tag = {"f64": "f64", "f32": "f32"}[precision]
+def _lib(precision, variant=""):
+    tag = {"f64": "f64", "f32": "f32"}[precision] + variant
     if tag not in _LIBS:
         path = os.path.join(_HERE, "liboracle_%s.so" % tag)
         src = os.path.join(_HERE, "apg_oracle.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             try:
-                build()
-            except Exception:  # -march=native binaries built elsewhere still load; rebuild is best effort
+                build(variant=variant, march="native" if variant == "_native" else None)
+            except Exception:  # a stale binary still loads; rebuild is best effort
                 if not os.path.exists(path):
                     raise
         lib = C.CDLL(path)
@@ -113,8 +116,8 @@ def forecast_at(forecast, sim_time):
 class Oracle:
     """CPU oracle for one (network, tree, config) triple."""
 
-    def __init__(self, network, tree, config, precision="f64", alias_operators=True):
-        self.lib = _lib(precision)
+    def __init__(self, network, tree, config, precision="f64", alias_operators=True, variant=""):
+        self.lib = _lib(precision, variant)
         self.lib.oracle_config_aliasing(1 if alias_operators else 0)
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.network, self.tree, self.config = network, tree, config

@@ -10,11 +10,45 @@ LIB_HIP = os.path.join(HERE, "librapidnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _stale(out, srcs):
-    if not os.path.exists(out):
+def _fingerprint(srcs, extra=()):
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _stale(out, srcs, extra=()):
+    """A built file is current when the stamp beside it (<out>.srchash) equals the fingerprint of its sources: content,
+    not mtimes -- a snapshot copied to another box keeps its binaries valid whatever the copy did to the timestamps."""
+    stamp = out + ".srchash"
+    if not os.path.exists(out) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(out)
-    return any(os.path.getmtime(s) > t for s in srcs)
+    return open(stamp).read().strip() != _fingerprint(srcs, extra)
+
+
+def _stamp(out, srcs, extra=()):
+    with open(out + ".srchash", "w") as f:
+        f.write(_fingerprint(srcs, extra) + "\n")
+
+
+def kernel_sources():
+    return [os.path.join(CSRC, f) for f in ("rapidnet_capi.hip", "kernels.hpp", "fbe_kernels.hpp", "fbe_methods.inc")]
+
+
+def kernel_sources_sha256():
+    """Fingerprint of the HIP sources: measurement artefacts (profiles/traffic.json) carry it, and bench.py only reports
+    PMC traffic collected with the kernels it is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in kernel_sources():
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def build_hip(force=False, verbose=False, defines=(), out=None):
@@ -25,13 +59,25 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     out = out or LIB_HIP
     srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "fbe_kernels.hpp"),
             os.path.join(CSRC, "fbe_methods.inc"), os.path.join(ROOT, "include", "rapidnet.h")]
-    if force or _stale(out, srcs):
+    if force or _stale(out, srcs, defines):
+        tmp = "%s.tmp.%d" % (out, os.getpid())   # compile beside the target, then rename: a concurrent loader never sees a partial file
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               "-Wno-pass-failed"] + ["-D" + d for d in defines] + ["-o", out, srcs[0], "-ldl"]
+               "-Wno-pass-failed"] + ["-D" + d for d in defines] + ["-o", tmp, srcs[0], "-ldl"]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, out)
+            _stamp(out, srcs, defines)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return out
+
+
+def hip_is_stale():
+    srcs = kernel_sources() + [os.path.join(ROOT, "include", "rapidnet.h")]
+    return _stale(LIB_HIP, [srcs[0], srcs[1], srcs[2], srcs[3], srcs[4]])
 
 
 LIB_HOST = os.path.join(HERE, "librapidnet_host.so")
@@ -45,14 +91,17 @@ def build_host(force=False):
     srcs = [os.path.join(hdir, f) for f in ("DataModel.cpp", "Engine.cpp", "SmpcController.cpp", "NullSpace.cpp")]
     deps = srcs + [os.path.join(hdir, f) for f in ("DataModel.hpp", "Engine.hpp", "SmpcController.hpp", "JsonLite.hpp", "Configuration.h", "NullSpace.hpp")]
     build_hip()
-    if force or _stale(LIB_HOST, deps + [LIB_HIP]):
+    hdr = [os.path.join(ROOT, "include", "rapidnet.h")]
+    if force or _stale(LIB_HOST, deps + hdr):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-fPIC", "-shared", "-o", LIB_HOST] + srcs +
                               ["-L" + HERE, "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN"])
+        _stamp(LIB_HOST, deps + hdr)
     test_src = os.path.join(ROOT, "tests", "cpp", "test_host.cpp")
     os.makedirs(BIN_DIR, exist_ok=True)
-    if force or _stale(TEST_HOST, [test_src, LIB_HOST]):
+    if force or _stale(TEST_HOST, [test_src] + deps + hdr):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-o", TEST_HOST, test_src, "-L" + HERE, "-lrapidnet_host",
                                "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN/.."])
+        _stamp(TEST_HOST, [test_src] + deps + hdr)
     return LIB_HOST
 
 

@@ -63,15 +63,31 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
-        # a fresh checkout: compile the HIP library in-tree (hipcc is part of the image); there is no CPU fallback
-        if os.environ.get("RAPIDNET_LIB"):
+    if os.environ.get("RAPIDNET_LIB"):
+        if not os.path.exists(path):
             raise RuntimeError("$RAPIDNET_LIB names a missing library: %s" % path)
+    else:
+        # (re)build in-tree when the library is missing or older than its sources (a no-op otherwise; hipcc is part of the
+        # image).  Under a launcher only local rank 0 compiles, before any GPU call; the others wait for the finished file
+        # (build_hip renames it into place).  There is no CPU fallback.
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         try:
-            _build.build_hip()
+            if local_rank == 0:
+                _build.build_hip()
+            else:
+                import time
+
+                for _ in range(1800):
+                    if not _build.hip_is_stale():
+                        break
+                    time.sleep(0.5)
         except Exception as e:
-            raise RuntimeError("librapidnet_hip.so is missing (%s) and could not be built (%s); run __graft_entry__.build() -- "
-                               "there is no CPU fallback" % (path, e))
+            if not os.path.exists(path):
+                raise RuntimeError("librapidnet_hip.so is missing (%s) and could not be built (%s); run __graft_entry__.build() -- "
+                                   "there is no CPU fallback" % (path, e))
+            import warnings
+
+            warnings.warn("librapidnet_hip.so could not be rebuilt (%s); loading the existing (possibly stale) binary" % e)
     lib = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_int
     lib.rn_create.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree), ip, ip, C.POINTER(vp)]

@@ -582,8 +582,11 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
     }
     const int wp = (w + 63) / 64 * 64;
     const int parts = CROWN_THREADS / wp > 0 ? CROWN_THREADS / wp : 1;
-    const int part = threadIdx.x / wp, t = threadIdx.x % wp;
-    if (part < parts && t < w) {
+    const int part = threadIdx.x / wp;
+    // vectors wider than the workgroup (w > CROWN_THREADS: parts == 1, part == 0 everywhere): a thread owns components
+    // t, t + CROWN_THREADS, ...; otherwise one pass (the second trip starts at t >= wp >= w)
+    const int tstep = wp < CROWN_THREADS ? wp : CROWN_THREADS;
+    if (part < parts) for (int t = threadIdx.x % wp; t < w; t += tstep) {
         T sum = 0;
         if (!presummed) {
             const T *rk = a.rkq;

@@ -36,7 +36,15 @@ CONFIGS = {
     # many inputs, few tanks: 2 nv = 580 rows per operator column (several 16-byte slots per thread in k_stream_gemv) and
     # shared-operator products too large for the LDS slab kernels (tile-kernel fallback)
     "tall": (19, 8, 300, 40, 10, 3, [2]),
+    # nv + 2 nx = 1200 components per crown node: more than the 1024 threads of a k_up_crown workgroup (and shared-operator
+    # products far too large for the LDS slab kernels)
+    "widecrown": (20, 400, 420, 30, 20, 4, [2, 2]),
 }
+
+
+# 0.95 / lipschitz_estimate(...) of the configs whose 40 power iterations take minutes on a host CPU (the estimate walks the
+# whole tree in numpy: ~90 GFLOP per application on wide4096); value computed once with exactly that call
+STEP_SIZE_CACHE = {"wide4096": 1.5525146548810805e-06}
 
 
 def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
@@ -245,7 +253,7 @@ def make_problem(name, max_iterations=500, sim_horizon=2, penalty_x=1e6, penalty
         "pathToForecaster": "forecastor.json", "algorithmName": "proximalAlgorithm", "lbfgsBufferSize": [5],
     }
     if step_size is None:
-        step_size = 0.95 / lipschitz_estimate(network, tree, config)
+        step_size = STEP_SIZE_CACHE.get(name) or 0.95 / lipschitz_estimate(network, tree, config)
     config["stepSize"] = [float(step_size)]
     forecast = {"N": [N], "simHorizon": [sim_horizon], "dimDemand": [nd], "dimPrices": [nu]}
     for t in range(sim_horizon):  # Forecaster reads members 4+2t / 5+2t in file order (Forecaster.cu:94,108)

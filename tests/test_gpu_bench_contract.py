@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10", "--cpu-iterations", "5"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
@@ -34,9 +34,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert 0.5 < r["frac"] < 1.0, "the streaming kernel should sit between 50 % and 100 % of the HBM peak"
     # achieved = algorithmic bytes per launch / average launch time; the PMC traffic may not be far above the algorithmic bytes
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] < 1.05 * r["algorithmic_bytes_per_launch"]
+    # traffic is carried over from profiles/traffic.json (a rocprofv3 --pmc pass of its own), never measured by this run:
+    # the line must say so, and must drop the number when the kernels have changed since it was collected
+    ts = r["traffic_source"]
+    assert ts["measured_in_this_run"] is False
+    assert (r["traffic"] is not None) == bool(ts.get("matches_current_kernels"))
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "iterations/s" and c["value"] > 0
+    assert c["scaled_by_nodes"] is False and "10864 nodes" in c["sample"]     # timed on the bench workload itself
     assert d["value"] > 10 * c["value"]                  # north_star: >= 10x the host-CPU baseline at 1 GPU

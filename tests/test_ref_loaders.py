@@ -4,7 +4,8 @@ files written by rapidnet_amd.synth must read back identically (to fp32, the ref
 
 The reference's ScenarioTree constructor writes past two of its heap blocks (it allocates N / N+1 entries for
 nodesPerStage / nodesPerStageCumul but the JSON carries N+1 / N+2, ScenarioTree.cu:66-75), so its code is only ever
-run in a CHILD process that leaves through os._exit(): `python tests/test_ref_loaders.py <directory>`."""
+run in a CHILD process that leaves through os._exit(): `python tests/test_ref_loaders.py <directory>`, with a
+heap-padding preload (oracle/malloc_pad.c, built by oracle/build_ref.sh) so that the overrun cannot reach a chunk header."""
 import ctypes as C
 import json
 import os
@@ -87,8 +88,16 @@ def _check_dir(d):
         assert _close(lib.ref_forecaster_demand(h), dh) and _close(lib.ref_forecaster_prices(h), ah)
 
 
+PAD = os.path.join(ROOT, "oracle", "_ref", "libmalloc_pad.so")
+
+
 def _check_in_child(directory):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), directory], capture_output=True, text=True, timeout=300)
+    # the child preloads oracle/malloc_pad.c: every heap request is padded, so the reference constructor's 4-byte overrun
+    # (ScenarioTree.cu:66-75) lands in padding instead of the next chunk's header whatever the heap layout is
+    env = dict(os.environ)
+    if os.path.exists(PAD):
+        env["LD_PRELOAD"] = PAD + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), directory], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "REF_LOADERS_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 

@@ -1,5 +1,8 @@
 """Median FETCH_SIZE / WRITE_SIZE per launch and kernel from two rocprofv3 --pmc passes -> the JSON kept in profiles/traffic.json."""
-import csv, glob, json, os, statistics, sys
+import csv, glob, json, os, statistics, subprocess, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rapidnet_amd import build as _build  # noqa: E402
 
 
 def load(directory, counter):
@@ -30,7 +33,15 @@ def total(prefix):
     return None
 
 
+def _git_head():
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
 print(json.dumps({
+    "kernels_sha256": _build.kernel_sources_sha256(), "collected_at_commit": _git_head(),
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_traffic.sh), bench.py --steps 12, "
               "barcelona493 fp64, medians per launch",
     "correction": "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request on wide streaming reads: MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KiB*1024",
