@@ -73,6 +73,9 @@ struct SweepArgs {
     // optimistic exchange: the all-reduced payload ends with the tree-global dist^2 of the previous iteration; the first
     // crown kernel after the all-reduce checks it against the thresholds (no extra launch)
     const T *distTail; double thrX, thrS; void *iterState;
+    // 0: the primal iterates x, u, v are not stored by this sweep (inner iterations of a device-resident batch: only Hx feeds
+    // the dual update; the last iteration of every batch and every step-wise call store them)
+    int writePrimal;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -894,7 +897,7 @@ __device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc
             if (EPI == EPI_V) r = auxv[j][reg] + scale * r;
             if (EPI == EPI_Z) r = auxv[j][reg] + r;
             const bool live = t < tiles && gr < g.m;
-            if (live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
+            if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;   // out == nullptr: the result only lives in sOut
             if (sOut && live) sOut[col * SO + gr] = nodeOk ? r : (T)0;
         }
     }
@@ -1107,7 +1110,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         run = uv - uh[dd];                                 // what a child reads back: u_par - uhat_par
                         if (writer[dd]) {
                             const T spc = a.tr.sqrtp[anc[dd]];
-                            a.u[(size_t)anc[dd] * nu + t] = uv;
+                            if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
                             a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
                         }
                     }
@@ -1128,7 +1131,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         const size_t node = (size_t)cum[k + j] + s;
                         run += dv[j];
                         const T uv = uh[j] + run;
-                        a.u[node * nu + t] = uv;
+                        if (a.writePrimal) a.u[node * nu + t] = uv;
                         a.hx[node * ny + 2 * nx + t] = sp * d0[j] * uv;
                     }
                 }
@@ -1151,7 +1154,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         if (writer[dd]) {
                             const T spc = a.tr.sqrtp[anc[dd]];
                             a.bw[(size_t)anc[dd] * nx + j0] = bw;
-                            a.x[(size_t)anc[dd] * nx + j0] = xr;
+                            if (a.writePrimal) a.x[(size_t)anc[dd] * nx + j0] = xr;
                             a.hx[(size_t)anc[dd] * ny + j0] = spc * dyAll[(size_t)k * ny + j0] * xr;
                             a.hx[(size_t)anc[dd] * ny + nx + j0] = spc * dyAll[(size_t)k * ny + nx + j0] * xr;
                         }
@@ -1177,7 +1180,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         const size_t node = (size_t)cum[k + j] + s;
                         bw += dv[j];
                         xr += ev[j] + bw;
-                        a.x[node * nx + j0] = xr;
+                        if (a.writePrimal) a.x[node * nx + j0] = xr;
                         a.hx[node * ny + j0] = sp * d0[j] * xr;
                         a.hx[node * ny + nx + j0] = sp * d1[j] * xr;
                     }
@@ -1209,7 +1212,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
 #pragma unroll
                     for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                         if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
-                    a.u[(size_t)j * nu + t] = uv;
+                    if (a.writePrimal) a.u[(size_t)j * nu + t] = uv;
                     a.hx[(size_t)j * ny + 2 * nx + t] = spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv;
                 } else {
                     const int j0 = t - nu;
@@ -1222,7 +1225,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                         if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
                     a.bw[(size_t)j * nx + j0] = bw;
-                    a.x[(size_t)j * nx + j0] = xr;
+                    if (a.writePrimal) a.x[(size_t)j * nx + j0] = xr;
                     a.hx[(size_t)j * ny + j0] = spj * dyAll[(size_t)kj * ny + j0] * xr;
                     a.hx[(size_t)j * ny + nx + j0] = spj * dyAll[(size_t)kj * ny + nx + j0] * xr;
                 }
@@ -1542,6 +1545,224 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
                 a.st->ticket = 0;
             }
         }
+    }
+}
+
+// Main pass of the fused dual update, stage-tiled (the default whenever ny is a whole number of 16-byte vectors).
+// k_dual_fused above walks the flat element range with a grid stride; to rebuild the scaled bounds it needs, per 16 bytes of
+// payload, ten 8-byte table gathers, two of them (stageOf -> dy) a dependent L2 round trip behind the in-order vmcnt of the
+// HBM loads: 23-25 us for 104 MB where a bare "3 reads + 2 writes" kernel takes 18 us on the same box
+// (tools/probes/probe_stream.hip).  Here a workgroup owns a tile of consecutive 16-byte vectors INSIDE ONE STAGE, found by
+// arithmetic on the block index (stages >= cs all have K nodes: the chain region of the tree; the few crown nodes in front
+// of it are handled by the first `crownBlocks` workgroups, which look the stage up per vector).  The stage is then
+// wave-uniform, the preconditioner row dy[stage] and the bounds are three 16-byte vector loads at addresses known up front,
+// sqrt(p_i) one more, and all seven loads of a vector are requested together: one memory round trip, no dependent chain.
+// Same arithmetic, element by element, as k_dual_fused (dual_elem); the partials (one per workgroup) are folded by the same
+// bookkeeping code.
+#ifndef RN_DUAL_ABL
+#define RN_DUAL_ABL 0   // timing ablations of k_dual_stage (tools/sweep_variants.sh; results are WRONG when set): bit 0 = no table loads,
+#endif                  // bit 1 = no reductions / partials, bit 2 = no stores
+struct DualStageShape {
+    int cs, K, node0;        // first regular stage, nodes per regular stage, first node of stage cs
+    int bps, crownBlocks;    // workgroups per regular stage; leading workgroups that cover the nodes [0, node0)
+    int vpn;                 // 16-byte vectors per node (ny / VN)
+    unsigned int vpnMagic;   // floor(2^32 / vpn) + 1: j / vpn == umulhi(j, vpnMagic) for j < 2^32 / vpn
+    int trips;               // vectors per thread; a tile is ELT_THREADS * trips vectors
+    double lnNext;           // extrapolation parameter of the NEXT iteration, by value: no st->it -> lamNext[] load chain in front of
+                             // the streams (every workgroup would pay those two dependent scalar round trips before its first load)
+};
+// Wave64 reductions on the VALU: DPP row shifts inside the 16-lane rows, then the gfx9 row broadcasts (row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3); the wave's result ends up in lane 63 and is read back with v_readlane.
+// __shfl_down compiles to ds_bpermute_b32 -- two per double, through the CU's ONE LDS pipe: the six-step arg-max fold of the
+// fused dual update was 96 of them per wave, ~4 us of LDS time per CU when all 27 resident waves reach their tail together
+// (measured: the kernel without its reductions ran 3.7 us faster; nothing else in it touches the LDS pipe).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+    const int rl = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROWMASK, 0xf, false);
+    const int rh = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {   // lane must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ long long readlane_i64(long long x, int lane) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(x & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
+    return ((long long)hi << 32) | (long long)lo;
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association => bitwise repeatable
+    x += dpp_f64<0x111, 0xf>(0.0, x);   // row_shr:1
+    x += dpp_f64<0x112, 0xf>(0.0, x);   // row_shr:2
+    x += dpp_f64<0x114, 0xf>(0.0, x);   // row_shr:4
+    x += dpp_f64<0x118, 0xf>(0.0, x);   // row_shr:8  -> lane 15 of every row holds the row's sum
+    x += dpp_f64<0x142, 0xa>(0.0, x);   // row_bcast:15 -> rows 1, 3
+    x += dpp_f64<0x143, 0xc>(0.0, x);   // row_bcast:31 -> rows 2, 3
+    return readlane_f64(x, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double x, double identity) {
+    x = fmax(x, dpp_f64<0x111, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x112, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x114, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x118, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x142, 0xa>(identity, x));
+    x = fmax(x, dpp_f64<0x143, 0xc>(identity, x));
+    return readlane_f64(x, 63);
+}
+// wave-wide arg-max of |.| with the reference's tie rule (cublasIsamax: the FIRST index of the largest magnitude,
+// SmpcController.cu:1487-1494): max by DPP, then the lane holding it -- almost always exactly one -- is read back; ties are
+// resolved by index in a (wave-uniform) loop over the tied lanes.  absV < 0 marks "no entry".  Result in every lane.
+__device__ __forceinline__ void wave_argmax(double &absV, double &val, long long &idx) {
+    const double m = wave_max_f64(absV, -1.0);
+    if (m < 0.0) { absV = -1.0; val = 0.0; idx = 0x7fffffffffffffffLL; return; }
+    unsigned long long tie = __ballot(absV == m);
+    int src = (int)__ffsll((long long)tie) - 1;
+    if (tie & (tie - 1)) {
+        long long best = readlane_i64(idx, src);
+        for (unsigned long long t = tie & (tie - 1); t; t &= t - 1) {
+            const int l = (int)__ffsll((long long)t) - 1;
+            const long long il = readlane_i64(idx, l);
+            if (il < best) { best = il; src = l; }
+        }
+    }
+    absV = m; val = readlane_f64(val, src); idx = readlane_i64(idx, src);
+}
+
+// one 16-byte vector of the tile with everything its update needs (all seven loads are independent)
+template <typename T>
+struct DualSlot {
+    typename VecOf<T>::type hx, w, yp, blo, bhi, dy;
+    T sp;
+    int c;            // column of the vector's first element
+    long long iv;     // global vector index
+    bool on;
+};
+template <typename T>
+struct DualAcc {      // per-thread running reductions; arg-max keeps the signed entry (|.| is recomputed in the compare) and
+    double d2x = 0, d2s = 0, valXi = 0, valPsi = 0;   // the 32-bit element index of its first occurrence (strict >, ascending walk)
+    unsigned int idxXi = 0xffffffffu, idxPsi = 0xffffffffu;
+};
+template <typename T>
+__device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T> &a, const DualStageShape &g, int trip, int jbase, int cnt,
+                                               int nodeFirst, int stageU, bool crownBlock) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    const int off = trip * ELT_THREADS + (int)threadIdx.x;
+    s.on = off < cnt;
+    const unsigned int J = (unsigned int)(jbase + (s.on ? off : 0));
+    const int q = (int)__umulhi(J, g.vpnMagic);
+    const int node = nodeFirst + q;
+    s.c = ((int)J - q * g.vpn) * VN;
+    s.iv = (long long)nodeFirst * g.vpn + J;
+    int stage = stageU;
+    if (crownBlock) stage = a.stageOf[node];
+    s.hx = reinterpret_cast<const VT *>(a.hx)[s.iv]; s.w = reinterpret_cast<const VT *>(a.w)[s.iv];
+    s.yp = reinterpret_cast<const VT *>(a.yprev)[s.iv];
+#if RN_DUAL_ABL & 1
+    s.sp = (T)1; for (int e = 0; e < VN; e++) { s.dy[e] = (T)1; s.blo[e] = (T)-1; s.bhi[e] = (T)stage; }
+#else
+    s.sp = a.sqrtp[node];
+    s.dy = *reinterpret_cast<const VT *>(a.dy + (size_t)stage * a.ny + s.c);
+    s.blo = *reinterpret_cast<const VT *>(a.blo + s.c);
+    s.bhi = *reinterpret_cast<const VT *>(a.bhi + s.c);
+#endif
+}
+template <typename T, bool MATERIALIZE>
+__device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualArgs<T> &a, T ln, DualAcc<T> &r) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    if (!s.on) return;
+    VT yn, wn, z, res;
+    const long long i0 = s.iv * VN;
+    const bool counted = a.countCrown || i0 >= a.crownElems;
+#pragma unroll
+    for (int e = 0; e < VN; e++) {
+        const int c = s.c + e;
+        const bool isBox = c < a.nx, isXi = c < 2 * a.nx;
+        const T k = s.sp * s.dy[e];
+        const T lo = k * s.blo[e];
+        const T hi = (isXi && !isBox) ? s.bhi[e] : k * s.bhi[e];
+        const DualOut<T> o = dual_elem<T, false>(s.hx[e], s.w[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
+        yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
+#if !(RN_DUAL_ABL & 2)
+        const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
+        r.d2x += isBox ? dd : 0.0;
+        r.d2s += (isXi && !isBox) ? dd : 0.0;
+        const double rv = (double)o.res;
+        const unsigned int ie = (unsigned int)i0 + (unsigned int)e;
+        const bool upX = isXi && (fabs(rv) > fabs(r.valXi) || r.idxXi == 0xffffffffu);
+        const bool upP = !isXi && (fabs(rv) > fabs(r.valPsi) || r.idxPsi == 0xffffffffu);
+        r.valXi = upX ? rv : r.valXi; r.idxXi = upX ? ie : r.idxXi;
+        r.valPsi = upP ? rv : r.valPsi; r.idxPsi = upP ? ie : r.idxPsi;
+#endif
+    }
+#if RN_DUAL_ABL & 4
+    if (yn[0] == (T)1.2345e-30) reinterpret_cast<VT *>(a.ynew)[s.iv] = wn;
+#else
+    reinterpret_cast<VT *>(a.ynew)[s.iv] = yn;
+    reinterpret_cast<VT *>(a.wnext)[s.iv] = wn;
+    if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[s.iv] = z; reinterpret_cast<VT *>(a.res)[s.iv] = res; }
+#endif
+    (void)counted;
+}
+// PIPE = 1: one vector at a time;  PIPE = 2: double-buffered -- the loads of trip t+1 are requested before trip t is consumed, so
+// a wave always has a trip in flight (the kernel lives on memory-level parallelism: its VALU phase is a gap in the streams)
+template <typename T, bool MATERIALIZE, int PIPE>
+__global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualStageShape g) {
+    __shared__ Partial sh_p[ELT_THREADS / 64];
+    const T ln = (T)g.lnNext;
+    const int vpn = g.vpn, tile = ELT_THREADS * g.trips;
+    const bool crownBlock = (int)blockIdx.x < g.crownBlocks;
+    int stageU = 0, nodeFirst = 0, jbase, cnt;
+    if (crownBlock) {
+        jbase = (int)blockIdx.x * tile;
+        cnt = g.node0 * vpn - jbase;
+    } else {
+        const int rb = (int)blockIdx.x - g.crownBlocks, sIdx = rb / g.bps, lb = rb - sIdx * g.bps;
+        stageU = g.cs + sIdx; nodeFirst = g.node0 + sIdx * g.K;
+        jbase = lb * tile;
+        cnt = g.K * vpn - jbase;
+    }
+    cnt = cnt < tile ? cnt : tile;
+    DualAcc<T> r;
+    if (PIPE == 1) {
+        for (int t = 0; t < g.trips; t++) {
+            DualSlot<T> s;
+            dual_slot_load<T>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE>(s, a, ln, r);
+        }
+    } else {
+        DualSlot<T> sA, sB;
+        dual_slot_load<T>(sA, a, g, 0, jbase, cnt, nodeFirst, stageU, crownBlock);
+        for (int t = 0; t < g.trips; t += 2) {
+            const bool hasB = t + 1 < g.trips;
+            if (hasB) dual_slot_load<T>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE>(sA, a, ln, r);
+            if (t + 2 < g.trips) dual_slot_load<T>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
+            if (hasB) dual_slot_use<T, MATERIALIZE>(sB, a, ln, r);
+        }
+    }
+#if RN_DUAL_ABL & 2
+    if (r.d2x == 1.2345e-30) a.partials[blockIdx.x] = Partial{r.d2x, r.d2s, 0, r.valXi, 0, r.valPsi, r.idxXi, r.idxPsi};
+    return;
+#endif
+    double valXi = r.valXi, valPsi = r.valPsi;
+    long long idxXi = r.idxXi == 0xffffffffu ? 0x7fffffffffffffffLL : (long long)r.idxXi;
+    long long idxPsi = r.idxPsi == 0xffffffffu ? 0x7fffffffffffffffLL : (long long)r.idxPsi;
+    double absXi = r.idxXi == 0xffffffffu ? -1.0 : fabs(valXi), absPsi = r.idxPsi == 0xffffffffu ? -1.0 : fabs(valPsi);
+    const double d2x = wave_sum_f64(r.d2x), d2s = wave_sum_f64(r.d2s);
+    wave_argmax(absXi, valXi, idxXi);
+    wave_argmax(absPsi, valPsi, idxPsi);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh_p[wave] = Partial{d2x, d2s, absXi, valXi, absPsi, valPsi, idxXi, idxPsi};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Partial p = sh_p[0];
+        for (int k = 1; k < ELT_THREADS / 64; k++) {
+            p.d2x += sh_p[k].d2x; p.d2s += sh_p[k].d2s;
+            better(p.absXi, p.valXi, p.idxXi, sh_p[k].absXi, sh_p[k].valXi, sh_p[k].idxXi);
+            better(p.absPsi, p.valPsi, p.idxPsi, sh_p[k].absPsi, sh_p[k].valPsi, sh_p[k].idxPsi);
+        }
+        a.partials[blockIdx.x] = p;
     }
 }
 

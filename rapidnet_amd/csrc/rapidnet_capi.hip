@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
@@ -30,6 +31,12 @@
 #endif
 #ifndef RN_FOLD_ROOT
 #define RN_FOLD_ROOT 1
+#endif
+#ifndef RN_DUAL_STAGE
+#define RN_DUAL_STAGE 1   // 1: stage-tiled main pass of the fused dual update (k_dual_stage) whenever the shape allows it
+#endif
+#ifndef RN_DUAL_STAGE_MAX_BLOCKS
+#define RN_DUAL_STAGE_MAX_BLOCKS 16384
 #endif
 #ifndef RN_GEMM_SLAB
 #define RN_GEMM_SLAB 1   // 1: slab kernels (k_gemm_slab / fused k_gemm_vlv); 0: always the tile kernel k_gemm_shared
@@ -221,6 +228,10 @@ struct Ctx : CtxBase {
     double stepSize = 1e-4, penX = 1e6, penXs = 1e4, wEco = 1.0;
     int useErrD = 1, useErrP = 1;
     int eltBlocks = 1;
+    DualStageShape dshape{};   // k_dual_stage launch shape (dual_stage_setup)
+    int dualU = 0;             // vectors a k_dual_stage thread keeps in flight; 0: shape not eligible, the flat k_dual_fused runs
+    int dualBlocks = 1;        // workgroups (= partials) of the main pass of the fused dual update
+    int mainPartials = 1;      // partials the most recent main pass left in d_partials (k_dual_stage or k_dual_fused)
     // profiling
     int prof = 0;
     struct EvPair { int cls; hipEvent_t a, b; };
@@ -291,6 +302,7 @@ struct Ctx : CtxBase {
         a.x = d_x; a.u = d_u; a.hx = d_hx;
         a.distTail = (carryTail && a.cutSums) ? d_cut + cut_tail_offset() : nullptr;
         a.thrX = penX / stepSize; a.thrS = penXs / stepSize; a.iterState = d_state;
+        a.writePrimal = 1;
         return a;
     }
     long long ntot() const { return (long long)d.nodes * ny; }
@@ -377,7 +389,7 @@ struct Ctx : CtxBase {
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
         DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
-        DA(d_state, 1) DA(d_partials, ELT_MAX_BLOCKS) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
+        DA(d_state, 1) DA(d_partials, std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
 #undef DA
         std::vector<double> sq(nodes);
         for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
@@ -393,6 +405,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_hx, 0, n * ny * sizeof(T), stream));
         const long long want = (ntot() + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
         eltBlocks = (int)std::max<long long>(1, std::min<long long>(ELT_MAX_BLOCKS, want));
+        dual_stage_setup();
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         return apg_reset();
     }
@@ -658,6 +671,7 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
         GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes};
+        if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), d_v, nv, d_lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
@@ -670,12 +684,19 @@ struct Ctx : CtxBase {
         launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
         launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
+    // crown handling of the forward sweep: 0 = crown launches of their own; 1 = every chain workgroup walks its crown path and
+    // the first descendant chain of a crown node writes it; 2 (sharded) = crown nodes dealt round-robin to the workgroups
+    int fold_crown_mode(int cs, bool sharded) const {
+        return (RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH) ? (sharded ? (h_stageCum[cs] <= 256 ? 2 : 0) : 1) : 0;
+    }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
     // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
     // hessianInput != nullptr: SmpcController::computeHessianOracalGlobalFbe (SmpcController.cu:884-1055) -- the same
     // sweep evaluated at `hessianInput` with sigma = 0 and every affine term zero, writing xdir / udir / H * dir
-    int launch_sweep(int phase = 0, const T *hessianInput = nullptr) {
+    // primalOut = false (inner iterations of a batch): x, u and v are not stored, only Hx (what the dual update reads)
+    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true) {
         SweepArgs<T> a = sweep_args();
+        a.writePrimal = primalOut ? 1 : 0;
         if (hessianInput) {
             a.w = hessianInput;
             a.beta = d_zero; a.uhat = d_zero; a.e = d_zero; a.eb = d_zero; a.bw0 = d_zero;
@@ -705,7 +726,7 @@ struct Ctx : CtxBase {
             // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
             FinArgs fin{};
             const bool ride = pendingFin && !a.cutSums;
-            if (ride) { fin = FinArgs{d_partials, eltBlocks, d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
+            if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
             hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
         }
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
@@ -714,7 +735,7 @@ struct Ctx : CtxBase {
             if (phase == 2) return RN_OK;              // payload already summed by the caller
             // optimistic exchange: the bookkeeping of the previous iteration's dual update rides in this launch
             FinArgs fin{};
-            if (pendingFin) fin = FinArgs{d_partials, eltBlocks, d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
+            if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
             pendingFin = false;
             if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
@@ -748,7 +769,7 @@ struct Ctx : CtxBase {
         // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch.
         // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
         // because a replicated crown node may have no chain on this rank while its Hx still feeds the replicated duals
-        const int foldCrown = (RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH) ? (a.cutSums ? (h_stageCum[cs] <= 256 ? 2 : 0) : 1) : 0;
+        const int foldCrown = fold_crown_mode(cs, a.cutSums != nullptr);
         if (!foldCrown) {
             if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
@@ -758,6 +779,54 @@ struct Ctx : CtxBase {
         RN_HIP(hipGetLastError());
         return RN_OK;
     }
+    // launch shape of k_dual_stage: one tile of ELT_THREADS * trips 16-byte vectors per workgroup, tiles never cross a stage
+    void dual_stage_setup() {
+        dualU = 0; dualBlocks = eltBlocks;
+        constexpr int VN = 16 / (int)sizeof(T);
+        if (!RN_DUAL_REGEN || !RN_DUAL_STAGE || ny % VN) return;
+        const int vpn = ny / VN, cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs], node0 = h_stageCum[cs];
+        const unsigned long long lim = (1ull << 32) / (unsigned)vpn;          // range in which umulhi(j, magic) == j / vpn
+        if ((unsigned long long)K * vpn >= lim || (unsigned long long)node0 * vpn >= lim || (unsigned long long)d.nodes * vpn >= (1ull << 31)) return;
+        int forced = 0;
+        if (const char *e = std::getenv("RAPIDNET_DUAL_TRIPS")) forced = std::atoi(e);   // tuning runs
+        // workgroups: at most one resident round (numCUs x 8 workgroups of 4 waves) so that every workgroup's loads start at
+        // once; measured on the 493-scenario tree: 1 trip (5 113 workgroups) 21.9 us, 2-3 trips 20.8, 4-6 trips 21.6-24 us
+        const long long resident = (long long)numCUs * 8;
+        for (int pass = 0; pass < 2 && dualU == 0; pass++)
+            for (int trips : {1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64}) {
+                if (forced > 0 && trips != forced) continue;
+                const long long tile = (long long)ELT_THREADS * trips;
+                const long long bps = ((long long)K * vpn + tile - 1) / tile, cb = ((long long)node0 * vpn + tile - 1) / tile;
+                const long long blocks = cb + bps * (d.N - cs);
+                if (blocks > (pass == 0 && forced <= 0 ? resident : (long long)RN_DUAL_STAGE_MAX_BLOCKS)) continue;
+                dshape = DualStageShape{cs, K, node0, (int)bps, (int)cb, vpn, (unsigned int)((1ull << 32) / (unsigned)vpn) + 1u, trips, 0.0};
+                dualU = 1;
+                if (const char *e = std::getenv("RAPIDNET_DUAL_PIPE")) dualU = std::atoi(e) >= 2 ? 2 : 1;   // tuning runs
+                dualBlocks = (int)blocks;
+                break;
+            }
+    }
+    // main pass of the fused dual update (prox as a pure projection, residual, dual update, arg-max partials, next
+    // extrapolation); `flat` forces the grid-stride kernel (eltBlocks partials), which the exact multi-GPU path folds
+    void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false) {
+        if (flat || dualU == 0) {
+            if (materialize) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            mainPartials = eltBlocks;
+            return;
+        }
+        mainPartials = dualBlocks;
+        DualStageShape g = dshape;
+        g.lnNext = h_lam[h_it + 1];   // ensure_tables(h_it + n) has run: the table covers every iteration of the batch
+        if (dualU == 1) {
+            if (materialize) hipLaunchKernelGGL((k_dual_stage<T, true, 1>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 1>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+        } else {
+            if (materialize) hipLaunchKernelGGL((k_dual_stage<T, true, 2>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 2>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+        }
+    }
+    int main_partials() const { return mainPartials; }
     DualArgs<T> dual_args() const {
         DualArgs<T> a{};
         a.hx = d_hx; a.w = p_acc; a.yprev = p_upd; a.lo = d_lo; a.hi = d_hi;
@@ -845,17 +914,16 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            if (int rc = launch_sweep()) { carryTail = false; pendingFin = false; return rc; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { carryTail = false; pendingFin = false; return rc; }
             DualArgs<T> a = dual_args();
             const hipEvent_t *e2 = prof_begin(2);
-            if (k == n - 1) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            launch_dual_main(a, k == n - 1);
             prof_end(e2);
             // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
             // batch gets a launch of its own
             if (k == n - 1) {
                 const hipEvent_t *e3 = prof_begin(3);
-                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_cut + tail,
+                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, d_cut + tail,
                                    d_hist, d_histParts, histCap, -1.0, -1.0);
                 prof_end(e3);
             } else pendingFin = true;
@@ -920,15 +988,14 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            if (int rc = launch_sweep()) { pendingFin = false; return rc; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { pendingFin = false; return rc; }
             DualArgs<T> a = dual_args();
             const hipEvent_t *e2 = prof_begin(2);
-            if (k == n - 1) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            launch_dual_main(a, k == n - 1);
             prof_end(e2);
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
                 const hipEvent_t *e3 = prof_begin(3);
-                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, (T *)nullptr,
+                hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, (T *)nullptr,
                                    d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize);
                 prof_end(e3);
             } else pendingFin = true;
@@ -974,15 +1041,15 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            if (int rc = launch_sweep()) return rc;
-            DualArgs<T> a = dual_args();
             const bool last = (k == n - 1);
+            if (int rc = launch_sweep(0, nullptr, last)) return rc;
+            DualArgs<T> a = dual_args();
             const hipEvent_t *e2 = prof_begin(2);
-            if (last) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-            else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
+            const bool exactSharded = comm && cutStage > 0;   // its fix-up pass and k_finalize fold eltBlocks partials: flat kernel
+            launch_dual_main(a, last, exactSharded);
             prof_end(e2);
             const hipEvent_t *e3 = prof_begin(3);
-            if (comm && cutStage > 0) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
+            if (exactSharded) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
                 hipLaunchKernelGGL(k_reduce_dist, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
                 const int rc = g_nccl.AllReduce(d_dist2, d_dist2, 2, 8 /*ncclFloat64*/, 0 /*ncclSum*/, comm, stream);
                 RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist) failed");
@@ -992,7 +1059,7 @@ struct Ctx : CtxBase {
                 hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
             } else {   // single GPU: the (small) fix-up launch also decides and does the bookkeeping (kernels.hpp, decideHere)
                 a.finalizedEarly = 1;
-                a.decideHere = 1; a.itHost = h_it; a.nMain = eltBlocks; a.mainPartials = d_partials; a.partials = d_partials2;
+                a.decideHere = 1; a.itHost = h_it; a.nMain = main_partials(); a.mainPartials = d_partials; a.partials = d_partials2;
                 const int fixBlocks = std::min(eltBlocks, RN_FIXUP_BLOCKS);
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(fixBlocks), dim3(ELT_THREADS), 0, stream, a);
