@@ -10,7 +10,8 @@ residual, dual update -- the loop body of SmpcController::algorithmApg, SmpcCont
 headline workload of BASELINE.json: Barcelona-style DWN (63 states / 114 inputs / nv = 97), N = 24, 493 scenarios
 (17 x 29 tree, 10 864 nodes), fp64, synthetic data (rapidnet_amd/synth.py, seed 20260103), all inputs resident in HBM.
 For N > 1 the SAME tree is sharded by subtree below stage 2 (18 crown nodes replicated, 493 chains dealt round-robin)
-with one RCCL all-reduce of the cut parents' children sums per iteration => strong scaling.
+with one RCCL all-reduce of the cut parents' children sums per iteration => strong scaling.  torch.distributed (gloo) only
+carries the rendezvous, the ncclUniqueId and the timing barriers; the data path is the library's own ncclAllReduce.
 
 Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
 """
@@ -130,12 +131,15 @@ def main():
     os.dup2(2, 1)
     if sharded:
         import torch
-        import torch.distributed as dist  # rendezvous, barrier and max-over-ranks only; the data path is RCCL in C
+        import torch.distributed as dist
 
+        # torch.distributed is the CONTROL plane only (rendezvous, the 128-byte ncclUniqueId, barriers, max over ranks) and
+        # runs over gloo on the host: the one RCCL communicator on each device is the solver library's own
+        # (rn_comm_init), whose ncclAllReduce sits on the solver's stream -- torch never creates a second one
         torch.cuda.set_device(local_rank)
         if "MASTER_ADDR" not in os.environ:   # --force-shard without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", init_method="env://")
     from rapidnet_amd import capi, synth
     from rapidnet_amd import partition
 
@@ -159,6 +163,12 @@ def main():
         dist.broadcast_object_list(box, src=0)
         uid, uid_error = box
     fallback_reason = [None]
+    rccl_library = None
+    if sharded:
+        try:
+            rccl_library = capi.comm_library()
+        except Exception as e:
+            rccl_library = "unavailable: %s" % e
 
     def run_mode(structured, steps, warmup, profile_steps, new_uid=None):
         if sharded:
@@ -176,7 +186,7 @@ def main():
                     s.commInit(rank, world, new_uid)
                 except capi.RapidNetError as e:
                     ok, err = 0, str(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 fallback_reason[0] = err or "a peer rank could not create the communicator"
@@ -203,9 +213,9 @@ def main():
                 theta[0], theta[1] = theta[1], 0.5 * (np.sqrt(theta[1] ** 4 + 4 * theta[1] ** 2) - theta[1] ** 2)
                 s.dualExtrapolationStep(lam)
                 s.debugSweepPhase(1)
-                payload = torch.from_numpy(s.debugCutBuffer(n_cut)).cuda()
+                payload = torch.from_numpy(s.debugCutBuffer(n_cut))
                 dist.all_reduce(payload)
-                s.debugCutBuffer(n_cut, payload.cpu().numpy())
+                s.debugCutBuffer(n_cut, payload.numpy())
                 s.debugSweepPhase(2)
                 s.proximalFunG(); s.computeFixedPointResidual(); s.dualUpdate()
 
@@ -226,7 +236,7 @@ def main():
         if dist is not None:
             import torch
 
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
@@ -326,6 +336,9 @@ def main():
                 "parallelism": "1 GPU" if not sharded else ("subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage if not fallback_reason[0]
                                                             else "subtree sharding below stage %d, FALLBACK exchange through torch.distributed, step-wise (%s)" % (cut_stage, fallback_reason[0]))},
             "local_nodes": int(tree["nodes"][0]),
+            "rccl": None if not sharded else {"ranks": world, "library": rccl_library, "communicator": "one per device, owned by librapidnet_hip (rn_comm_init); "
+                                              "ncclUniqueId and barriers travel over torch.distributed/gloo",
+                                              "exchange": "torch.distributed fallback: " + fallback_reason[0] if fallback_reason[0] else "ncclAllReduce on the solver's stream"},
             "roofline": roofline, "kernel_classes": classes,
         }
         if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates

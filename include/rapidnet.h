@@ -186,6 +186,8 @@ int rn_compute_hessian_oracle(rn_ctx *ctx);                 /* computeHessianOra
 int rn_compute_gradient_fbe(rn_ctx *ctx);                   /* computeGradientFbe                     :1077-1097 */
 int rn_update_fixed_point_residual_nama(rn_ctx *ctx);       /* updateFixedPointResidualNamaAlgorithm  :1060-1072 */
 int rn_compute_lbfgs_direction(rn_ctx *ctx);                /* computeLbfgsDirection                  :1103-1237 */
+int rn_update_lbfgs_buffer(rn_ctx *ctx);                    /*   its first half:  updateLbfgsBuffer   :1103-1169 */
+int rn_two_loop_recursion_lbfgs(rn_ctx *ctx);               /*   its second half: twoLoopRecursionLbfgs :1175-1229 */
 int rn_compute_value_fbe(rn_ctx *ctx, double *value);       /* computeValueFbe                        :1416-1476 */
 int rn_line_search_lbfgs_update(rn_ctx *ctx, double valueFbeY, double *tau);     /* computeLineSearchLbfgsUpdate    :1242-1305 */
 int rn_line_search_ame_lbfgs_update(rn_ctx *ctx, double valueAmeY, double *tau); /* computeLineSearchAmeLbfgsUpdate :1311-1414 */
@@ -229,6 +231,9 @@ void *rn_stream(rn_ctx *ctx);
  * distributed by the caller (bench.py uses torch.distributed for that). */
 int rn_comm_unique_id(void *id128 /* 128 bytes out */);
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
+/* Path of the RCCL image the library bound (an image the process has already loaded -- e.g. the one PyTorch links --
+ * is reused, never a second copy), written as a C string into buf; RN_E_COMM when RCCL cannot be loaded. */
+int rn_comm_library(char *buf, size_t n);
 /* stage c of the (rank-local) tree whose nodes are the roots of the sharded subtrees: the children sums of the
  * stage c-1 nodes (replicated on every rank) are all-reduced once per iteration; -1 switches sharding off. */
 int rn_set_cut_stage(rn_ctx *ctx, int stage);

@@ -33,6 +33,13 @@
  *   SmpcController::computeValueFbe                         SmpcController.cu:1416-1476
  *   SmpcController::algorithmGlobalFbe / algorithmNama      SmpcController.cu:1529-1586
  *   pinned by src/test/testDataFiles/{smpcFbeTest,smpcNamaTest}.json, see tests/test_oracle_fbe_nama.py
+ * and, for the closed loop around the solve (third part of this file):
+ *   SmpcController::controlAction (both overloads)          SmpcController.cu:1607-1667 (+ projectionBox<<<1,nu>>> :1649)
+ *   SmpcController::moveForewardInTime (in-built simulator) SmpcController.cu:1679-1716
+ *   SmpcController::updateKpi, get{Economic,Smooth,Network,Safety}Kpi   SmpcController.cu:1778-1859
+ *   (Forecaster::predictDemand / predictPrices, Forecaster.cu:93-119, are file lookups: the caller passes the horizons)
+ *   The reference holds no golden vectors for these; they are short scalar loops restated line by line, checked in
+ *   tests/test_oracle_closed_loop.py against a hand computation in numpy.
  *
  * Third-party arithmetic the reference calls and that is absent from /root/reference: cuBLAS
  * (gemm/gemv/axpy/scal/nrm2/isamax, getrfBatched/getriBatched) from the CUDA toolkit 7.0/8.0.  These
@@ -100,6 +107,10 @@ typedef struct {
     real *matS, *matY, *rho;   /* (lbfgsSize + 1) columns: the reference indexes columns 1..lbfgsSize (see oracle_lbfgs_update) */
     real valueGxBox, valueGxSafe, valueGuBox;
     real *W;                   /* costW, nu x nu (computeValueFbe) */
+    /* closed loop */
+    real *controlAction;       /* devControlAction, nu (SmpcController.cuh) */
+    real *stateUpdate;         /* devStateUpdate, nx */
+    real economicKpi, smoothKpi, safeKpi, networkKpi;   /* SmpcController.cu:103-106 (zeroed by the constructor) */
 } oracle_t;
 
 static real *ralloc(size_t n) { real *p = (real *)calloc(n ? n : 1, sizeof(real)); return p; }
@@ -248,6 +259,7 @@ oracle_t *oracle_create(int nx, int nu, int nv, int nd, int N, int K, int nodes,
     o->q = ralloc((size_t)K * nx); o->r = ralloc((size_t)K * nv);
     o->stepSize = (real)1e-4; o->penaltyX = (real)1e6; o->penaltyXs = (real)1e4;
     o->W = ralloc((size_t)nu * nu);
+    o->controlAction = ralloc(nu); o->stateUpdate = ralloc(nx);
     return o;
 }
 
@@ -258,7 +270,7 @@ void oracle_destroy(oracle_t *o) {
                     o->xs, o->umin, o->umax, o->Omega, o->Theta, o->Phi, o->D, o->Psi, o->Ftil, o->Gtil, o->curX,
                     o->prevU, o->prevUhat, o->prevD, o->uhat, o->e, o->beta, o->alpha, o->sigma, o->x, o->u, o->v,
                     o->xi, o->psi, o->accXi, o->accPsi, o->updXi, o->updPsi, o->primalXi, o->primalPsi, o->dualXi,
-                    o->dualPsi, o->resXi, o->resPsi, o->q, o->r};
+                    o->dualPsi, o->resXi, o->resPsi, o->q, o->r, o->controlAction, o->stateUpdate};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(ptrs[i]);
     free(o);
 }
@@ -982,6 +994,87 @@ void oracle_lbfgs_state(oracle_t *o, int set, int *col, int *mem, double *H) {
     else { *col = o->lbfgsCol; *mem = o->lbfgsMem; *H = (double)o->lbfgsH; }
 }
 
+/* ====================================================================================================
+ * Closed loop around the solve
+ * ==================================================================================================== */
+
+/* SmpcController::controlAction(fstream&) SmpcController.cu:1633-1667 (project = 1): updateStateControl and
+ * eliminateInputDistubanceCoupling are the caller's (oracle_update_state_control / oracle_eliminate), then
+ * algorithmApg (:1646), devControlAction = devVecU[0..nu) (:1647), projectionBox<<<1,nu>>> with the SCALED bounds
+ * of node 0 (:1649; Utilities.cu:237-254), copy to the host (:1650).
+ * controlAction(real_t*) :1607-1626 (project = 0) returns devVecU[0..nu) as it is and leaves devControlAction alone. */
+void oracle_control_action(oracle_t *o, int maxIterations, int project, double *uOut) {
+    oracle_apg(o, maxIterations, NULL);
+    if (!project) {
+        for (int i = 0; i < o->nu; i++) uOut[i] = (double)o->u[i];
+        return;
+    }
+    for (int i = 0; i < o->nu; i++) {
+        real v = o->u[i];
+        if (v < o->umin[i]) v = o->umin[i]; else if (v > o->umax[i]) v = o->umax[i];
+        o->controlAction[i] = v;
+        uOut[i] = (double)v;
+    }
+}
+
+/* SmpcController::updateKpi SmpcController.cu:1778-1813.  previousControl is the configuration's prevU BEFORE it is
+ * shifted (moveForewardInTime calls updateKpi first, :1706-1708); variablePrice = the forecaster's current nominal
+ * prices (the first nu entries are used: stage 0); constantPrice = DwnNetwork::getAlpha() = costAlpha1. */
+static void update_kpi(oracle_t *o, const real *state, const real *control, const real *safeX, const real *variablePrice,
+                       real weightEconomic) {
+    real ecoKpi = 0, smKpi = 0, saKpi = 0, netKpi = 0;
+    for (int i = 0; i < o->nu; i++) {
+        ecoKpi = ecoKpi + weightEconomic * (o->alpha1[i] + variablePrice[i]) * (real)fabs((double)control[i]);   /* :1795 */
+        real deltaU = o->prevU[i] - control[i];                                                                    /* :1796 */
+        smKpi = smKpi + deltaU * deltaU;                                                                           /* :1797 */
+    }
+    for (int i = 0; i < o->nx; i++) {
+        real waterLevel = state[i] - safeX[i];                 /* :1800 */
+        if (waterLevel > 0) waterLevel = 0;                    /* :1801-1803 */
+        saKpi = saKpi + (real)fabs((double)waterLevel);        /* :1805 */
+        netKpi = netKpi + (real)fabs((double)state[i]);        /* :1806 */
+    }
+    o->economicKpi += ecoKpi; o->smoothKpi += smKpi; o->safeKpi += saKpi; o->networkKpi += netKpi;   /* :1809-1812 */
+}
+
+/* SmpcController::moveForewardInTime, in-built simulator branch (simulatorFlag = 1), SmpcController.cu:1680-1711.
+ * plantMode 0 = the reference as written: devStateUpdate = currentX (:1692); the disturbance is added to devVecX -- the
+ *   x of node 0 -- instead of the state update (:1695, a slip that only changes that output buffer); devStateUpdate +=
+ *   B devControlAction (:1697-1698): the simulated plant is x+ = x + B u.
+ * plantMode 1 = the plant of DwnNetwork.cuh:41-57 with the disturbance of node 0, x+ = x + e_0 + B u (what :1694's
+ *   comment says it computes); devVecX is left alone.
+ * Then updateKpi (:1706), setCurrentState / setPreviousControl / setpreviousdemand (:1707-1709) with
+ * previousDemand = the forecaster's nominal demand (first nd entries).  The shifted triple is returned through xOut,
+ * uOut, dOut and installed as the oracle's current state / previous control / previous demand. */
+void oracle_move_forward(oracle_t *o, const double *nominalDemand, const double *nominalPrices, const double *xsafe,
+                         double weightEconomic, int plantMode, double *xOut, double *uOut, double *dOut) {
+    const int nx = o->nx, nu = o->nu, nd = o->nd;
+    for (int i = 0; i < nx; i++) o->stateUpdate[i] = o->curX[i];
+    if (plantMode == 0) { for (int i = 0; i < nx; i++) o->x[i] += o->e[i]; }
+    else { for (int i = 0; i < nx; i++) o->stateUpdate[i] += o->e[i]; }
+    gemv_n(nx, nu, 1, o->B, nx, o->controlAction, 1, o->stateUpdate);
+    real *safeX = ralloc(nx), *price = ralloc(nu);
+    for (int i = 0; i < nx; i++) safeX[i] = (real)xsafe[i];
+    for (int i = 0; i < nu; i++) price[i] = (real)nominalPrices[i];
+    update_kpi(o, o->stateUpdate, o->controlAction, safeX, price, (real)weightEconomic);
+    free(safeX); free(price);
+    for (int i = 0; i < nx; i++) { o->curX[i] = o->stateUpdate[i]; xOut[i] = (double)o->curX[i]; }
+    for (int i = 0; i < nu; i++) { o->prevU[i] = o->controlAction[i]; uOut[i] = (double)o->prevU[i]; }
+    for (int i = 0; i < nd; i++) { o->prevD[i] = (real)nominalDemand[i]; dOut[i] = (double)o->prevD[i]; }
+}
+
+/* get{Economic,Smooth,Network,Safety}Kpi SmpcController.cu:1819-1859; which = 0 economic, 1 smooth, 2 network, 3 safety */
+double oracle_kpi(const oracle_t *o, int which, int simulationTime, const double *xsafe) {
+    if (which == 0) { real v = o->economicKpi / 3600; return (double)(v / simulationTime); }      /* :1819-1822 */
+    if (which == 1) { real v = o->smoothKpi / 3600; return (double)(v / simulationTime); }        /* :1828-1831 */
+    if (which == 2) {                                                                              /* :1837-1846 */
+        real safeLevelNorm = 0;
+        for (int i = 0; i < o->nx; i++) safeLevelNorm = safeLevelNorm + (real)xsafe[i];
+        return (double)(100 * simulationTime * safeLevelNorm / o->networkKpi);
+    }
+    return (double)o->safeKpi;                                                                     /* :1852-1854 */
+}
+
 int oracle_sizeof_real(void) { return (int)sizeof(real); }
 int oracle_final_branch_node(const oracle_t *o) { return o->finalBranchNode; }
 double oracle_dist(const oracle_t *o, int which) { return which ? (double)o->distXs : (double)o->distXcst; }
@@ -1005,7 +1098,8 @@ real *oracle_buffer(oracle_t *o, const char *name, long *count) {
     BUF("Omega", o->Omega, (size_t)o->finalBranchNode * nv * nv) BUF("Theta", o->Theta, (size_t)o->finalBranchNode * nv * nx)
     BUF("Phi", o->Phi, n * nv * 2 * nx) BUF("D", o->D, n * nv * 2 * nx)
     BUF("Psi", o->Psi, n * nv * nu) BUF("Ftil", o->Ftil, n * nv * nu) BUF("Gtil", o->Gtil, (size_t)nv * nx)
-    BUF("prevUhat", o->prevUhat, nu) BUF("curX", o->curX, nx) BUF("prevU", o->prevU, nu)
+    BUF("prevUhat", o->prevUhat, nu) BUF("curX", o->curX, nx) BUF("prevU", o->prevU, nu) BUF("prevD", o->prevD, o->nd)
+    BUF("controlAction", o->controlAction, nu) BUF("stateUpdate", o->stateUpdate, nx)
     if (o->matS) {
         size_t nall = n * (2 * nx + nu);
         BUF("prevXi", o->prevXi, n * 2 * nx) BUF("prevPsi", o->prevPsi, n * nu)

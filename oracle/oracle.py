@@ -85,6 +85,11 @@ def _lib(precision, variant=""):
         lib.oracle_fbe_nama.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.oracle_lbfgs_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.c_double)]
+        lib.oracle_control_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.oracle_move_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_kpi.restype = C.c_double
+        lib.oracle_kpi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIBS[tag] = lib
     return _LIBS[tag]
 
@@ -261,6 +266,31 @@ class Oracle:
         hist, val, tau = (np.zeros(max(iters, 1)) for _ in range(3))
         self.lib.oracle_fbe_nama(self.h, iters, hist.ctypes.data, val.ctypes.data, tau.ctypes.data)
         return hist[:iters], val[: max(iters - 1, 0)], tau[: max(iters - 1, 0)]
+
+    # --- closed loop (SmpcController.cu:1607-1716, 1778-1859) -----------------------------------------
+    def control_action(self, nominal_demand, nominal_prices, max_iterations=None, project=True, **elim):
+        """controlAction(fstream&) (project=True) / controlAction(real_t*) (project=False) at the oracle's current
+        state / previous control / previous demand."""
+        a = [np.array(self.buf(k), dtype=np.float64) for k in ("curX", "prevU", "prevD")]
+        self.update_state_control(*a)
+        self.eliminate(nominal_demand, nominal_prices, **elim)
+        n = self.max_iterations if max_iterations is None else int(max_iterations)
+        u = np.zeros(self.nu)
+        self.lib.oracle_control_action(self.h, n, int(project), u.ctypes.data)
+        return u
+
+    def move_forward(self, nominal_demand, nominal_prices, weight_economical=1.0, plant_mode=0):
+        """moveForewardInTime with the in-built simulator; returns the shifted (currentX, prevU, prevDemand)."""
+        dh, ah, xs = _f64(nominal_demand), _f64(nominal_prices), _f64(self.network["vecXsafe"])
+        x, u, d = np.zeros(self.nx), np.zeros(self.nu), np.zeros(self.nd)
+        self.lib.oracle_move_forward(self.h, dh.ctypes.data, ah.ctypes.data, xs.ctypes.data, float(weight_economical),
+                                     int(plant_mode), x.ctypes.data, u.ctypes.data, d.ctypes.data)
+        return x, u, d
+
+    def kpis(self, simulation_time):
+        """(economic, smooth, network, safety) KPI read-outs."""
+        xs = _f64(self.network["vecXsafe"])
+        return tuple(self.lib.oracle_kpi(self.h, w, int(simulation_time), xs.ctypes.data) for w in range(4))
 
     @property
     def final_branch_node(self):

@@ -28,10 +28,10 @@ SYMBOLS = [
     "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
-    "rn_comm_unique_id", "rn_comm_init", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
+    "rn_comm_unique_id", "rn_comm_init", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
-    "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_compute_value_fbe",
+    "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
 ]
 
@@ -123,6 +123,7 @@ def load():
     lib.rn_stream.restype = vp
     lib.rn_comm_unique_id.argtypes = [dp]
     lib.rn_comm_init.argtypes = [vp, ip, ip, dp]
+    lib.rn_comm_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
@@ -135,7 +136,7 @@ def load():
     lib.rn_measure_hbm_shape.argtypes = [vp, ip, C.c_size_t, C.c_size_t, ip, ip, ip, dp]
     lib.rn_set_algorithm.argtypes = [vp, ip, ip]
     for f in ("rn_fbe_reset", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe", "rn_update_fixed_point_residual_nama",
-              "rn_compute_lbfgs_direction"):
+              "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs"):
         getattr(lib, f).argtypes = [vp]
     lib.rn_algorithm_fbe_nama.argtypes = [vp, ip, dp, dp, dp]
     lib.rn_compute_value_fbe.argtypes = [vp, dp]
@@ -453,6 +454,15 @@ class Solver:
         out = np.zeros(4 * n)
         self._check(self.lib.rn_get_history_parts(self.h, int(first), int(n), out.ctypes.data))
         return out.reshape(n, 4)
+
+
+def comm_library():
+    """Path of the RCCL image librapidnet_hip bound (an already-loaded image is reused)."""
+    buf = C.create_string_buffer(4096)
+    rc = load().rn_comm_library(buf, 4096)
+    if rc != 0:
+        raise RapidNetError("rn_comm_library failed (%d)" % rc)
+    return buf.value.decode()
 
 
 def comm_unique_id():

@@ -51,8 +51,7 @@ uint_t SmpcController::controlAction(real_t *u) {
                                      ptrMySmpcConfig->getPrevDemand(), ptrMyForecaster->getNominalDemand(),
                                      ptrMyForecaster->getNominalPrices(), ptrMySmpcConfig->getMaxIterations(), 0, u);
     if (rc != RN_OK) { std::cerr << "controlAction: " << rn_last_error(ptrMyEngine->getContext()) << std::endl; return 0; }
-    for (uint_t i = 0; i < ptrMySmpcConfig->getNU(); i++) lastControl[i] = u[i];
-    return 1;
+    return 1;   // devControlAction (lastControl) is only written by the stream overload (:1647), as in the reference
 }
 
 uint_t SmpcController::controlAction(std::fstream &out) {
@@ -72,10 +71,12 @@ uint_t SmpcController::controlAction(std::fstream &out) {
     return 1;
 }
 
-// SmpcController::moveForewardInTime (SmpcController.cu:1679-1716).  In-built simulator: x+ = x + e_root + B u with the
-// control returned by the last controlAction, KPIs updated, then state / previous control / previous demand shifted.
-// (The reference's version adds e to devVecX instead of the state update, :1695 -- so its simulated plant ignores the
-// demand; here the plant equation x+ = x + B u + Gd d of DwnNetwork.cuh:41-57 is applied.)
+// SmpcController::moveForewardInTime (SmpcController.cu:1679-1716).
+// In-built simulator: the plant is advanced with the (projected) control of the last controlAction(fstream&), the KPIs
+// are accumulated with the still-unshifted previous control, then state / previous control / previous demand are shifted.
+// Default: the reference as written -- its "x = x + w" (:1695) adds the disturbance of node 0 to devVecX, the x iterate of
+// node 0, not to the state update, so the simulated plant is x+ = x + B u and that output buffer changes; reproduced
+// here, buffer included.  setSimulatorDisturbance(true): x+ = x + e_0 + B u, the plant of DwnNetwork.cuh:41-57.
 // External simulator (simulatorFlag == false): the three vectors are re-read from the configuration file.
 void SmpcController::moveForewardInTime() {
     if (!simulatorFlag) {
@@ -88,51 +89,71 @@ void SmpcController::moveForewardInTime() {
     const uint_t nx = net->getNumTanks(), nu = net->getNumControls(), nd = net->getNumDemands();
     std::vector<real_t> e(ptrMyEngine->getBufferSize(RN_BUF_E));
     ptrMyEngine->getBuffer(RN_BUF_E, e.data());
-    std::vector<real_t> x(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getCurrentX() + nx);
-    const real_t *B = net->getMatB();
-    for (uint_t i = 0; i < nx; i++) {
-        real_t s = x[i] + e[i];
-        for (uint_t j = 0; j < nu; j++) s += B[i + (size_t)j * nx] * lastControl[j];
-        x[i] = s;
+    std::vector<real_t> next(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getCurrentX() + nx);
+    if (simulatorDisturbance) {
+        for (uint_t i = 0; i < nx; i++) next[i] += e[i];
+    } else {
+        std::vector<real_t> xAll(ptrMyEngine->getBufferSize(RN_BUF_X));
+        ptrMyEngine->getBuffer(RN_BUF_X, xAll.data());
+        for (uint_t i = 0; i < nx; i++) xAll[i] += e[i];
+        ptrMyEngine->setBuffer(RN_BUF_X, xAll.data());
     }
-    updateKpi(x.data(), lastControl.data());                  // uses the still-unshifted previous control (:1706)
-    ptrMySmpcConfig->setCurrentState(x.data());
+    const real_t *B = net->getMatB();
+    for (uint_t j = 0; j < nu; j++)                             // column sweep, like the gemv it stands for
+        for (uint_t i = 0; i < nx; i++) next[i] += B[i + (size_t)j * nx] * lastControl[j];
+    updateKpi(next.data(), lastControl.data());
+    ptrMySmpcConfig->setCurrentState(next.data());
     ptrMySmpcConfig->setPreviousControl(lastControl.data());
-    std::vector<real_t> d(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalDemand() + nd);
-    ptrMySmpcConfig->setpreviousdemand(d.data());
+    std::vector<real_t> demand(ptrMyForecaster->getNominalDemand(), ptrMyForecaster->getNominalDemand() + nd);
+    ptrMySmpcConfig->setpreviousdemand(demand.data());
 }
 
-// SmpcController::updateKpi (SmpcController.cu:1769-1802)
+// Key performance indicators of one simulated step, accumulated over the closed loop (SmpcController.cu:1778-1813):
+//   economic += w_e * sum_j (alpha1_j + alphahat_j) |u_j|        smooth += || u_prev - u ||^2
+//   safety   += sum_i max(0, xs_i - x_i)                          network += sum_i |x_i|
+// alphahat = the forecaster's nominal prices of the current stage, u_prev = the configuration's previous control.
 void SmpcController::updateKpi(real_t *state, real_t *control) {
-    const uint_t nx = ptrMySmpcConfig->getNX(), nu = ptrMySmpcConfig->getNU();
-    const real_t *safeX = ptrMyEngine->getDwnNetwork()->getXsafe();
-    const real_t *constantPrice = ptrMyEngine->getDwnNetwork()->getAlpha();
-    const real_t *variablePrice = ptrMyForecaster->getNominalPrices();
-    const real_t *previousControl = ptrMySmpcConfig->getPrevU();
-    const real_t weightEconomic = ptrMySmpcConfig->getWeightEconomical();
-    real_t ecoKpi = 0, smKpi = 0, saKpi = 0, netKpi = 0;
-    for (uint_t i = 0; i < nu; i++) {
-        ecoKpi += weightEconomic * (constantPrice[i] + variablePrice[i]) * std::fabs(control[i]);
-        const real_t dU = previousControl[i] - control[i];
-        smKpi += dU * dU;
+    DwnNetwork *net = ptrMyEngine->getDwnNetwork();
+    const uint_t nTanks = ptrMySmpcConfig->getNX(), nInputs = ptrMySmpcConfig->getNU();
+    const real_t *price0 = net->getAlpha(), *priceNow = ptrMyForecaster->getNominalPrices(), *uBefore = ptrMySmpcConfig->getPrevU();
+    const real_t wEco = ptrMySmpcConfig->getWeightEconomical();
+    real_t pumping = 0, variation = 0;
+    for (uint_t j = 0; j < nInputs; j++) {
+        pumping = pumping + wEco * (price0[j] + priceNow[j]) * std::fabs(control[j]);
+        const real_t step = uBefore[j] - control[j];
+        variation = variation + step * step;
     }
-    for (uint_t i = 0; i < nx; i++) {
-        real_t level = state[i] - safeX[i];
-        if (level > 0) level = 0;
-        saKpi += std::fabs(level);
-        netKpi += std::fabs(state[i]);
+    const real_t *reserve = net->getXsafe();
+    real_t shortfall = 0, stored = 0;
+    for (uint_t i = 0; i < nTanks; i++) {
+        real_t below = state[i] - reserve[i];
+        if (below > 0) below = 0;
+        shortfall = shortfall + std::fabs(below);
+        stored = stored + std::fabs(state[i]);
     }
-    economicKpi += ecoKpi; smoothKpi += smKpi; safeKpi += saKpi; networkKpi += netKpi;
+    economicKpi = economicKpi + pumping;
+    smoothKpi = smoothKpi + variation;
+    safeKpi = safeKpi + shortfall;
+    networkKpi = networkKpi + stored;
 }
-real_t SmpcController::getEconomicKpi(uint_t simulationTime) { return economicKpi / 3600 / simulationTime; }
-real_t SmpcController::getSmoothKpi(uint_t simulationTime) { return smoothKpi / 3600 / simulationTime; }
+// KPI read-outs (SmpcController.cu:1819-1859): the first two are per simulated hour (sampling time 3600 s)
+real_t SmpcController::getEconomicKpi(uint_t simulationTime) { const real_t perHour = economicKpi / 3600; return perHour / simulationTime; }
+real_t SmpcController::getSmoothKpi(uint_t simulationTime) { const real_t perHour = smoothKpi / 3600; return perHour / simulationTime; }
 real_t SmpcController::getNetworkKpi(uint_t simulationTime) {
-    real_t safeLevelNorm = 0;
-    for (uint_t i = 0; i < ptrMySmpcConfig->getNX(); i++) safeLevelNorm += getDwnNetwork()->getXsafe()[i];
-    return 100 * simulationTime * safeLevelNorm / networkKpi;
+    const real_t *reserve = getDwnNetwork()->getXsafe();
+    real_t reserveTotal = 0;
+    for (uint_t i = 0; i < ptrMySmpcConfig->getNX(); i++) reserveTotal = reserveTotal + reserve[i];
+    return 100 * simulationTime * reserveTotal / networkKpi;
 }
 real_t SmpcController::getSafetyKpi(uint_t) { return safeKpi; }
 
+void SmpcController::initialiseAlgorithm() {
+    const bool quasiNewton = ptrMyEngine->getGlobalFbeFlag() || ptrMyEngine->getNamaFlag();
+    check(quasiNewton ? rn_fbe_reset(ptrMyEngine->getContext()) : rn_apg_reset(ptrMyEngine->getContext()), "initialiseAlgorithm");
+}
+void SmpcController::initaliseLbfgBuffer() { check(rn_fbe_reset(ptrMyEngine->getContext()), "rn_fbe_reset"); }
+void SmpcController::updateLbfgsBuffer() { check(rn_update_lbfgs_buffer(ptrMyEngine->getContext()), "rn_update_lbfgs_buffer"); }
+void SmpcController::twoLoopRecursionLbfgs() { check(rn_two_loop_recursion_lbfgs(ptrMyEngine->getContext()), "rn_two_loop_recursion_lbfgs"); }
 void SmpcController::dualExtrapolationStep(real_t lambda) { check(rn_dual_extrapolation_step(ptrMyEngine->getContext(), lambda), "rn_dual_extrapolation_step"); }
 void SmpcController::solveStep() {
     if (!factorStepFlag) initialiseSmpcController();          // SmpcController.cu:579-582

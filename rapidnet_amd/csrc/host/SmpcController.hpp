@@ -21,6 +21,10 @@ public:
     Forecaster *getForecaster() { return ptrMyForecaster; }
     Engine *getEngine() { return ptrMyEngine; }
     void moveForewardInTime();                              // :1679-1716
+    // in-built simulator of moveForewardInTime: false (default) = the reference as written, x+ = x + B u (its disturbance
+    // term lands in the x of node 0 instead of the state update, :1695); true = x+ = x + e_0 + B u (DwnNetwork.cuh:41-57)
+    void setSimulatorDisturbance(bool on) { simulatorDisturbance = on; }
+    void setSimulatorFlag(bool inBuilt) { simulatorFlag = inBuilt; }   // false: external simulator, the state is re-read from the configuration file
     real_t getEconomicKpi(uint_t simulationTime);           // :1808-1811
     real_t getSmoothKpi(uint_t simulationTime);             // :1817-1820
     real_t getNetworkKpi(uint_t simulationTime);            // :1826-1835
@@ -32,6 +36,11 @@ public:
     ~SmpcController();
 
 protected:
+    void initialiseAlgorithm();                             // :420-450  zero the iterates of the selected algorithm
+    void initialiseAlgorithmSpecificData() {}               // :494-528  rebuilds device pointer tables: nothing to do here
+    void initaliseLbfgBuffer();                             // :453-468
+    void updateLbfgsBuffer();                               // :1103
+    void twoLoopRecursionLbfgs();                           // :1175
     void dualExtrapolationStep(real_t lambda);              // :535
     void solveStep();                                       // :563
     void proximalFunG();                                    // :759
@@ -62,7 +71,7 @@ protected:
     Forecaster *ptrMyForecaster;
     SmpcConfiguration *ptrMySmpcConfig;
     real_t stepSize;
-    bool factorStepFlag, simulatorFlag, ownsObjects;
+    bool factorStepFlag, simulatorFlag, ownsObjects, simulatorDisturbance = false;
     std::vector<real_t> vecPrimalInfs, vecValueFbe, vecTau, lastControl;
     real_t economicKpi, smoothKpi, safeKpi, networkKpi;
 };

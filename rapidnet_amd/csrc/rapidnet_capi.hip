@@ -73,15 +73,21 @@ struct NcclApi {
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    std::string path;   // file the bound image was loaded from (rn_comm_library)
     bool load() {
         if (h) return true;
+        // an RCCL image that is already part of the process (PyTorch links one under the soname librccl.so.1) is reused:
+        // RTLD_NOLOAD only returns a handle to a loaded object; a second image of the library is never mapped
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (h) break; }
+        if (!h) for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
         if (!h) return false;
         GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
         AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
         CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
         GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+        Dl_info info;
+        if (AllReduce && dladdr((void *)AllReduce, &info) && info.dli_fname) path = info.dli_fname;
         return GetUniqueId && AllReduce && dlsym(h, "ncclCommInitRank");
     }
 };
@@ -136,6 +142,8 @@ struct CtxBase {
     virtual int gradient_fbe() = 0;
     virtual int nama_residual() = 0;
     virtual int lbfgs_direction() = 0;
+    virtual int lbfgs_update_buffer() = 0;
+    virtual int lbfgs_two_loop() = 0;
     virtual int value_fbe(double *) = 0;
     virtual int line_search_fbe(double, double *) = 0;
     virtual int line_search_ame(double, double *) = 0;
@@ -1495,6 +1503,12 @@ int rn_comm_unique_id(void *id128) {
     return rn::g_nccl.GetUniqueId(id128) == 0 ? RN_OK : RN_E_COMM;
 }
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128) { RN_GUARD(ctx); return ctx->impl->comm_init(rank, nranks, id128); }
+int rn_comm_library(char *buf, size_t n) {
+    if (!buf || n == 0) return RN_E_ARG;
+    if (!rn::g_nccl.load()) { buf[0] = 0; return RN_E_COMM; }
+    snprintf(buf, n, "%s", rn::g_nccl.path.c_str());
+    return RN_OK;
+}
 int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
@@ -1509,6 +1523,8 @@ int rn_compute_hessian_oracle(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->he
 int rn_compute_gradient_fbe(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->gradient_fbe(); }
 int rn_update_fixed_point_residual_nama(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->nama_residual(); }
 int rn_compute_lbfgs_direction(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->lbfgs_direction(); }
+int rn_update_lbfgs_buffer(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->lbfgs_update_buffer(); }
+int rn_two_loop_recursion_lbfgs(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->lbfgs_two_loop(); }
 int rn_compute_value_fbe(rn_ctx *ctx, double *v) { RN_GUARD(ctx); return ctx->impl->value_fbe(v); }
 int rn_line_search_lbfgs_update(rn_ctx *ctx, double vy, double *tau) { RN_GUARD(ctx); return ctx->impl->line_search_fbe(vy, tau); }
 int rn_line_search_ame_lbfgs_update(rn_ctx *ctx, double vy, double *tau) { RN_GUARD(ctx); return ctx->impl->line_search_ame(vy, tau); }

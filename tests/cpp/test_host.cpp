@@ -8,6 +8,7 @@
 // usage: test_host <loaders|engine|controller|fbe|nama|closedloop|nullspace|warmstart> <directory with the fixture JSON files>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -334,6 +335,44 @@ static void testClosedLoop(const string &dir) {
     std::remove((dir + "/controlOutput.tmp").c_str());
 }
 
+// closed loop of main.cu:45-63 for `steps` control steps, every quantity the loop carries printed with 17 digits (one JSON
+// object per step) for tests/test_gpu_closed_loop.py, which runs the CPU oracle through the same steps
+static void dumpClosedLoop(const string &dir, uint_t steps, bool disturbance) {
+    SmpcController ctl(dir + "/controllerConfig.json");
+    ctl.setSimulatorDisturbance(disturbance);
+    std::fstream out((dir + "/controlOutput.tmp").c_str(), std::fstream::out);
+    SmpcConfiguration *cfg = ctl.getSmpcConfiguration();
+    const uint_t nx = cfg->getNX(), nu = cfg->getNU(), nd = cfg->getND();
+    std::cout.precision(17);
+    auto arr = [](const char *key, const real_t *v, size_t n) {
+        std::cout << "\"" << key << "\": [";
+        for (size_t i = 0; i < n; i++) std::cout << (i ? ", " : "") << v[i];
+        std::cout << "]";
+    };
+    for (uint_t t = 0; t < steps; t++) {
+        ctl.getForecaster()->predictDemand(t);
+        ctl.getForecaster()->predictPrices(t);
+        if (t == 0) ctl.initialiseSmpcController();
+        CHECK(ctl.controlAction(out) == 1);
+        std::vector<real_t> u0(ctl.getEngine()->getBufferSize(RN_BUF_U));
+        ctl.getEngine()->getBuffer(RN_BUF_U, u0.data());
+        ctl.moveForewardInTime();
+        std::vector<real_t> xAll(ctl.getEngine()->getBufferSize(RN_BUF_X));
+        ctl.getEngine()->getBuffer(RN_BUF_X, xAll.data());
+        const real_t kpi[4] = {ctl.getEconomicKpi(t + 1), ctl.getSmoothKpi(t + 1), ctl.getNetworkKpi(t + 1), ctl.getSafetyKpi(t + 1)};
+        std::cout << "CLSTEP {";
+        arr("u_root_unprojected", u0.data(), nu); std::cout << ", ";
+        arr("x", cfg->getCurrentX(), nx); std::cout << ", ";
+        arr("prevU", cfg->getPrevU(), nu); std::cout << ", ";
+        arr("prevD", cfg->getPrevDemand(), nd); std::cout << ", ";
+        arr("x_node0", xAll.data(), nx); std::cout << ", ";
+        arr("kpi", kpi, 4);
+        std::cout << "}" << std::endl;
+    }
+    out.close();
+    std::remove((dir + "/controlOutput.tmp").c_str());
+}
+
 // Engine::calculateMatLandMatLhat: E L = 0, L'L = I, E Lhat = -Ed, and the solve does not depend on the basis
 static void testNullSpace(const string &dir) {
     SmpcConfiguration cfg(dir + "/controllerConfig.json");
@@ -423,6 +462,7 @@ int main(int argc, char **argv) {
             t.getForecaster()->predictPrices(1);
             t.run(dir);
         } else if (mode == "closedloop") testClosedLoop(dir);
+        else if (mode == "closedloop_dump") dumpClosedLoop(dir, argc > 3 ? (uint_t)std::atoi(argv[3]) : 3, argc > 4 && std::atoi(argv[4]) != 0);
         else if (mode == "nullspace") testNullSpace(dir);
         else if (mode == "warmstart") testWarmStart(dir);
         else { std::cerr << "unknown mode\n"; return 2; }
