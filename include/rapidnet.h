@@ -254,6 +254,10 @@ int rn_set_cut_children_moments(rn_ctx *ctx, const double *E /* parents*nd */, c
 /* per-iteration {max|res_xi|, signed entry, max|res_psi|, signed entry} for iterations [first, first+n), so that
  * ranks can combine their local arg-max into the tree-global vecPrimalInfs (SmpcController.cu:1480-1496) */
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out /* 4*n */);
+/* Batch bookkeeping of rn_apg_iterate: out = {optimistic batches, exact batches, optimistic batches that were replayed
+ * through the exact path because a tree-global prox distance exceeded its threshold, exact batches still to run before the
+ * optimistic path is tried again (back-off after a replay)}. */
+int rn_get_counters(rn_ctx *ctx, long out[4]);
 /* Test hooks for the sharded sweep: run rn_solve_step in two halves around the exchange -- phase 1 stops after the
  * cut parents' LOCAL children sums are in the exchange buffer, phase 2 resumes from a buffer the caller has summed
  * over the shards (rn_debug_cut_buffer reads / writes it: cutParents * (nv + 2 nx) reals).  rn_comm_init with

@@ -28,7 +28,7 @@ SYMBOLS = [
     "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
-    "rn_comm_unique_id", "rn_comm_init", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_debug_sweep_phase",
+    "rn_comm_unique_id", "rn_comm_init", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
@@ -126,6 +126,7 @@ def load():
     lib.rn_comm_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
+    lib.rn_get_counters.argtypes = [vp, dp]
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
     lib.rn_set_operator_mode.argtypes = [vp, ip]
     lib.rn_set_warm_start.argtypes = [vp, ip]
@@ -449,6 +450,12 @@ class Solver:
         if moments is not None:
             E, P = _f64(moments[0]), _f64(moments[1])
             self._check(self.lib.rn_set_cut_children_moments(self.h, E.ctypes.data, P.ctypes.data, P.size))
+
+    def counters(self):
+        """rn_apg_iterate batch bookkeeping: dict(optimistic, exact, replayed, hold)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.rn_get_counters(self.h, out.ctypes.data))
+        return dict(zip(("optimistic", "exact", "replayed", "hold"), (int(v) for v in out)))
 
     def historyParts(self, first, n):
         out = np.zeros(4 * n)

@@ -37,7 +37,7 @@ struct TreeDev {
 };
 
 struct IterState {         // device-resident scalars of the APG loop
-    int it;                // iteration counter (incremented by k_finalize / k_decide_finalize)
+    int it;                // iteration counter (advanced by whichever kernel does the iteration's bookkeeping)
     unsigned int ticket;   // arrival counter of the fix-up kernel's blocks (rare path only)
     int violated;          // multi-GPU optimistic mode: a tree-global distance exceeded its threshold (sticky)
     int tripped;           // soft-constraint branch taken in this iteration
@@ -622,23 +622,6 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
             a.rkq[(size_t)node * w + nv + j0] = kap;
             a.rkq[(size_t)node * w + nv + nx + j0] = qs + a.qa[(size_t)node * nx + j0];
         }
-    }
-}
-// small crowns: ONE workgroup walks the stages [fromStage .. 0]; its own earlier stores are made visible to its
-// later loads by the barrier (same CU, same L1)
-template <typename T>
-__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_all(SweepArgs<T> a, int fromStage) {
-    const int per = a.nv + a.nx;                         // work items per node
-    for (int k = fromStage; k >= 0; k--) {
-        const int nk = a.tr.stageCum[k + 1] - a.tr.stageCum[k];
-        const int lanesPerNode = per < CROWN_THREADS ? ((per + 63) / 64) * 64 : CROWN_THREADS;
-        const int nodesPerPass = CROWN_THREADS / lanesPerNode;
-        for (int p0 = 0; p0 < nk; p0 += nodesPerPass) {
-            const int pos = p0 + threadIdx.x / lanesPerNode;
-            if (pos < nk && threadIdx.x / lanesPerNode < nodesPerPass) up_crown_node<T>(a, k, pos, threadIdx.x % lanesPerNode, lanesPerNode);
-        }
-        __threadfence_block();
-        __syncthreads();
     }
 }
 // multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload).
@@ -1323,6 +1306,102 @@ __device__ __forceinline__ void better(double &a, double &v, long long &i, doubl
     if (a2 > a || (a2 == a && i2 < i)) { a = a2; v = v2; i = i2; }
 }
 
+// Wave64 reductions on the VALU: DPP row shifts inside the 16-lane rows, then the gfx9 row broadcasts (row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3); the wave's result ends up in lane 63 and is read back with v_readlane.
+// __shfl_down compiles to ds_bpermute_b32 -- two per double, through the CU's ONE LDS pipe: the six-step arg-max fold of the
+// fused dual update was 96 of them per wave, ~4 us of LDS time per CU when all 27 resident waves reach their tail together
+// (measured: the kernel without its reductions ran 3.7 us faster; nothing else in it touches the LDS pipe).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+    const int rl = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROWMASK, 0xf, false);
+    const int rh = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {   // lane must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ long long readlane_i64(long long x, int lane) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(x & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
+    return ((long long)hi << 32) | (long long)lo;
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association => bitwise repeatable
+    x += dpp_f64<0x111, 0xf>(0.0, x);   // row_shr:1
+    x += dpp_f64<0x112, 0xf>(0.0, x);   // row_shr:2
+    x += dpp_f64<0x114, 0xf>(0.0, x);   // row_shr:4
+    x += dpp_f64<0x118, 0xf>(0.0, x);   // row_shr:8  -> lane 15 of every row holds the row's sum
+    x += dpp_f64<0x142, 0xa>(0.0, x);   // row_bcast:15 -> rows 1, 3
+    x += dpp_f64<0x143, 0xc>(0.0, x);   // row_bcast:31 -> rows 2, 3
+    return readlane_f64(x, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double x, double identity) {
+    x = fmax(x, dpp_f64<0x111, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x112, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x114, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x118, 0xf>(identity, x));
+    x = fmax(x, dpp_f64<0x142, 0xa>(identity, x));
+    x = fmax(x, dpp_f64<0x143, 0xc>(identity, x));
+    return readlane_f64(x, 63);
+}
+// wave-wide arg-max of |.| with the reference's tie rule (cublasIsamax: the FIRST index of the largest magnitude,
+// SmpcController.cu:1487-1494): max by DPP, then the lane holding it -- almost always exactly one -- is read back; ties are
+// resolved by index in a (wave-uniform) loop over the tied lanes.  absV < 0 marks "no entry".  Result in every lane.
+__device__ __forceinline__ void wave_argmax(double &absV, double &val, long long &idx) {
+    const double m = wave_max_f64(absV, -1.0);
+    if (m < 0.0) { absV = -1.0; val = 0.0; idx = 0x7fffffffffffffffLL; return; }
+    unsigned long long tie = __ballot(absV == m);
+    int src = (int)__ffsll((long long)tie) - 1;
+    if (tie & (tie - 1)) {
+        long long best = readlane_i64(idx, src);
+        for (unsigned long long t = tie & (tie - 1); t; t &= t - 1) {
+            const int l = (int)__ffsll((long long)t) - 1;
+            const long long il = readlane_i64(idx, l);
+            if (il < best) { best = il; src = l; }
+        }
+    }
+    absV = m; val = readlane_f64(val, src); idx = readlane_i64(idx, src);
+}
+
+
+// Fold of per-workgroup partials by ONE workgroup of ELT_THREADS threads (every thread calls; the result is valid in thread
+// 0): tx2 / ts2 = sums of the dist^2 partials, `out` = arg-max pairs (only when wantArgmax).  Fixed association, so every
+// caller that folds the same partials gets the same bits (the fix-up launch relies on that: all its workgroups take the same
+// trip decision).
+__device__ __forceinline__ void fold_partials(const Partial *partials, int nblocks, bool wantArgmax, double &tx2, double &ts2, Partial &out) {
+    __shared__ double f_sx[ELT_THREADS / 64], f_ss[ELT_THREADS / 64];
+    __shared__ Partial f_sh[ELT_THREADS / 64];
+    double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
+    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
+    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
+        const Partial q = partials[b];
+        d2x += q.d2x; d2s += q.d2s;
+        if (wantArgmax) { better(absXi, valXi, idxXi, q.absXi, q.valXi, q.idxXi); better(absPsi, valPsi, idxPsi, q.absPsi, q.valPsi, q.idxPsi); }
+    }
+    d2x = wave_sum_f64(d2x); d2s = wave_sum_f64(d2s);
+    if (wantArgmax) { wave_argmax(absXi, valXi, idxXi); wave_argmax(absPsi, valPsi, idxPsi); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { f_sx[wave] = d2x; f_ss[wave] = d2s; f_sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi}; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out = f_sh[0];
+        tx2 = f_sx[0]; ts2 = f_ss[0];
+        for (int k = 1; k < ELT_THREADS / 64; k++) {
+            tx2 += f_sx[k]; ts2 += f_ss[k];
+            better(out.absXi, out.valXi, out.idxXi, f_sh[k].absXi, f_sh[k].valXi, f_sh[k].idxXi);
+            better(out.absPsi, out.valPsi, out.idxPsi, f_sh[k].absPsi, f_sh[k].valPsi, f_sh[k].idxPsi);
+        }
+    }
+    __syncthreads();
+}
+// primal infeasibility of one iteration from the folded arg-max pairs: the larger of the two SIGNED entries (the reference's
+// updatePrimalInfeasibity quirk, SmpcController.cu:1480-1496) into the history, with the four parts kept for sharded callers
+__device__ __forceinline__ void write_history(const Partial &p, int it, double *hist, double *histParts, int histCap) {
+    if (it < 0 || it >= histCap) return;
+    hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
+    histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
+    histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
+}
+
 template <typename T> struct VecOf;
 template <> struct VecOf<double> { typedef nat_d2 type; static constexpr int N = 2; };
 template <> struct VecOf<float> { typedef nat_f4 type; static constexpr int N = 4; };
@@ -1356,37 +1435,11 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
     __shared__ Partial sh_p[ELT_THREADS / 64];
     T scX = 0, scS = 0;
     if (FIXUP && a.decideHere) {
-        __shared__ double dsx[ELT_THREADS / 64], dss[ELT_THREADS / 64];
-        __shared__ Partial dsh[ELT_THREADS / 64];
         __shared__ double dec[3];   // tripped, scaleX, scaleS
-        double f2x = 0, f2s = 0, aX = -1, vX = 0, aP = -1, vP = 0;
-        long long iX = 0x7fffffffffffffffLL, iP = 0x7fffffffffffffffLL;
-        for (int b = threadIdx.x; b < a.nMain; b += ELT_THREADS) {
-            const Partial q = a.mainPartials[b];
-            f2x += q.d2x; f2s += q.d2s;
-            if (blockIdx.x == 0) { better(aX, vX, iX, q.absXi, q.valXi, q.idxXi); better(aP, vP, iP, q.absPsi, q.valPsi, q.idxPsi); }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            f2x += __shfl_down(f2x, off); f2s += __shfl_down(f2s, off);
-            if (blockIdx.x == 0) {
-                const double a2 = __shfl_down(aX, off), v2 = __shfl_down(vX, off);
-                const long long i2 = __shfl_down(iX, off);
-                better(aX, vX, iX, a2, v2, i2);
-                const double a3 = __shfl_down(aP, off), v3 = __shfl_down(vP, off);
-                const long long i3 = __shfl_down(iP, off);
-                better(aP, vP, iP, a3, v3, i3);
-            }
-        }
-        if ((threadIdx.x & 63) == 0) { dsx[threadIdx.x >> 6] = f2x; dss[threadIdx.x >> 6] = f2s; dsh[threadIdx.x >> 6] = Partial{0, 0, aX, vX, aP, vP, iX, iP}; }
-        __syncthreads();
+        double tx2 = 0, ts2 = 0;
+        Partial p;
+        fold_partials(a.mainPartials, a.nMain, blockIdx.x == 0, tx2, ts2, p);
         if (threadIdx.x == 0) {
-            double tx2 = dsx[0], ts2 = dss[0];
-            Partial p = dsh[0];
-            for (int k = 1; k < ELT_THREADS / 64; k++) {
-                tx2 += dsx[k]; ts2 += dss[k];
-                better(p.absXi, p.valXi, p.idxXi, dsh[k].absXi, dsh[k].valXi, dsh[k].idxXi);
-                better(p.absPsi, p.valPsi, p.idxPsi, dsh[k].absPsi, dsh[k].valPsi, dsh[k].idxPsi);
-            }
             const double dX = sqrt(tx2), dS = sqrt(ts2);
             const bool trX = dX > a.thrX, trS = dS > a.thrS;
             dec[0] = (trX || trS) ? 1.0 : 0.0;
@@ -1396,13 +1449,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
                 a.st->distX = dX; a.st->distS = dS;
                 a.st->tripped = (trX || trS) ? 1 : 0;
                 a.st->scaleX = dec[1]; a.st->scaleS = dec[2];
-                const int it = a.itHost;
-                if (it < a.histCap) {
-                    a.hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
-                    a.histParts[4 * (size_t)it + 0] = p.absXi; a.histParts[4 * (size_t)it + 1] = p.valXi;
-                    a.histParts[4 * (size_t)it + 2] = p.absPsi; a.histParts[4 * (size_t)it + 3] = p.valPsi;
-                }
-                a.st->it = it + 1;
+                write_history(p, a.itHost, a.hist, a.histParts, a.histCap);
+                a.st->it = a.itHost + 1;
             }
         }
         __syncthreads();
@@ -1536,12 +1584,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
                     better(aX, vX, iX, q.absXi, q.valXi, q.idxXi);
                     better(aP, vP, iP, q.absPsi, q.valPsi, q.idxPsi);
                 }
-                const int it = a.decideHere ? a.itHost : a.st->it - 1;
-                if (it >= 0 && it < a.histCap) {
-                    a.hist[it] = vX > vP ? vX : vP;
-                    a.histParts[4 * (size_t)it + 0] = aX; a.histParts[4 * (size_t)it + 1] = vX;
-                    a.histParts[4 * (size_t)it + 2] = aP; a.histParts[4 * (size_t)it + 3] = vP;
-                }
+                Partial pr{0, 0, aX, vX, aP, vP, iX, iP};
+                write_history(pr, a.decideHere ? a.itHost : a.st->it - 1, a.hist, a.histParts, a.histCap);
                 a.st->ticket = 0;
             }
         }
@@ -1571,62 +1615,6 @@ struct DualStageShape {
     double lnNext;           // extrapolation parameter of the NEXT iteration, by value: no st->it -> lamNext[] load chain in front of
                              // the streams (every workgroup would pay those two dependent scalar round trips before its first load)
 };
-// Wave64 reductions on the VALU: DPP row shifts inside the 16-lane rows, then the gfx9 row broadcasts (row_bcast:15 into rows
-// 1 and 3, row_bcast:31 into rows 2 and 3); the wave's result ends up in lane 63 and is read back with v_readlane.
-// __shfl_down compiles to ds_bpermute_b32 -- two per double, through the CU's ONE LDS pipe: the six-step arg-max fold of the
-// fused dual update was 96 of them per wave, ~4 us of LDS time per CU when all 27 resident waves reach their tail together
-// (measured: the kernel without its reductions ran 3.7 us faster; nothing else in it touches the LDS pipe).
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_f64(double old, double x) {
-    const int rl = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROWMASK, 0xf, false);
-    const int rh = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROWMASK, 0xf, false);
-    return __hiloint2double(rh, rl);
-}
-__device__ __forceinline__ double readlane_f64(double x, int lane) {   // lane must be wave-uniform
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
-}
-__device__ __forceinline__ long long readlane_i64(long long x, int lane) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(x & 0xffffffffLL), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
-    return ((long long)hi << 32) | (long long)lo;
-}
-__device__ __forceinline__ double wave_sum_f64(double x) {   // fixed association => bitwise repeatable
-    x += dpp_f64<0x111, 0xf>(0.0, x);   // row_shr:1
-    x += dpp_f64<0x112, 0xf>(0.0, x);   // row_shr:2
-    x += dpp_f64<0x114, 0xf>(0.0, x);   // row_shr:4
-    x += dpp_f64<0x118, 0xf>(0.0, x);   // row_shr:8  -> lane 15 of every row holds the row's sum
-    x += dpp_f64<0x142, 0xa>(0.0, x);   // row_bcast:15 -> rows 1, 3
-    x += dpp_f64<0x143, 0xc>(0.0, x);   // row_bcast:31 -> rows 2, 3
-    return readlane_f64(x, 63);
-}
-__device__ __forceinline__ double wave_max_f64(double x, double identity) {
-    x = fmax(x, dpp_f64<0x111, 0xf>(identity, x));
-    x = fmax(x, dpp_f64<0x112, 0xf>(identity, x));
-    x = fmax(x, dpp_f64<0x114, 0xf>(identity, x));
-    x = fmax(x, dpp_f64<0x118, 0xf>(identity, x));
-    x = fmax(x, dpp_f64<0x142, 0xa>(identity, x));
-    x = fmax(x, dpp_f64<0x143, 0xc>(identity, x));
-    return readlane_f64(x, 63);
-}
-// wave-wide arg-max of |.| with the reference's tie rule (cublasIsamax: the FIRST index of the largest magnitude,
-// SmpcController.cu:1487-1494): max by DPP, then the lane holding it -- almost always exactly one -- is read back; ties are
-// resolved by index in a (wave-uniform) loop over the tied lanes.  absV < 0 marks "no entry".  Result in every lane.
-__device__ __forceinline__ void wave_argmax(double &absV, double &val, long long &idx) {
-    const double m = wave_max_f64(absV, -1.0);
-    if (m < 0.0) { absV = -1.0; val = 0.0; idx = 0x7fffffffffffffffLL; return; }
-    unsigned long long tie = __ballot(absV == m);
-    int src = (int)__ffsll((long long)tie) - 1;
-    if (tie & (tie - 1)) {
-        long long best = readlane_i64(idx, src);
-        for (unsigned long long t = tie & (tie - 1); t; t &= t - 1) {
-            const int l = (int)__ffsll((long long)t) - 1;
-            const long long il = readlane_i64(idx, l);
-            if (il < best) { best = il; src = l; }
-        }
-    }
-    absV = m; val = readlane_f64(val, src); idx = readlane_i64(idx, src);
-}
-
 // one 16-byte vector of the tile with everything its update needs (all seven loads are independent)
 template <typename T>
 struct DualSlot {
@@ -1766,71 +1754,15 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
     }
 }
 
-// single-GPU bookkeeping in ONE launch: k_decide + k_finalize (the fix-up kernel then redoes the history entry itself
-// if, and only if, the soft-constraint branch tripped)
-__global__ void __launch_bounds__(ELT_THREADS) k_decide_finalize(const Partial *partials, int nblocks, IterState *st, double thrX,
-                                                                 double thrS, double *hist, double *histParts, int histCap) {
-    __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
-    __shared__ Partial sh[ELT_THREADS / 64];
-    double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
-    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
-    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
-        const Partial q = partials[b];
-        d2x += q.d2x; d2s += q.d2s;
-        better(absXi, valXi, idxXi, q.absXi, q.valXi, q.idxXi);
-        better(absPsi, valPsi, idxPsi, q.absPsi, q.valPsi, q.idxPsi);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off);
-        const double a2 = __shfl_down(absXi, off), v2 = __shfl_down(valXi, off);
-        const long long i2 = __shfl_down(idxXi, off);
-        better(absXi, valXi, idxXi, a2, v2, i2);
-        const double a3 = __shfl_down(absPsi, off), v3 = __shfl_down(valPsi, off);
-        const long long i3 = __shfl_down(idxPsi, off);
-        better(absPsi, valPsi, idxPsi, a3, v3, i3);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { sx[wave] = d2x; ss[wave] = d2s; sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi}; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Partial p = sh[0];
-        double tx2 = sx[0], ts2 = ss[0];
-        for (int k = 1; k < ELT_THREADS / 64; k++) {
-            tx2 += sx[k]; ts2 += ss[k];
-            better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
-            better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
-        }
-        const double dX = sqrt(tx2), dS = sqrt(ts2);
-        st->distX = dX; st->distS = dS;
-        const bool trX = dX > thrX, trS = dS > thrS;
-        st->tripped = (trX || trS) ? 1 : 0;
-        st->scaleX = trX ? 1.0 - thrX / dX : 0.0;
-        st->scaleS = trS ? 1.0 - thrS / dS : 0.0;
-        const int it = st->it;
-        if (it < histCap) {
-            hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
-            histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
-            histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
-        }
-        st->it = it + 1;
-    }
-}
-
 // one workgroup: fold the block partials; decide whether the soft-constraint branch trips
 // (dist > gamma/lambda, SmpcController.cu:793, :811)
 __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials, int nblocks, IterState *st, double thrX,
                                                         double thrS) {
-    __shared__ double sx[ELT_THREADS], ss[ELT_THREADS];
-    double d2x = 0, d2s = 0;
-    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) { d2x += partials[b].d2x; d2s += partials[b].d2s; }
-    sx[threadIdx.x] = d2x; ss[threadIdx.x] = d2s;
-    __syncthreads();
-    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { sx[threadIdx.x] += sx[threadIdx.x + off]; ss[threadIdx.x] += ss[threadIdx.x + off]; }
-        __syncthreads();
-    }
+    double tx2 = 0, ts2 = 0;
+    Partial p;
+    fold_partials(partials, nblocks, false, tx2, ts2, p);
     if (threadIdx.x == 0) {
-        const double dX = sqrt(sx[0]), dS = sqrt(ss[0]);
+        const double dX = sqrt(tx2), dS = sqrt(ts2);
         st->distX = dX; st->distS = dS;
         const bool tx = dX > thrX, ts = dS > thrS;
         st->tripped = (tx || ts) ? 1 : 0;
@@ -1849,36 +1781,10 @@ __device__ void finalize_optimistic_body(const FinArgs &fin) {
     IterState *st = fin.st;
     T *tail = reinterpret_cast<T *>(fin.tail);
     double *hist = fin.hist, *histParts = fin.histParts;
-    __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
-    __shared__ Partial sh[ELT_THREADS / 64];
-    double d2x = 0, d2s = 0, absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
-    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
-    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
-        const Partial q = partials[b];
-        d2x += q.d2x; d2s += q.d2s;
-        better(absXi, valXi, idxXi, q.absXi, q.valXi, q.idxXi);
-        better(absPsi, valPsi, idxPsi, q.absPsi, q.valPsi, q.idxPsi);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off);
-        const double a2 = __shfl_down(absXi, off), v2 = __shfl_down(valXi, off);
-        const long long i2 = __shfl_down(idxXi, off);
-        better(absXi, valXi, idxXi, a2, v2, i2);
-        const double a3 = __shfl_down(absPsi, off), v3 = __shfl_down(valPsi, off);
-        const long long i3 = __shfl_down(idxPsi, off);
-        better(absPsi, valPsi, idxPsi, a3, v3, i3);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { sx[wave] = d2x; ss[wave] = d2s; sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi}; }
-    __syncthreads();
+    double tx2 = 0, ts2 = 0;
+    Partial p;
+    fold_partials(partials, nblocks, true, tx2, ts2, p);
     if (threadIdx.x == 0) {
-        Partial p = sh[0];
-        double tx2 = sx[0], ts2 = ss[0];
-        for (int k = 1; k < ELT_THREADS / 64; k++) {
-            tx2 += sx[k]; ts2 += ss[k];
-            better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
-            better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
-        }
         if (tail) { tail[0] = (T)tx2; tail[1] = (T)ts2; }
         if (fin.thrX >= 0) {   // single GPU: the distances are complete -- verify the projection-only prox right here
             const double dX = sqrt(tx2), dS = sqrt(ts2);
@@ -1886,11 +1792,7 @@ __device__ void finalize_optimistic_body(const FinArgs &fin) {
             if (dX > fin.thrX || dS > fin.thrS) st->violated = 1;
         }
         const int it = st->it;
-        if (it < histCap) {
-            hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
-            histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
-            histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
-        }
+        write_history(p, it, hist, histParts, histCap);
         st->it = it + 1;
     }
 }
@@ -1913,16 +1815,10 @@ __global__ void k_check_dist(T *tail, IterState *st, double thrX, double thrS, T
 
 // multi-GPU variant of k_decide: fold the local partials to (d2x, d2s), all-reduce those two numbers, then decide
 __global__ void __launch_bounds__(ELT_THREADS) k_reduce_dist(const Partial *partials, int nblocks, double *out2) {
-    __shared__ double sx[ELT_THREADS], ss[ELT_THREADS];
-    double d2x = 0, d2s = 0;
-    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) { d2x += partials[b].d2x; d2s += partials[b].d2s; }
-    sx[threadIdx.x] = d2x; ss[threadIdx.x] = d2s;
-    __syncthreads();
-    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { sx[threadIdx.x] += sx[threadIdx.x + off]; ss[threadIdx.x] += ss[threadIdx.x + off]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { out2[0] = sx[0]; out2[1] = ss[0]; }
+    double tx2 = 0, ts2 = 0;
+    Partial p;
+    fold_partials(partials, nblocks, false, tx2, ts2, p);
+    if (threadIdx.x == 0) { out2[0] = tx2; out2[1] = ts2; }
 }
 __global__ void k_decide_from(const double *d2, IterState *st, double thrX, double thrS) {
     const double dX = sqrt(d2[0]), dS = sqrt(d2[1]);
@@ -1937,36 +1833,12 @@ __global__ void k_decide_from(const double *d2, IterState *st, double thrX, doub
 // positions -- the reference's quirk) into hist[it]; advance the iteration counter.
 __global__ void __launch_bounds__(ELT_THREADS) k_finalize(const Partial *partials, int nblocks, IterState *st, double *hist,
                                                           double *histParts, int histCap) {
-    __shared__ Partial sh[ELT_THREADS / 64];
-    double absXi = -1, valXi = 0, absPsi = -1, valPsi = 0;
-    long long idxXi = 0x7fffffffffffffffLL, idxPsi = 0x7fffffffffffffffLL;
-    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) {
-        better(absXi, valXi, idxXi, partials[b].absXi, partials[b].valXi, partials[b].idxXi);
-        better(absPsi, valPsi, idxPsi, partials[b].absPsi, partials[b].valPsi, partials[b].idxPsi);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double a2 = __shfl_down(absXi, off), v2 = __shfl_down(valXi, off);
-        const long long i2 = __shfl_down(idxXi, off);
-        better(absXi, valXi, idxXi, a2, v2, i2);
-        const double a3 = __shfl_down(absPsi, off), v3 = __shfl_down(valPsi, off);
-        const long long i3 = __shfl_down(idxPsi, off);
-        better(absPsi, valPsi, idxPsi, a3, v3, i3);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) sh[wave] = Partial{0, 0, absXi, valXi, absPsi, valPsi, idxXi, idxPsi};
-    __syncthreads();
+    double tx2 = 0, ts2 = 0;
+    Partial p;
+    fold_partials(partials, nblocks, true, tx2, ts2, p);
     if (threadIdx.x == 0) {
-        Partial p = sh[0];
-        for (int k = 1; k < ELT_THREADS / 64; k++) {
-            better(p.absXi, p.valXi, p.idxXi, sh[k].absXi, sh[k].valXi, sh[k].idxXi);
-            better(p.absPsi, p.valPsi, p.idxPsi, sh[k].absPsi, sh[k].valPsi, sh[k].idxPsi);
-        }
         const int it = st->it;
-        if (it < histCap) {
-            hist[it] = p.valXi > p.valPsi ? p.valXi : p.valPsi;
-            histParts[4 * (size_t)it + 0] = p.absXi; histParts[4 * (size_t)it + 1] = p.valXi;
-            histParts[4 * (size_t)it + 2] = p.absPsi; histParts[4 * (size_t)it + 3] = p.valPsi;
-        }
+        write_history(p, it, hist, histParts, histCap);
         st->it = it + 1;
     }
 }

@@ -26,6 +26,9 @@
 #ifndef RN_OPT_LOCAL_MIN
 #define RN_OPT_LOCAL_MIN 16   // shortest rn_apg_iterate batch that takes the optimistic single-GPU path
 #endif
+#ifndef RN_OPT_BACKOFF
+#define RN_OPT_BACKOFF 8      // exact batches after an optimistic batch had to be replayed
+#endif
 #ifndef RN_DUAL_REGEN
 #define RN_DUAL_REGEN 1
 #endif
@@ -127,6 +130,7 @@ struct CtxBase {
     virtual int comm_init(int, int, const void *) = 0;
     virtual int set_cut_stage(int) = 0;
     virtual int hist_parts(int, int, double *) = 0;
+    virtual int counters(long *) = 0;
     virtual int sweep_phase(int) = 0;
     virtual int set_operator_mode(int) = 0;
     virtual int set_warm_start(int) = 0;
@@ -214,7 +218,11 @@ struct Ctx : CtxBase {
     bool pendingFin = false; // optimistic exchange: the previous iteration's bookkeeping has not been launched yet (it rides in the next k_cut_partial_sums)
     bool carryTail = false;  // the cut payload carries 2 extra reals (rank-local dist^2 of the previous iteration)
     T *d_ck[3] = {nullptr, nullptr, nullptr};   // checkpoint of (y, y+, w) for the exact fallback
-    long fallbacks = 0;
+    long fallbacks = 0;          // optimistic batches that had to be replayed through the exact path
+    long optBatches = 0, exactBatches = 0;
+    bool inReplay = false;
+    int optHold = 0;             // batches still to run through the exact path after a replay (back-off: a state that violates its
+                                 // soft bounds would otherwise pay checkpoint + replay on every batch of every control step)
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
@@ -967,9 +975,9 @@ struct Ctx : CtxBase {
             RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
             RN_HIP(hipStreamSynchronize(stream));
             const int keep = optimistic;
-            optimistic = 0;
+            optimistic = 0; inReplay = true; optHold = RN_OPT_BACKOFF;
             const int rc = apg_iterate(n, primalInfs);
-            optimistic = keep;
+            optimistic = keep; inReplay = false;
             return rc;
         }
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1026,9 +1034,9 @@ struct Ctx : CtxBase {
             RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
             RN_HIP(hipStreamSynchronize(stream));
             const int keep = optimistic;
-            optimistic = 0;
+            optimistic = 0; inReplay = true; optHold = RN_OPT_BACKOFF;
             const int rc = apg_iterate(n, primalInfs);
-            optimistic = keep;
+            optimistic = keep; inReplay = false;
             return rc;
         }
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1039,9 +1047,15 @@ struct Ctx : CtxBase {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
         RN_HIP(hipSetDevice(device));
-        if (comm && cutStage > 0 && optimistic && n > 0) return apg_iterate_optimistic(n, primalInfs);
+        // optimistic batches (prox as a pure projection, verified afterwards); after a replay the next RN_OPT_BACKOFF batches
+        // go straight through the exact path (every rank sees the same verdicts, so sharded ranks stay in step)
+        const bool wantOptSharded = comm && cutStage > 0 && optimistic && n > 0;
         // single GPU: worth a checkpoint (3 vector copies) and a read-back per batch once the batch is long enough
-        if (!comm && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN) return apg_iterate_optimistic_local(n, primalInfs);
+        const bool wantOptLocal = !comm && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN;
+        if ((wantOptSharded || wantOptLocal) && optHold > 0 && !inReplay) optHold--;
+        else if (wantOptSharded) { optBatches++; return apg_iterate_optimistic(n, primalInfs); }
+        else if (wantOptLocal) { optBatches++; return apg_iterate_optimistic_local(n, primalInfs); }
+        if (!inReplay && n > 0) exactBatches++;
         const int first = h_it;
         if (int rc = ensure_tables(h_it + n)) return rc;
         for (int k = 0; k < n; k++) {
@@ -1084,6 +1098,11 @@ struct Ctx : CtxBase {
             RN_HIP(hipStreamSynchronize(stream));
             RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         }
+        return RN_OK;
+    }
+    int counters(long *out) override {
+        RN_CHECK(out, RN_E_ARG, "rn_get_counters: null output");
+        out[0] = optBatches; out[1] = exactBatches; out[2] = fallbacks; out[3] = optHold;
         return RN_OK;
     }
     int hist_parts(int first, int n, double *out) override {
@@ -1511,6 +1530,7 @@ int rn_comm_library(char *buf, size_t n) {
 }
 int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
+int rn_get_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->counters(out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }

@@ -170,6 +170,26 @@ def test_soft_constraint_branch():
     # step-wise prox on the same branch
     s.proximalFunG(); o.prox()
     assert relmax(s.get(capi.BUF_DUAL_XI), o.get("dualXi")) < REL_TOL
+    # the 30-iteration batch ran optimistically (prox as a projection), tripped, and was replayed exactly; the next batches
+    # back off to the exact path instead of paying checkpoint + replay again
+    c = s.counters()
+    assert c["optimistic"] == 1 and c["replayed"] == 1 and c["hold"] > 0
+    hold = c["hold"]
+    h2 = s.apgIterate(20)
+    o2 = Oracle(p["network"], p["tree"], p["config"])
+    o2.initialise(*synth.forecast_at(p["forecast"], 0))
+    ref = o2.apg(50)
+    assert np.abs(np.concatenate([hist, h2]) - ref).max() <= 1e-9 * np.abs(ref).max()
+    c = s.counters()
+    assert c["optimistic"] == 1 and c["replayed"] == 1 and c["hold"] == hold - 1 and c["exact"] >= 1
+
+
+def test_counters_on_a_clean_run():
+    p, o, s = make_pair("small")
+    s.algorithmApg(40)
+    s.apgIterate(8)
+    c = s.counters()
+    assert c == {"optimistic": 1, "exact": 1, "replayed": 0, "hold": 0}
 
 
 # Tree shapes at the edge of (and beyond) what the reference can represent.  Its Omega/Theta pointer aliasing
