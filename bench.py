@@ -266,7 +266,7 @@ def main():
             for i, nm in enumerate(names):
                 classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
             dual_s = 1e-3 * ms[2] / max(n[2], 1)
-            dual = {"achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
+            dual = {"kernel": "k_dual_stage", "achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
                     "avg_launch_us": 1e6 * dual_s}
             dual["frac"] = dual["achieved"] / 8000.0
             # HBM traffic from the PMC counters is NOT measured by this run (rocprofv3 --pmc needs passes of its own): it is
@@ -288,7 +288,7 @@ def main():
                 except Exception:
                     traffic = {}
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
-                roofline = {"kernel": "k_dual_fused", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
+                roofline = {"kernel": "k_dual_stage", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
                             "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
                 if copy_ceiling:
@@ -303,7 +303,8 @@ def main():
                 if read_ceiling:   # read-only stream vs a read-only probe; the dual update (5 read + 2 write streams) vs the copy probe
                     roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
                     dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
-        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps,
+        batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
+        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
                "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}
         s.close()
@@ -339,7 +340,7 @@ def main():
             "rccl": None if not sharded else {"ranks": world, "library": rccl_library, "communicator": "one per device, owned by librapidnet_hip (rn_comm_init); "
                                               "ncclUniqueId and barriers travel over torch.distributed/gloo",
                                               "exchange": "torch.distributed fallback: " + fallback_reason[0] if fallback_reason[0] else "ncclAllReduce on the solver's stream"},
-            "roofline": roofline, "kernel_classes": classes,
+            "roofline": roofline, "kernel_classes": classes, "batch_counters": head["batch_counters"],
         }
         if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates
             out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",

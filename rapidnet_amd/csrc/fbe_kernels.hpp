@@ -27,9 +27,25 @@ struct DotArgs {
 // order (a last-block-folds variant that saves the k_dots_finish launch was measured: the per-block agent-scope release
 // makes k_dots 2.5x and k_value_terms 4x slower on this multi-XCD part -- two launches it stays);
 // order (thread-strided partial sums -> wave shuffle -> LDS -> one partial per block), so a repeat is bitwise equal
+// block tail of every kernel that produces dot partials: wave shuffle -> LDS -> one partial per block and dot, fixed order.
+// Kernels that fuse a dot product into another pass (k_lbfgs_fused, k_lbfgs_diffs_dots, k_prox_res) walk the range exactly as
+// k_dots does (same grid, same 16-byte vectors, same element order), so a fused dot is bitwise the k_dots value.
+__device__ __forceinline__ void dots_block_reduce(double (&acc)[DOT_MAX], double *partials) {
+    __shared__ double sh[ELT_THREADS / 64][DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) {
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < DOT_MAX) {
+        double s = 0;
+        for (int k = 0; k < ELT_THREADS / 64; k++) s += sh[k][threadIdx.x];
+        partials[(size_t)blockIdx.x * DOT_MAX + threadIdx.x] = s;
+    }
+}
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
-    __shared__ double sh[ELT_THREADS / 64][DOT_MAX];
     double acc[DOT_MAX];
 #pragma unroll
     for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
@@ -53,17 +69,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
         for (int j = 0; j < DOT_MAX; j++)
             if (j < g.cnt) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
     }
-#pragma unroll
-    for (int j = 0; j < DOT_MAX; j++) {
-        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = acc[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < DOT_MAX) {
-        double s = 0;
-        for (int k = 0; k < ELT_THREADS / 64; k++) s += sh[k][threadIdx.x];
-        g.partials[(size_t)blockIdx.x * DOT_MAX + threadIdx.x] = s;
-    }
+    dots_block_reduce(acc, g.partials);
 }
 // second stage: out[j] = sum over blocks of partials[b][j], fixed order
 __global__ void __launch_bounds__(ELT_THREADS) k_dots_finish(const double *partials, int nblocks, int cnt, double *out) {
@@ -101,6 +107,190 @@ __global__ void k_lbfgs_diffs(T *S, T *Y, const T *y, const T *yPrev, const T *g
         S[i] = y[i] - yPrev[i];
         Y[i] = g[i] - gPrev[i];
     }
+}
+
+// One step of the two-loop recursion AND the dot product the next step needs, in one pass over the direction
+// (SmpcController::twoLoopRecursionLbfgs, SmpcController.cu:1175-1229; the reference issues Sdot + Saxpy per step):
+//   mode -1: dir = scale * src                          (start: src = gradient, scale = -1; between the loops: src = dir, scale = H0)
+//   mode  0: alpha_c = rho_c scal[0]; dir -= alpha_c vec           (vec = Y_c)
+//   mode  1: dir += (alpha_c - rho_c scal[0]) vec                  (vec = S_c)
+//   next != nullptr: partials[block][0] = <next, dir_new> over the block's elements (k_dots order), for k_dots_finish
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *src, const T *vec, const double *scal, double rho, double *alphaArr, int c,
+                                                             int mode, T scale, const T *next, double *partials, long long n) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    T coef = 0;
+    if (mode >= 0) {
+        const T prod = (T)rho * (T)scal[0];
+        coef = mode == 0 ? -prod : (T)alphaArr[c] - prod;
+    }
+    double acc[DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
+    const unsigned long long misal = (unsigned long long)dir | (unsigned long long)(mode < 0 ? src : vec) | (unsigned long long)(next ? next : dir);
+    const long long nvec = (misal & 15ull) ? 0 : n / VN;
+    const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    for (long long i = gid; i < nvec; i += stride) {
+        VT d;
+        if (mode < 0) {
+            const VT sv = reinterpret_cast<const VT *>(src)[i];
+#pragma unroll
+            for (int e = 0; e < VN; e++) d[e] = scale * sv[e];
+        } else {
+            d = reinterpret_cast<VT *>(dir)[i];
+            const VT vv = reinterpret_cast<const VT *>(vec)[i];
+#pragma unroll
+            for (int e = 0; e < VN; e++) d[e] += coef * vv[e];
+        }
+        reinterpret_cast<VT *>(dir)[i] = d;
+        if (next) {
+            const VT nv = reinterpret_cast<const VT *>(next)[i];
+#pragma unroll
+            for (int e = 0; e < VN; e++) acc[0] += (double)nv[e] * (double)d[e];
+        }
+    }
+    for (long long i = nvec * VN + gid; i < n; i += stride) {
+        T d;
+        if (mode < 0) d = scale * src[i]; else { d = dir[i]; d += coef * vec[i]; }
+        dir[i] = d;
+        if (next) acc[0] += (double)next[i] * (double)d;
+    }
+    // the coefficient of the first loop is kept for the second one; written after every block has read scal / alphaArr is not
+    // required: nobody reads alphaArr[c] in mode 0, and the next launch is stream-ordered behind this one
+    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) alphaArr[c] = (double)((T)rho * (T)scal[0]);
+    if (next) dots_block_reduce(acc, partials);
+}
+// S = y - yPrev, Y = g - gPrev (SmpcController::updateLbfgsBuffer, :1119-1130) and the four dot products its skip rule and
+// H0 scaling need (<g,g>, <S,Y>, <Y,Y>, <S,S>, :1131-1156) in the same pass
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, const T *y, const T *yPrev, const T *g, const T *gPrev, double *partials, long long n) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    double acc[DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
+    const long long nvec = n / VN;   // the six vectors are allocations of their own: 16-byte aligned
+    const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    for (long long i = gid; i < nvec; i += stride) {
+        const VT yv = reinterpret_cast<const VT *>(y)[i], ypv = reinterpret_cast<const VT *>(yPrev)[i];
+        const VT gv = reinterpret_cast<const VT *>(g)[i], gpv = reinterpret_cast<const VT *>(gPrev)[i];
+        VT sv, dv;
+#pragma unroll
+        for (int e = 0; e < VN; e++) { sv[e] = yv[e] - ypv[e]; dv[e] = gv[e] - gpv[e]; }
+        reinterpret_cast<VT *>(S)[i] = sv;
+        reinterpret_cast<VT *>(Y)[i] = dv;
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[0] += (double)gv[e] * (double)gv[e];
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[1] += (double)sv[e] * (double)dv[e];
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[2] += (double)dv[e] * (double)dv[e];
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[3] += (double)sv[e] * (double)sv[e];
+    }
+    for (long long i = nvec * VN + gid; i < n; i += stride) {
+        const T sv = y[i] - yPrev[i], dv = g[i] - gPrev[i];
+        S[i] = sv; Y[i] = dv;
+        acc[0] += (double)g[i] * (double)g[i]; acc[1] += (double)sv * (double)dv; acc[2] += (double)dv * (double)dv; acc[3] += (double)sv * (double)sv;
+    }
+    dots_block_reduce(acc, partials);
+}
+// prox + fixed-point residual (+ the negated residual the quasi-Newton loops start from) in one pass, with the partials of the
+// two dot products of computeValueFbe (<w, res>, <res, res>, SmpcController.cu:1430-1441) and of the prox distances:
+//   z = clamp(hx + w / lambda)   res = hx - z   [gneg = -res]          (:778-792, :839-850, :1077 / :1060)
+// The soft-constraint correction, if the distances trip it, is applied afterwards by k_prox_soft_res.
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg, double *dotPartials) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    __shared__ double sx[ELT_THREADS / 64], ss[ELT_THREADS / 64];
+    double acc[DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
+    double d2x = 0, d2s = 0;
+    const int nx = a.nx, ny = a.ny;
+    const long long nvec = a.n / VN;
+    const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    int c0 = (int)((gid * VN) % ny);
+    const int cstep = (int)((stride * VN) % ny);
+    for (long long i = gid; i < nvec; i += stride) {
+        const VT hx = reinterpret_cast<const VT *>(a.hx)[i], w = reinterpret_cast<const VT *>(a.w)[i];
+        const VT lo = reinterpret_cast<const VT *>(a.lo)[i], hi = reinterpret_cast<const VT *>(a.hi)[i];
+        VT z, r, gn;
+        int c = c0;
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+            const T t = hx[e] + a.invLambda * w[e];
+            z[e] = t < lo[e] ? lo[e] : (t > hi[e] ? hi[e] : t);
+            r[e] = hx[e] - z[e];
+            gn[e] = -r[e];
+            const double diff = (double)(t - z[e]);
+            if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
+            if (++c == ny) c = 0;
+        }
+        reinterpret_cast<VT *>(a.z)[i] = z;
+        reinterpret_cast<VT *>(a.res)[i] = r;
+        if (gneg) reinterpret_cast<VT *>(gneg)[i] = gn;
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[0] += (double)w[e] * (double)r[e];
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[1] += (double)r[e] * (double)r[e];
+        c0 += cstep; if (c0 >= ny) c0 -= ny;
+    }
+    for (long long i = nvec * VN + gid; i < a.n; i += stride) {
+        const int c = (int)(i % ny);
+        const T t = a.hx[i] + a.invLambda * a.w[i];
+        const T z = t < a.lo[i] ? a.lo[i] : (t > a.hi[i] ? a.hi[i] : t);
+        const T r = a.hx[i] - z;
+        a.z[i] = z; a.res[i] = r;
+        if (gneg) gneg[i] = -r;
+        const double diff = (double)(t - z);
+        if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
+        acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r;
+    }
+    for (int off = 32; off > 0; off >>= 1) { d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off); }
+    if ((threadIdx.x & 63) == 0) { sx[threadIdx.x >> 6] = d2x; ss[threadIdx.x >> 6] = d2s; }
+    dots_block_reduce(acc, dotPartials);   // contains the barrier the two arrays above need
+    if (threadIdx.x == 0) {
+        Partial p{};
+        for (int k = 0; k < ELT_THREADS / 64; k++) { p.d2x += sx[k]; p.d2s += ss[k]; }
+        a.partials[blockIdx.x] = p;
+    }
+}
+// second half of the fused prox (only does anything when k_decide found a distance above its threshold): the prox of
+// gamma * dist(., C) on the tripped halves (:793-815), then residual, negated residual and the dot partials redone
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_prox_soft_res(DualArgs<T> a, T *gneg, double *dotPartials) {
+    if (!a.st->tripped) return;
+    const T scX = (T)a.st->scaleX, scS = (T)a.st->scaleS;
+    constexpr int VN = VecOf<T>::N;
+    double acc[DOT_MAX];
+#pragma unroll
+    for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
+    const long long nvec = a.n / VN;
+    const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    auto one = [&](long long i) -> T {
+        const int c = (int)(i % a.ny);
+        const T t = a.hx[i] + a.invLambda * a.w[i];
+        T z = a.z[i];
+        if (c < 2 * a.nx) { z = z + (c < a.nx ? scX : scS) * (t - z); a.z[i] = z; }
+        const T r = a.hx[i] - z;
+        a.res[i] = r;
+        if (gneg) gneg[i] = -r;
+        return r;
+    };
+    for (long long i = gid; i < nvec; i += stride) {       // element order of k_dots: the VN elements of vector i, then i + stride
+        T r[VN];
+#pragma unroll
+        for (int e = 0; e < VN; e++) r[e] = one(i * VN + e);
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[0] += (double)a.w[i * VN + e] * (double)r[e];
+#pragma unroll
+        for (int e = 0; e < VN; e++) acc[1] += (double)r[e] * (double)r[e];
+    }
+    for (long long i = nvec * VN + gid; i < a.n; i += stride) { const T r = one(i); acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r; }
+    dots_block_reduce(acc, dotPartials);
 }
 
 // one line-search trial step (SmpcController.cu:1274-1283 / 1383-1392): x += tau xdir, u += tau udir, w += tau dir,

@@ -46,5 +46,5 @@ print(json.dumps({
               "barcelona493 fp64, medians per launch",
     "correction": "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request on wide streaming reads: MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KiB*1024",
     "k_stream_gemv_bytes_per_launch": total("void rn::k_stream_gemv<double"),
-    "k_dual_fused_bytes_per_launch": total("void rn::k_dual_fused<double, false, false"),
+    "k_dual_fused_bytes_per_launch": total("void rn::k_dual_stage<double, false"),
     "raw": raw}, indent=1))
