@@ -289,7 +289,7 @@ def main():
                     traffic = {}
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
                 roofline = {"kernel": "k_dual_stage", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
-                            "frac": dual["frac"], "traffic": traffic.get("k_dual_fused_bytes_per_launch"), "traffic_source": traffic_source,
+                            "frac": dual["frac"], "traffic": traffic.get("k_dual_stage_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
                 if copy_ceiling:
                     roofline.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})

@@ -1380,7 +1380,9 @@ struct Ctx : CtxBase {
             (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
             if (r > 0 && ms > 0) bestR = std::max(bestR, (double)bytes / (ms * 1e-3) / 1e9);
             (void)hipEventRecord(e0, stream);
-            hipLaunchKernelGGL(k_bw_copy, dim3(blocks), dim3(256), 0, stream, (const nat_d2 *)a, (nat_d2 *)b, n);
+            // copy: 4 workgroups per CU measured best for a read + write stream (tools/probes/probe_stream.hip: 6.2 TB/s with
+            // 1 024 workgroups, 5.2-5.4 with 4 096 or 8 192 on a 1 GiB vector)
+            hipLaunchKernelGGL(k_bw_copy, dim3(numCUs * 4), dim3(256), 0, stream, (const nat_d2 *)a, (nat_d2 *)b, n);
             (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
             if (r > 0 && ms > 0) bestC = std::max(bestC, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
         }
