@@ -139,6 +139,7 @@ def main():
         torch.cuda.set_device(local_rank)
         if "MASTER_ADDR" not in os.environ:   # --force-shard without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: loopback (the box's hostname may not resolve)
         dist.init_process_group("gloo", init_method="env://")
     from rapidnet_amd import capi, synth
     from rapidnet_amd import partition

@@ -832,6 +832,9 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
         acc[j] = acc_t{0, 0, 0, 0};
     }
     const T *Bp = sB + col * SB + kq;
+#ifndef RN_VLV_ABL
+#define RN_VLV_ABL 0   // timing ablations of the slab products (results WRONG when set): 1 = no A loads, 2 = no B loads, 4 = no MFMA
+#endif
     for (int ks = 0; ks < ksteps; ks += KU) {
         T av[KU][TG], bv[KU];
 #pragma unroll
@@ -839,13 +842,16 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
             const bool on = ks + i < ksteps;
             const int kc = on ? ks + i : ksteps - 1;
 #pragma unroll
-            for (int j = 0; j < TG; j++) av[i][j] = Ap[j][(size_t)kc * 4 * mp];
-            bv[i] = on ? Bp[kc * 4] : (T)0;
+            for (int j = 0; j < TG; j++) av[i][j] = (RN_VLV_ABL & 1) ? (T)(lane + kc) : Ap[j][(size_t)kc * 4 * mp];
+            bv[i] = (RN_VLV_ABL & 2) ? (T)(lane - kc) : (on ? Bp[kc * 4] : (T)0);
         }
 #pragma unroll
         for (int i = 0; i < KU; i++)
 #pragma unroll
-            for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+            for (int j = 0; j < TG; j++) {
+                if (RN_VLV_ABL & 4) acc[j][0] += av[i][j] * bv[i];
+                else acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+            }
     }
 }
 // auxiliary operands of the epilogue (m1_i or e_i), requested BEFORE the MFMA loop so that their latency hides behind it

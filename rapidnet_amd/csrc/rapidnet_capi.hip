@@ -807,7 +807,10 @@ struct Ctx : CtxBase {
         if (const char *e = std::getenv("RAPIDNET_DUAL_TRIPS")) forced = std::atoi(e);   // tuning runs
         // workgroups: at most one resident round (numCUs x 8 workgroups of 4 waves) so that every workgroup's loads start at
         // once; measured on the 493-scenario tree: 1 trip (5 113 workgroups) 21.9 us, 2-3 trips 20.8, 4-6 trips 21.6-24 us
-        const long long resident = (long long)numCUs * 8;
+        // vectors that do not fit the 256 MiB Infinity Cache stream from HBM: there 4x as many (smaller) workgroups and the
+        // double-buffered variant measured best (wide4096 fp32, 1.3 GB per launch: 279 -> 257 us)
+        const bool cacheResident = 5.0 * (double)ntot() * sizeof(T) <= 256.0 * 1024 * 1024;
+        const long long resident = (long long)numCUs * (cacheResident ? 8 : 32);
         for (int pass = 0; pass < 2 && dualU == 0; pass++)
             for (int trips : {1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64}) {
                 if (forced > 0 && trips != forced) continue;
@@ -816,7 +819,7 @@ struct Ctx : CtxBase {
                 const long long blocks = cb + bps * (d.N - cs);
                 if (blocks > (pass == 0 && forced <= 0 ? resident : (long long)RN_DUAL_STAGE_MAX_BLOCKS)) continue;
                 dshape = DualStageShape{cs, K, node0, (int)bps, (int)cb, vpn, (unsigned int)((1ull << 32) / (unsigned)vpn) + 1u, trips, 0.0};
-                dualU = 1;
+                dualU = (!cacheResident && trips >= 2) ? 2 : 1;
                 if (const char *e = std::getenv("RAPIDNET_DUAL_PIPE")) dualU = std::atoi(e) >= 2 ? 2 : 1;   // tuning runs
                 dualBlocks = (int)blocks;
                 break;
