@@ -331,6 +331,22 @@ static void testClosedLoop(const string &dir) {
         CHECK(std::fabs(ctl.getEconomicKpi(1) * 3600 - e0 - de) < 1e-9 * (1 + std::fabs(de)));
         CHECK(std::fabs(ctl.getSmoothKpi(1) * 3600 - s0 - ds) < 1e-9 * (1 + std::fabs(ds)));
     }
+    // external simulator (simulatorFlag = 0, SmpcController.cu:1712-1716): the state, the previous control and the previous
+    // demand are re-read from the configuration file -- whatever the in-built simulator had left in memory is replaced
+    {
+        SmpcConfiguration fresh(dir + "/controllerConfig.json");
+        SmpcConfiguration *cfg = ctl.getSmpcConfiguration();
+        const uint_t nx = cfg->getNX(), nu = cfg->getNU(), nd = cfg->getND();
+        bool moved = false;                                      // two simulated steps have changed the in-memory state
+        for (uint_t i = 0; i < nx; i++) moved = moved || cfg->getCurrentX()[i] != fresh.getCurrentX()[i];
+        CHECK(moved);
+        ctl.setSimulatorFlag(false);
+        ctl.moveForewardInTime();
+        CHECK(closeAbs(cfg->getCurrentX(), fresh.getCurrentX(), nx, 1e-12, "currentX re-read"));
+        CHECK(closeAbs(cfg->getPrevU(), fresh.getPrevU(), nu, 1e-12, "prevU re-read"));
+        CHECK(closeAbs(cfg->getPrevDemand(), fresh.getPrevDemand(), nd, 1e-12, "prevDemand re-read"));
+        ctl.setSimulatorFlag(true);
+    }
     out.close();
     std::remove((dir + "/controlOutput.tmp").c_str());
 }

@@ -184,6 +184,21 @@ def test_soft_constraint_branch():
     assert c["optimistic"] == 1 and c["replayed"] == 1 and c["hold"] == hold - 1 and c["exact"] >= 1
 
 
+@pytest.mark.parametrize("trips,pipe", [(1, 1), (2, 1), (3, 2), (5, 2), (8, 1)])
+def test_dual_stage_launch_shapes(trips, pipe, monkeypatch):
+    """k_dual_stage with every tile / pipelining shape (the defaults pick one by problem size): vectors per thread 1 .. 8,
+    single- and double-buffered, on a tree with a two-stage crown (crown workgroups + regular stages) and partially filled
+    last tiles; same iterates and history as the oracle."""
+    monkeypatch.setenv("RAPIDNET_DUAL_TRIPS", str(trips))
+    monkeypatch.setenv("RAPIDNET_DUAL_PIPE", str(pipe))
+    for name, iters in (("medium", 24), ("small", 20)):
+        p, o, s = make_pair(name)
+        hist, ohist = s.algorithmApg(iters), o.apg(iters)
+        compare_all(s, o, REL_TOL, "%s trips=%d pipe=%d" % (name, trips, pipe))
+        assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
+        s.close()
+
+
 def test_counters_on_a_clean_run():
     p, o, s = make_pair("small")
     s.algorithmApg(40)
