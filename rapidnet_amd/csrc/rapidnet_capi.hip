@@ -692,8 +692,9 @@ struct Ctx : CtxBase {
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
+            const int nSlabs = (d.nodes + 15) / 16;
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
             return;
         }
 #endif
