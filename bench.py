@@ -23,6 +23,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's cross-process buffers); must be set before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
