@@ -158,8 +158,8 @@ constexpr int STREAM_THREADS = RN_STREAM_THREADS;
 constexpr int STREAM_NLMAX = 4;   // slots per thread and span
 
 // ------------------------------------------------------------------------------------------------------
-// Pieces of the fused dual update that the streaming kernel shares with the kernels further down: the per-workgroup
-// partial reductions, the wave-level reductions and the update of one element.
+// Pieces of the fused dual update shared by the kernels further down: the per-workgroup partial reductions, the wave-level
+// reductions and the update of one element.
 struct Partial {           // per-block partial reductions of the fused kernel
     double d2x, d2s;       // sum (t - clamp)^2 over the box / safety halves
     double absXi, valXi;   // max |res| over xi entries and the signed entry there
@@ -234,9 +234,10 @@ template <> struct VecOf<float> { typedef nat_f4 type; static constexpr int N = 
 template <typename T> struct DualOut { T yn, wn, z, res, diff; };
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-// The update of one element.  Three kernels inline this (k_dual_fused, k_dual_stage, k_stream_gemv<FUSE>) and a batch mixes
-// them, so the roundings are spelled out -- explicit fused multiply-adds, contraction of everything else off -- instead of
-// left to each call site's instruction selection (fp32: the compiler contracted w_next differently in two of them).
+// The update of one element.  Several kernels inline this (k_dual_fused with and without the soft-constraint fix-up,
+// k_dual_stage) and a batch mixes them, so the roundings are spelled out -- explicit fused multiply-adds, contraction of
+// everything else off -- instead of left to each call site's instruction selection (in fp32 the compiler was seen to
+// contract w_next differently in two instances).
 template <typename T, bool FIXUP>
 __device__ __forceinline__ DualOut<T> dual_elem(T hx, T w, T lo, T hi, T yp, T lambda, T invLambda, T ln, T sc) {
 #pragma clang fp contract(off)
@@ -257,54 +258,11 @@ template <typename T> struct Slot;
 template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
 template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4; };
 
-// FUSE: the dual update of the PREVIOUS iteration (k_dual_stage's work: prox as a pure projection, residual, dual update, the
-// reductions, the extrapolation -- SmpcController.cu:759-864, :535-557) is done here, node by node, in the prologue: the
-// update is node-local and its result w_i is exactly the vector this workgroup multiplies A_i with, so instead of loading
-// w_i the workgroup loads Hx_i, w_i(prev), y+_i(prev), computes, stores y+_i and w_i and keeps w_i in LDS.  The first group
-// of A_i is already in flight, so the two extra loads ride in the shadow of the stream; the launch of the dual-update kernel
-// (18 us + a launch gap per iteration on the 493-scenario tree, and its 21 MB read of w) disappears from inner iterations.
-// One Partial per NODE; the bookkeeping workgroup of k_up_chain / k_cut_partial_sums folds them as before.
-template <typename T>
-struct StreamDual {
-    const T *hx, *wPrev, *yprev;
-    T *ynew, *wnext;
-    const T *blo, *bhi;       // [ny] unscaled bounds (the scaled ones are rebuilt from sqrt(p_i) and the stage's preconditioner row)
-    T lambda, invLambda, ln;  // ln: extrapolation parameter of the iteration this sweep belongs to
-    Partial *partials;        // [nodes]
-    long long crownElems;     // multi-GPU: leading elements replicated on every rank (counted once, on rank 0)
-    int countCrown;
-    int node0;                // first node of stage chainStage
-};
-#ifndef RN_FUSE_ABL
-#define RN_FUSE_ABL 0   // timing ablations of the FUSE prologue (results are WRONG when set): 1 = no per-node loads, 2 = no y+/w stores,
-#endif                  // 4 = no reductions
-struct NodeAcc {           // one thread's share of a node's reductions (plain values: must stay in registers)
-    double d2x, d2s, absXi, valXi, absPsi, valPsi;
-    long long idxXi, idxPsi;
-    bool box, saf, psi;    // which parts of the dual vector this thread has met
-};
-template <typename T>
-__device__ __forceinline__ DualOut<T> stream_dual_elem(const StreamDual<T> &f, NodeAcc &r, int c, size_t i, int nx, bool counted, T spn,
-                                                       T hx, T wp, T yp, T dyc, T bl, T bh) {
-    const bool isBox = c < nx, isXi = c < 2 * nx;
-    const T k = spn * dyc;
-    const T lo = k * bl;
-    const T hi = (isXi && !isBox) ? bh : k * bh;
-    const DualOut<T> o = dual_elem<T, false>(hx, wp, lo, hi, yp, f.lambda, f.invLambda, f.ln, (T)0);
-    const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
-    r.d2x += isBox ? dd : 0.0;
-    r.d2s += (isXi && !isBox) ? dd : 0.0;
-    r.box |= isBox; r.saf |= isXi && !isBox; r.psi |= !isXi;
-    const double rv = (double)o.res, ra = fabs(rv);
-    const bool upX = isXi && ra > r.absXi, upP = !isXi && ra > r.absPsi;   // ascending walk: strict > keeps the first index
-    r.absXi = upX ? ra : r.absXi; r.valXi = upX ? rv : r.valXi; r.idxXi = upX ? (long long)i : r.idxXi;
-    r.absPsi = upP ? ra : r.absPsi; r.valPsi = upP ? rv : r.valPsi; r.idxPsi = upP ? (long long)i : r.idxPsi;
-    return o;
-}
 // Results of the streaming kernel leave with non-temporal stores.  One workgroup is resident per CU and it cannot retire
-// before its last stores are acknowledged, so the acknowledgement time of the ~2 KB a node writes is a hole in that CU's read
-// stream: measured on the 493-scenario tree, the kernel takes 572 us without its stores, 619 us with plain stores (write-back
-// through L2) and 595 us with non-temporal ones; the consumers (k_up_chain) read them 3 us slower from beyond L2.
+// before its last stores are acknowledged, and written-back lines compete with the read stream: measured on the 493-scenario
+// tree, the kernel takes 572 us without its stores, 619 us with plain stores (write-back through L2) and 595 us with
+// non-temporal ones; the consumers (k_up_chain) read them 3 us slower from beyond L2 (interleaved A/B, tools/ab_rounds.sh:
+// 0.677 ms per iteration against 0.690).
 #ifndef RN_STREAM_NT_OUT
 #define RN_STREAM_NT_OUT 1
 #endif
@@ -317,25 +275,13 @@ __device__ __forceinline__ void stream_out(T v, T *dst) {
 #endif
 }
 template <typename T>
-__device__ __forceinline__ T stream_qa_elem(T sp, T d0, T y0, T d1, T y1) {   // roundings spelled out: the FUSE and the plain instance agree
+__device__ __forceinline__ T stream_qa_elem(T sp, T d0, T y0, T d1, T y1) {   // roundings spelled out (fp32: contraction is otherwise the compiler's choice)
 #pragma clang fp contract(off)
     const T p = d1 * y1;
     return sp * fma_rn(d0, y0, p);
 }
-// A wave reduces only what its lanes have met (thread t holds column t of the node: a wave is mostly one part of the dual
-// vector -- on the 493-scenario tree 8 wave reductions per node instead of 32; waves without elements do nothing at all):
-// the reductions are dependent DPP chains, ~0.1 us each, on a workgroup that has the CU to itself.
-__device__ __forceinline__ void stream_reduce_waves(NodeAcc &r, Partial *sh_part) {
-    const bool anyBox = __ballot(r.box) != 0, anySaf = __ballot(r.saf) != 0, anyPsi = __ballot(r.psi) != 0;
-    if (!(anyBox || anySaf || anyPsi)) return;
-    if (anyBox) r.d2x = wave_sum_f64(r.d2x);
-    if (anySaf) r.d2s = wave_sum_f64(r.d2s);
-    if (anyBox || anySaf) wave_argmax(r.absXi, r.valXi, r.idxXi);
-    if (anyPsi) wave_argmax(r.absPsi, r.valPsi, r.idxPsi);
-    if ((threadIdx.x & 63) == 0) sh_part[threadIdx.x >> 6] = Partial{r.d2x, r.d2s, r.absXi, r.valXi, r.absPsi, r.valPsi, r.idxXi, r.idxPsi};
-}
-template <typename T, int NL, bool FUSE>
-__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, StreamDual<T> f) {
+template <typename T, int NL>
+__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0) {
     typedef typename Slot<T>::type VT;
     constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -380,27 +326,16 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     // nothing after the barrier has to queue a small load behind the stream.  The first group is requested unconditionally
     // (clamped into the block when the block is shorter than a group): a branch around it makes the compiler's wait-count
     // bookkeeping merge two paths and fall back to "wait for everything" in front of the prologue's arithmetic.
-    __shared__ Partial sh_part[STREAM_THREADS / 64];
-    NodeAcc acc{0, 0, -1, 0, -1, 0, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, false, false, false};
     const bool has0 = tid < ny;
     const size_t i0 = (size_t)node * ny + (has0 ? tid : 0);
-    const int c0 = has0 ? tid : 0;
-    // stage of the node by arithmetic in the chain region (every stage >= chainStage has K nodes); a table load for the few
-    // crown nodes in front of it
-    const int stage = node >= f.node0 ? a.chainStage + (node - f.node0) / a.K : a.tr.stageOf[node];
+    // stage of the node by arithmetic in the chain region (every stage >= chainStage has K nodes: no table load in front of
+    // the preconditioner row's address); a table load for the few crown nodes before it
+    const int stage = node >= node0 ? a.chainStage + (node - node0) / a.K : a.tr.stageOf[node];
     const T *dyRow = a.tr.dy + (size_t)stage * ny;
     const T spn = a.tr.sqrtp[node];
     const int tq = tid < nx ? tid : 0;
     const T dq0 = dyRow[tq], dq1 = dyRow[nx + tq];    // for a_i below
-    T w0 = 0, hx0 = 0, wp0 = 0, yp0 = 0, dy0 = 0, blo0 = 0, bhi0 = 0;
-    if (!FUSE) w0 = a.w[i0];
-    else {
-#if RN_FUSE_ABL & 1
-        hx0 = (T)node; wp0 = (T)tid; yp0 = (T)1; dy0 = dyRow[c0]; blo0 = f.blo[c0]; bhi0 = f.bhi[c0];
-#else
-        hx0 = f.hx[i0]; wp0 = f.wPrev[i0]; yp0 = f.yprev[i0]; dy0 = dyRow[c0]; blo0 = f.blo[c0]; bhi0 = f.bhi[c0];
-#endif
-    }
+    const T w0 = a.w[i0];
     asm volatile("" ::: "memory");   // keep the request order: the compiler otherwise hoists the group's loads above the small ones
     {
         const int lastSlot = (int)blockSlots - 1;
@@ -413,47 +348,18 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
             }
     }
     asm volatile("" ::: "memory");
-    // What the prologue produces (y+_i, w_i, a_i) is STORED AT THE END of the kernel: stores count in the same in-order
-    // counter as the loads, so a store issued here has to be acknowledged before the wave may consume any group of A_i
-    // requested after it -- and a write's acknowledgement under a saturated read stream takes far longer than a read.
-    T yn0 = 0, wn0 = 0, qa0 = 0;
-    if (!FUSE) {
-        if (has0) sh_y[tid] = w0;
-        for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
-    } else {
-        const bool counted = f.countCrown || (long long)node * ny >= f.crownElems;
-        if (has0) {
-            const DualOut<T> o = stream_dual_elem<T>(f, acc, tid, i0, nx, counted, spn, hx0, wp0, yp0, dy0, blo0, bhi0);
-            yn0 = o.yn; wn0 = o.wn; sh_y[tid] = o.wn;
-        }
-        for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) {   // ny > 512 (wide problems only): stored right away
-            const size_t i = (size_t)node * ny + c;
-            const DualOut<T> o = stream_dual_elem<T>(f, acc, c, i, nx, counted, spn, f.hx[i], f.wPrev[i], f.yprev[i], dyRow[c], f.blo[c], f.bhi[c]);
-            f.ynew[i] = o.yn; f.wnext[i] = o.wn; sh_y[c] = o.wn;
-        }
-    }
+    // a_i is STORED AT THE END of the kernel: stores count in the same in-order counter as the loads, so a store issued
+    // here has to be acknowledged before the wave may consume any group of A_i requested after it
+    T qa0 = 0;
+    if (has0) sh_y[tid] = w0;
+    for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
     __syncthreads();
     // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
     if (tid < nx) qa0 = stream_qa_elem(spn, dq0, sh_y[tid], dq1, sh_y[nx + tid]);
     for (int t = tid + STREAM_THREADS; t < nx; t += STREAM_THREADS)
         a.qa[(size_t)node * nx + t] = stream_qa_elem(spn, dyRow[t], sh_y[t], dyRow[nx + t], sh_y[nx + t]);
-    // FUSE: the wave-level reductions of the prologue's update.  One workgroup per CU is resident, so any time the workgroup
-    // spends without loads in flight is a hole in the CU's stream -- this code is therefore placed where the wave would wait
-    // for memory anyway (first pass of the loop below: group 2 has just been requested, group 1 is still on its way).
-    bool reduced = false;
     if (nGroups > 0) {
         int g = 0;
-        if (FUSE && nGroups > 2) {
-            RN_LOADG(bufB, 1)
-            RN_USEG(bufA, 0)
-            RN_LOADG(bufA, 2)
-#if !(RN_FUSE_ABL & 4)
-            stream_reduce_waves(acc, sh_part);
-#endif
-            reduced = true;
-            RN_USEG(bufB, 1)
-            g = 2;
-        }
         // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is consumed, group
         // g+1 (and then g+2) is in flight
         for (; g + 2 < nGroups; g += 2) {
@@ -491,24 +397,8 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
 #pragma unroll
             for (int e = 0; e < VPL; e++) sh_red[(size_t)off[j] * VPL + e] = part[j][e];
         }
-    if (FUSE && !reduced) stream_reduce_waves(acc, sh_part);
     if (tid < nx) stream_out(qa0, a.qa + (size_t)node * nx + tid);
-#if !(RN_FUSE_ABL & 2)
-    if (FUSE && has0) { stream_out(yn0, f.ynew + i0); stream_out(wn0, f.wnext + i0); }
-#endif
     __syncthreads();
-    if (FUSE && tid == STREAM_THREADS - 64 && !(RN_FUSE_ABL & 4)) {
-        // the node's Partial: the waves that held elements, combined by the last wave while the first ones fold the mat-vec
-        const int nw = ny < STREAM_THREADS ? (ny + 63) / 64 : STREAM_THREADS / 64;
-        Partial p = sh_part[0];
-        for (int k = 1; k < nw; k++) {
-            const Partial q = sh_part[k];
-            p.d2x += q.d2x; p.d2s += q.d2s;
-            better(p.absXi, p.valXi, p.idxXi, q.absXi, q.valXi, q.idxXi);
-            better(p.absPsi, p.valPsi, p.idxPsi, q.absPsi, q.valPsi, q.idxPsi);
-        }
-        f.partials[node] = p;
-    }
     for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {    // slot q of a span = column q / SPC, rows (q % SPC) * VPL ...
         T s = sh_red[r];
         for (int k = 1; k < G; k++) s += sh_red[(size_t)k * LD + r];
@@ -1530,8 +1420,6 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // elements) [+ z, res when MATERIALIZE].
 //   t = hx + w/lambda ; z = clamp(t, lo, hi) [+ sc_half (t - clamp) when the soft-constraint branch trips]
 //   res = hx - z ; ynew = w + lambda res ; wnext = (1 + ln) ynew - ln yprev
-// (Partial, the wave reductions and dual_elem sit in front of k_stream_gemv, which performs the same update in its prologue
-// when the update of an inner iteration is deferred to the next sweep.)
 template <typename T>
 struct DualArgs {
     const T *hx, *w, *yprev, *lo, *hi;

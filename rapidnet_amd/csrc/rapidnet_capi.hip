@@ -35,11 +35,6 @@
 #ifndef RN_FOLD_ROOT
 #define RN_FOLD_ROOT 1
 #endif
-#ifndef RN_STREAM_FUSE_DUAL
-#define RN_STREAM_FUSE_DUAL 0   // 1: inner iterations of an optimistic batch do their dual update in the prologue of the next k_stream_gemv
-                                // (measured SLOWER: the update's 3.8 KB of stores per node cost the streaming kernel more than the
-                                // k_dual_stage launch they replace -- DESIGN.md section 3; RAPIDNET_FUSE_DUAL=1 switches it on)
-#endif
 #ifndef RN_DUAL_STAGE
 #define RN_DUAL_STAGE 1   // 1: stage-tiled main pass of the fused dual update (k_dual_stage) whenever the shape allows it
 #endif
@@ -252,10 +247,7 @@ struct Ctx : CtxBase {
     DualStageShape dshape{};   // k_dual_stage launch shape (dual_stage_setup)
     int dualU = 0;             // vectors a k_dual_stage thread keeps in flight; 0: shape not eligible, the flat k_dual_fused runs
     int dualBlocks = 1;        // workgroups (= partials) of the main pass of the fused dual update
-    int mainPartials = 1;      // partials the most recent main pass left in d_partials (k_dual_stage, k_dual_fused or the fused k_stream_gemv)
-    size_t partialsCap = 0;    // capacity of d_partials
-    bool fuseDual = RN_STREAM_FUSE_DUAL != 0;   // inner iterations of an optimistic batch: dual update inside the next sweep's k_stream_gemv
-    long deferredDuals = 0;    // dual updates that ran inside k_stream_gemv (rn_get_counters does not report it; bench reads the kernel names)
+    int mainPartials = 1;      // partials the most recent main pass left in d_partials (k_dual_stage or k_dual_fused)
     // profiling
     int prof = 0;
     struct EvPair { int cls; hipEvent_t a, b; };
@@ -397,9 +389,6 @@ struct Ctx : CtxBase {
         if (int rc = upload_int(d_stageOf, h_stageOf)) return rc;
         const size_t n = nodes;
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd;
-        // one Partial per workgroup of the dual update -- per NODE when the update is deferred into the streaming kernel
-        partialsCap = std::max((size_t)std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS), (size_t)nodes);
-        if (const char *e = std::getenv("RAPIDNET_FUSE_DUAL")) fuseDual = std::atoi(e) != 0;   // A/B runs: 0 = every dual update is a launch of its own
 #define DA(ptr, cnt) if (int rc = dalloc(&ptr, (size_t)(cnt))) return rc;
         DA(d_sqrtp, n) DA(d_prob, n) DA(d_dy, (size_t)N * ny)
         DA(d_Rinv, nv * nv) DA(d_Bbt, nv * nx) DA(d_L, nu * nv) DA(d_B, nx * nu) DA(d_Lt, nv * nu) DA(d_WLt, nv * nu) DA(d_W, nu * nu)
@@ -416,7 +405,7 @@ struct Ctx : CtxBase {
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
         DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
-        DA(d_state, 1) DA(d_partials, partialsCap) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
+        DA(d_state, 1) DA(d_partials, std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
 #undef DA
         std::vector<double> sq(nodes);
         for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
@@ -591,10 +580,7 @@ struct Ctx : CtxBase {
     int algorithmic_bytes(double *bwd, double *dual) const override {
         // k_stream_gemv, one launch = the whole tree: A_i (2nv x ny, unpadded) read once + y_i read + m1,m2,a_i written
         const double s = sizeof(T), n = d.nodes;
-        // with the deferred dual update in its prologue (inner iterations of an optimistic batch): Hx_i, w_i(prev), y+_i(prev)
-        // read instead of w_i, y+_i and w_i written -- 4 ny more values per node
-        const bool fused = can_defer_dual() && optimistic;
-        if (bwd) *bwd = structured ? 0.0 : n * ((double)2 * d.nv * ny + (fused ? 5.0 : 1.0) * ny + 2.0 * d.nv + d.nx) * s;
+        if (bwd) *bwd = structured ? 0.0 : n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
         // k_dual_fused: Hx, w, y+prev read, y+, w_next written (+ the two scaled-bound streams unless they are regenerated)
         if (dual) *dual = (RN_DUAL_REGEN ? 5.0 : 7.0) * (double)ntot() * s;
         return RN_OK;
@@ -628,49 +614,19 @@ struct Ctx : CtxBase {
         *G = bestG; *NL = bestNL;
     }
     size_t stream_lds(int G) const { return (size_t)(((ny + 3) & ~3) + (size_t)G * LD) * sizeof(T); }
-    // fuse != nullptr: the streaming kernel also performs the deferred dual update of the previous iteration (its prologue)
-    int launch_stream(const SweepArgs<T> &a, const StreamDual<T> *fuse = nullptr) {
+    int launch_stream(const SweepArgs<T> &a) {
         int G, NL;
         stream_shape(&G, &NL);
         RN_CHECK(NL <= STREAM_NLMAX, RN_E_ARG, "k_stream_gemv: more than 4096 values per operator column are not supported (2*nv too large)");
         const size_t lds = stream_lds(G);
-        StreamDual<T> f = fuse ? *fuse : StreamDual<T>{};
-        f.node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
-#define RN_STREAM_LAUNCH(NL_, FUSE_) hipLaunchKernelGGL((k_stream_gemv<T, NL_, FUSE_>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, f)
-        if (fuse) switch (NL) {
-            case 1: RN_STREAM_LAUNCH(1, true); break;
-            case 2: RN_STREAM_LAUNCH(2, true); break;
-            case 3: RN_STREAM_LAUNCH(3, true); break;
-            default: RN_STREAM_LAUNCH(4, true); break;
-        } else switch (NL) {
-            case 1: RN_STREAM_LAUNCH(1, false); break;
-            case 2: RN_STREAM_LAUNCH(2, false); break;
-            case 3: RN_STREAM_LAUNCH(3, false); break;
-            default: RN_STREAM_LAUNCH(4, false); break;
+        const int node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
+        switch (NL) {
+            case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
+            case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
+            case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
+            default: hipLaunchKernelGGL((k_stream_gemv<T, 4>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
         }
-#undef RN_STREAM_LAUNCH
         return RN_OK;
-    }
-    // May the dual update of an inner iteration of an optimistic batch be deferred into the next sweep's streaming kernel?
-    // (dense operator mode only: the structured mode has no per-node streaming workgroup to host it)
-    // (and not with 4 slots per thread and span: that instance of the kernel has no registers to spare)
-    bool can_defer_dual() const {
-        if (!fuseDual || structured || (size_t)d.nodes > partialsCap) return false;
-        int G, NL;
-        stream_shape(&G, &NL);
-        return NL < STREAM_NLMAX;
-    }
-    // arguments of the deferred update of the iteration that has just been rotated away: its y+ target is now p_upd, its
-    // y+(prev) is p_xi, its w is p_acc_other and the w it produces is p_acc -- the input of the sweep being launched
-    StreamDual<T> stream_dual_args() const {
-        StreamDual<T> f{};
-        f.hx = d_hx; f.wPrev = p_acc_other; f.yprev = p_xi; f.ynew = p_upd; f.wnext = p_acc;
-        f.blo = d_blo; f.bhi = d_bhi;
-        f.lambda = (T)stepSize; f.invLambda = (T)(1.0 / stepSize); f.ln = (T)h_lam[h_it];
-        f.partials = d_partials;   // node0 is filled in by launch_stream
-        f.crownElems = 0; f.countCrown = 1;
-        if (cutStage > 0) { f.crownElems = (long long)h_stageCum[cutStage] * ny; f.countCrown = (rank == 0); }
-        return f;
     }
     static int slab_stride(int kp) { return (kp + 59) / 64 * 64 + 4; }   // >= kp, = 4 (mod 64): conflict-free MFMA B reads
     // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
@@ -756,7 +712,7 @@ struct Ctx : CtxBase {
     // hessianInput != nullptr: SmpcController::computeHessianOracalGlobalFbe (SmpcController.cu:884-1055) -- the same
     // sweep evaluated at `hessianInput` with sigma = 0 and every affine term zero, writing xdir / udir / H * dir
     // primalOut = false (inner iterations of a batch): x, u and v are not stored, only Hx (what the dual update reads)
-    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true, const StreamDual<T> *fuse = nullptr) {
+    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true) {
         SweepArgs<T> a = sweep_args();
         a.writePrimal = primalOut ? 1 : 0;
         if (hessianInput) {
@@ -779,7 +735,7 @@ struct Ctx : CtxBase {
             e0 = prof_begin(0);
             if (structured) {
                 launch_prep_m2(a);
-            } else if (int rc = launch_stream(a, fuse)) return rc;
+            } else if (int rc = launch_stream(a)) return rc;
             prof_end(e0);
         }
         e1 = prof_begin(1);
@@ -974,23 +930,16 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_cut + tail, 0, 2 * sizeof(T), stream));
         RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
         carryTail = true;
-        bool deferred = false;   // the previous iteration's dual update has not been launched: this sweep's streaming kernel does it
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            const StreamDual<T> fd = deferred ? stream_dual_args() : StreamDual<T>{};
-            if (int rc = launch_sweep(0, nullptr, k == n - 1, deferred ? &fd : nullptr)) { carryTail = false; pendingFin = false; return rc; }
-            // inner iterations: the dual update is left to the streaming kernel of the next sweep (k_stream_gemv<FUSE>)
-            deferred = k < n - 1 && can_defer_dual();
-            if (deferred) { mainPartials = d.nodes; deferredDuals++; }
-            else {
-                DualArgs<T> a = dual_args();
-                const hipEvent_t *e2 = prof_begin(2);
-                launch_dual_main(a, k == n - 1);
-                prof_end(e2);
-            }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { carryTail = false; pendingFin = false; return rc; }
+            DualArgs<T> a = dual_args();
+            const hipEvent_t *e2 = prof_begin(2);
+            launch_dual_main(a, k == n - 1);
+            prof_end(e2);
             // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
             // batch gets a launch of its own
             if (k == n - 1) {
@@ -1055,23 +1004,16 @@ struct Ctx : CtxBase {
         T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
         const bool s_ready = acc_ready;
         RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
-        bool deferred = false;   // the previous iteration's dual update has not been launched: this sweep's streaming kernel does it
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            const StreamDual<T> fd = deferred ? stream_dual_args() : StreamDual<T>{};
-            if (int rc = launch_sweep(0, nullptr, k == n - 1, deferred ? &fd : nullptr)) { pendingFin = false; return rc; }
-            // inner iterations: the dual update is left to the streaming kernel of the next sweep (k_stream_gemv<FUSE>)
-            deferred = k < n - 1 && can_defer_dual();
-            if (deferred) { mainPartials = d.nodes; deferredDuals++; }
-            else {
-                DualArgs<T> a = dual_args();
-                const hipEvent_t *e2 = prof_begin(2);
-                launch_dual_main(a, k == n - 1);
-                prof_end(e2);
-            }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { pendingFin = false; return rc; }
+            DualArgs<T> a = dual_args();
+            const hipEvent_t *e2 = prof_begin(2);
+            launch_dual_main(a, k == n - 1);
+            prof_end(e2);
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
                 const hipEvent_t *e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, (T *)nullptr,

@@ -199,27 +199,6 @@ def test_dual_stage_launch_shapes(trips, pipe, monkeypatch):
         s.close()
 
 
-@pytest.mark.parametrize("name,precision", [("medium", "f64"), ("widecrown", "f64"), ("small", "f32")])
-def test_deferred_dual_update_changes_no_bit(name, precision, monkeypatch):
-    """Inner iterations of a batch run their dual update in the prologue of the next sweep's streaming kernel
-    (k_stream_gemv<FUSE>); RAPIDNET_FUSE_DUAL=0 launches k_dual_stage every iteration instead.  Same element arithmetic,
-    same arg-max rule: every iterate and the whole primal-infeasibility history are bit-for-bit the same, in one batch
-    and across batches (the last iteration of a batch is always a launch of its own)."""
-    out = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("RAPIDNET_FUSE_DUAL", fuse)
-        p = synth.make_problem(name)
-        dh, ah = synth.forecast_at(p["forecast"], 0)
-        s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision)
-        s.initialiseSmpcController(dh, ah)
-        hist = np.concatenate([s.algorithmApg(33), s.apgIterate(17), s.apgIterate(3)])
-        out.append((hist, [s.get(bid).copy() for bid, _ in PAIRS]))
-        s.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    for (bid, nm), a, b in zip(PAIRS, out[0][1], out[1][1]):
-        assert np.array_equal(a, b), nm
-
-
 def test_counters_on_a_clean_run():
     p, o, s = make_pair("small")
     s.algorithmApg(40)
