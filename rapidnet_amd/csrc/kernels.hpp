@@ -258,22 +258,24 @@ template <typename T> struct Slot;
 template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
 template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4; };
 
-// Results of the streaming kernel leave with non-temporal stores.  One workgroup is resident per CU and it cannot retire
-// before its last stores are acknowledged, and written-back lines compete with the read stream: measured on the 493-scenario
-// tree, the kernel takes 572 us without its stores, 619 us with plain stores (write-back through L2) and 595 us with
-// non-temporal ones; the consumers (k_up_chain) read them 3 us slower from beyond L2 (interleaved A/B, tools/ab_rounds.sh:
-// 0.677 ms per iteration against 0.690).
-#ifndef RN_STREAM_NT_OUT
-#define RN_STREAM_NT_OUT 1
+// Results of the streaming kernel leave with write-through stores (system-scope relaxed atomic stores: `sc0 sc1` on gfx950).
+// One workgroup is resident per CU and it cannot retire before its last stores are acknowledged, and lines left dirty in L2
+// compete with the read stream when they are written back: measured on the 493-scenario tree, the kernel takes 572 us
+// without its stores, 619 us with plain stores (write-back through L2), 595 us with non-temporal ones -- whose consumers
+// (k_up_chain, k_gemm_vlv) then read them 3 us slower -- and 582-590 us with write-through stores, which the consumers read
+// as fast as plain ones.  Interleaved same-box A/B over 6 rounds (tools/ab_rounds.sh), ms per iteration: plain 0.687,
+// non-temporal 0.676, write-through 0.666.
+#ifndef RN_STREAM_OUT_POLICY
+#define RN_STREAM_OUT_POLICY 2   // 0 plain, 1 non-temporal, 2 write-through
 #endif
 template <typename T>
-__device__ __forceinline__ void stream_out(T v, T *dst) {
-#if RN_STREAM_NT_OUT
-    __builtin_nontemporal_store(v, dst);
-#else
-    *dst = v;
-#endif
+__device__ __forceinline__ void store_policy(T v, T *dst, int policy) {   // policy is a compile-time constant at every call site
+    if (policy == 2) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (policy == 1) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
 }
+template <typename T>
+__device__ __forceinline__ void stream_out(T v, T *dst) { store_policy(v, dst, RN_STREAM_OUT_POLICY); }
 template <typename T>
 __device__ __forceinline__ T stream_qa_elem(T sp, T d0, T y0, T d1, T y1) {   // roundings spelled out (fp32: contraction is otherwise the compiler's choice)
 #pragma clang fp contract(off)
