@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's full size (493-scenario N=24 Barcelona tree, 10 864 nodes, fp64).
 
-The CPU oracle needs ~6 GB and ~25 s for its factor step at this size, so it is run for two iterations only; the rest
-of the evidence is size-independent properties: the dense-block path and the structured path are two independent
+The CPU oracle needs ~6 GB and ~25 s for its factor step at this size and ~0.25 s per iteration, so it is run for 100
+iterations; the rest of the evidence is size-independent properties: the dense-block path and the structured path are two independent
 implementations of the same operator and must agree; the dual-gradient map is affine in the dual (linearity of
 Hx(w) - Hx(0)); the iteration is deterministic (bitwise repeatable)."""
 import numpy as np
@@ -68,7 +68,7 @@ def test_sweep_is_affine_in_the_dual(problem):
     s.close()
 
 
-def test_two_iterations_against_the_oracle_at_full_size(problem):
+def test_hundred_iterations_against_the_oracle_at_full_size(problem):
     from oracle.oracle import Oracle
 
     p, (dh, ah) = problem
@@ -87,4 +87,17 @@ def test_two_iterations_against_the_oracle_at_full_size(problem):
                     (capi.BUF_DUAL_XI, "dualXi"), (capi.BUF_RES_PSI, "resPsi")):
         assert relmax(s.get(bid), o.get(nm)) < 1e-9, nm
     assert np.abs(h - oh).max() <= 1e-9 * np.abs(oh).max()
+    # ... and 100 iterations (the oracle needs ~0.2 s per iteration at this size): north_star's bound is 1e-8 relative on
+    # the iterates; one device-resident batch on the GPU, the same count on the CPU.  Measured: 3.5e-13 after 50
+    # iterations, 9.2e-9 after 200 -- the iteration itself amplifies rounding differences on this data (see
+    # test_rounding_sensitivity_bounds_long_runs), so 200 would sit on the bound whatever the implementation.
+    oh2 = o.apg(100)         # algorithmApg semantics: both start again from zero duals
+    h2 = s.algorithmApg(100)
+    worst = {}
+    for bid, nm in ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_V, "v"), (capi.BUF_UPD_XI, "updXi"), (capi.BUF_UPD_PSI, "updPsi"),
+                    (capi.BUF_DUAL_XI, "dualXi"), (capi.BUF_RES_PSI, "resPsi")):
+        worst[nm] = relmax(s.get(bid), o.get(nm))
+    print("full size, 100 iterations, max relative difference to the oracle:", {k: "%.1e" % v for k, v in worst.items()})
+    assert max(worst.values()) < 1e-8, worst
+    assert np.abs(h2 - oh2).max() <= 1e-8 * np.abs(oh2).max()
     s.close()
