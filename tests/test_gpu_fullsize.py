@@ -101,3 +101,19 @@ def test_hundred_iterations_against_the_oracle_at_full_size(problem):
     assert max(worst.values()) < 1e-8, worst
     assert np.abs(h2 - oh2).max() <= 1e-8 * np.abs(oh2).max()
     s.close()
+
+
+def test_control_step_is_bitwise_repeatable(problem):
+    """Two contexts, the same inputs, one 500-iteration control step each (the reference's maxIterations): every iterate and
+    the whole primal-infeasibility history are bit-for-bit the same -- no atomics, no order-dependent reductions anywhere
+    on the path (dispatch order of 10 864 workgroups included)."""
+    p, (dh, ah) = problem
+    out = []
+    for _ in range(2):
+        s = _solver(problem, False)
+        u0 = s.controlAction(dh, ah, maxIterations=500)
+        out.append((u0.copy(), [s.get(bid).copy() for bid in (capi.BUF_X, capi.BUF_U, capi.BUF_UPD_XI, capi.BUF_UPD_PSI, capi.BUF_RES_XI)]))
+        s.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
