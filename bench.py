@@ -44,7 +44,49 @@ def parse():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"], help="sharded runs: 'rccl' = the library's own ncclAllReduce on the solver's stream (default); 'torch' = step-wise fallback, the cut payload is all-reduced through torch.distributed (slow; used automatically if the library's communicator cannot be created)")
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=7, help="further timed regions of --steps steps after the contract's one (median / min / max in the JSON line)")
+    ap.add_argument("--other-configs", default="barcelona31,wide4096", help="comma list of further BASELINE.json configs timed in the same run on 1 GPU "
+                    "(their own roofline objects, in the `configs` array of the JSON line); '' = none")
+    ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
+                    "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, one rank
+    per GPU) before this process has made any GPU / HIP call, relay rank 0's JSON line and return the launcher's exit code.
+    Nothing here imports torch or loads the HIP library; a process that has touched the GPU is never re-exec'ed."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:            # the ranks send everything but rank 0's result to stderr
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = proc.wait()
+    if rc == 0 and line is not None:
+        print(line, flush=True)
+        return 0
+    print("bench.py --gpus %d: the launcher exited with code %d%s" % (args.gpus, rc, "" if line is None else " after a result line (discarded)"), file=sys.stderr)
+    return rc if rc != 0 else 1
 
 
 def _cpu_model():
@@ -57,7 +99,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(problem_name, problem, precision, timed_iterations=20):
+def cpu_baseline(problem_name, problem, precision, timed_iterations=20, sample_levels=None):
     """The CPU oracle ("port" of the reference's sweep: oracle/apg_oracle.c, 1 thread pinned to one core) timed on THIS
     workload: the same network, tree, forecasts, step size and precision as the GPU run (SURVEY.md section 8(d),
     BASELINE.md section 2): 2 warm-up iterations, then `timed_iterations` iterations timed one by one; value = 1 / median.
@@ -81,6 +123,8 @@ def cpu_baseline(problem_name, problem, precision, timed_iterations=20):
     if scaled:
         idx, _, _, _, ne, N, branching = synth.CONFIGS[problem_name]
         sample_branching = list(branching[:-1]) if len(branching) > 1 else [2]
+        if sample_levels:   # the secondary configs of a run: a smaller sample keeps the whole bench within minutes
+            sample_branching = list(branching[:sample_levels])
         synth.CONFIGS["_cpu_sample"] = (idx, nx, nu, nd, ne, N, sample_branching)
         p = synth.make_problem("_cpu_sample", step_size=float(problem["config"]["stepSize"][0]))
         note = "; the full tree's blocks (%.0f GB) do not fit in host memory: timed on the %s sub-tree and scaled by nodes" % (
@@ -121,9 +165,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))     # one child process per rank, started before anything touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     sharded = world > 1 or args.force_shard or args.emulate_world > 0
     # stdout carries exactly ONE line, the JSON: libraries that write to fd 1 on their own (RCCL prints a version banner
@@ -138,13 +183,19 @@ def main():
         # torch.distributed is the CONTROL plane only (rendezvous, the 128-byte ncclUniqueId, barriers, max over ranks) and
         # runs over gloo on the host: the one RCCL communicator on each device is the solver library's own
         # (rn_comm_init), whose ncclAllReduce sits on the solver's stream -- torch never creates a second one
-        torch.cuda.set_device(local_rank)
+        ndev = torch.cuda.device_count()       # counting devices does not initialise the GPU
+        oversubscribed = ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if ndev < 1:
+            sys.exit("bench.py: no GPU visible")
+        device = local_rank % ndev               # fewer GPUs than ranks: RCCL will refuse the duplicates (see below)
+        torch.cuda.set_device(device)
         if "MASTER_ADDR" not in os.environ:   # --force-shard without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: loopback (the box's hostname may not resolve)
         dist.init_process_group("gloo", init_method="env://")
+    else:
+        device, oversubscribed = local_rank, False
     from rapidnet_amd import capi, synth
-    from rapidnet_amd import partition
 
     precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
     problem = synth.make_problem(args.workload)
@@ -152,9 +203,14 @@ def main():
     dh, ah = synth.forecast_at(problem["forecast"], 0)
     cut_stage = -1
     tree = problem["tree"]
+    debug_part = None
     if sharded:
-        cut_stage = partition.default_cut_stage(problem["tree"])
-        tree, _ = partition.local_tree(problem["tree"], rank, args.emulate_world if (world == 1 and args.emulate_world > 0) else world, cut_stage)
+        # the partition itself happens behind the C-ABI (rn_create_sharded); the debug modes (one rank driving the sharded code
+        # path: --force-shard, --emulate-world) take the rank-local tree from the same C partitioner and set the pieces by hand
+        cut_stage = capi.default_cut_stage(problem["tree"])
+        if world == 1:
+            debug_part = capi.partition_tree(problem["tree"], 0, max(args.emulate_world, 1), cut_stage)
+            tree = debug_part["tree"]
     uid, uid_error = None, ""
     if sharded:
         box = [None, ""]
@@ -166,6 +222,7 @@ def main():
         dist.broadcast_object_list(box, src=0)
         uid, uid_error = box
     fallback_reason = [None]
+    comm_ranks = [None]
     rccl_library = None
     if sharded:
         try:
@@ -173,10 +230,24 @@ def main():
         except Exception as e:
             rccl_library = "unavailable: %s" % e
 
-    def run_mode(structured, steps, warmup, profile_steps, new_uid=None):
+    def run_mode(structured, steps, warmup, profile_steps, new_uid=None, repeats=0, problem=problem, tree=tree, precision=precision, workload=args.workload,
+                 control_step=True):
         if sharded:
             import torch
-        s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
+        def make(uid_bytes):
+            if not sharded:
+                return capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
+            if world == 1:    # debug modes: rank 0's shard (or the whole tree) through the sharded code path with a one-rank communicator
+                s_ = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
+                s_.commInit(0, 1, uid_bytes)
+                s_.setCutStage(cut_stage, (debug_part["momE"], debug_part["momP"]))
+                return s_
+            # the real thing: partition + communicator + cut stage + children moments in ONE call of the C-ABI
+            return capi.Solver(problem["network"], problem["tree"], problem["config"], precision=precision, device=device, structured=structured,
+                               rank=rank, nranks=world, cut_stage=cut_stage, unique_id=uid_bytes)
+
+        dh, ah = synth.forecast_at(problem["forecast"], 0)
+        s = None
         if sharded:
             # the library's RCCL communicator; if any rank cannot create it, ALL ranks fall back to the step-wise exchange
             ok, err = 1, ""
@@ -186,17 +257,26 @@ def main():
                 ok, err = 0, uid_error or "no unique id"
             else:
                 try:
-                    s.commInit(rank, world, new_uid)
+                    s = make(new_uid)
                 except capi.RapidNetError as e:
                     ok, err = 0, str(e)
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                fallback_reason[0] = err or "a peer rank could not create the communicator"
-                s.close()
-                s = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=local_rank, structured=structured)
-                s.commInit(rank, world, None)
-            s.setCutStage(cut_stage, partition.cut_children_moments(problem["tree"], cut_stage))
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                fallback_reason[0] = next((e for e in errs if e), "a peer rank could not create the communicator")
+                if oversubscribed and not args.allow_oversubscribe:
+                    if s is not None:
+                        s.close()
+                    sys.exit("bench.py --gpus %d on a box with fewer GPUs: RCCL refused the communicator (%s); one rank per GPU is required "
+                             "(--allow-oversubscribe rehearses the launcher path over gloo)" % (world, fallback_reason[0]))
+                if s is not None:
+                    s.close()
+                s = make(None)
+            comm_ranks[0] = s.shardInfo()["comm_ranks"]
+        else:
+            s = make(None)
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
         theta = [1.0, 1.0]
@@ -236,15 +316,34 @@ def main():
         iterate(steps)
         barrier()
         dt = time.perf_counter() - t0
-        if dist is not None:
+
+        def max_over_ranks(v):
+            if dist is None:
+                return v
             import torch
 
-            t = torch.tensor([dt], dtype=torch.float64)
+            t = torch.tensor([v], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            return float(t.item())
+
+        dt = max_over_ranks(dt)
+        # the contract's timed region is the one above; `repeats` further regions of the same K steps give its spread
+        rep = []
+        for _ in range(max(0, repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            iterate(steps)
+            barrier()
+            rep.append(max_over_ranks(time.perf_counter() - t0))
+        spread = None
+        if rep:
+            allr = sorted([dt] + rep)
+            spread = {"regions": len(allr), "steps_per_region": steps, "ms_per_step_median": 1e3 * float(np.median(allr)) / steps,
+                      "ms_per_step_min": 1e3 * allr[0] / steps, "ms_per_step_max": 1e3 * allr[-1] / steps,
+                      "value_median": steps / float(np.median(allr)), "note": "region 1 is the contract's timed region (`value`); all regions max over ranks"}
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
         ctrl_ms = None
-        if not sharded:
+        if not sharded and control_step:
             s.controlAction(dh, ah, maxIterations=5)
             t1 = time.perf_counter()
             s.controlAction(dh, ah, maxIterations=500)
@@ -268,8 +367,10 @@ def main():
             names = ("stream_gemv" if not structured else "struct_prep+gemm_m2", "recursion+shared_gemms", "dual_update", "bookkeeping")
             for i, nm in enumerate(names):
                 classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
+            kinfo = s.kernelInfo()
+            dual_kernel = "k_dual_stage" if kinfo["dual_stage"] else "k_dual_fused"
             dual_s = 1e-3 * ms[2] / max(n[2], 1)
-            dual = {"kernel": "k_dual_stage", "achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
+            dual = {"kernel": dual_kernel, "workgroups": kinfo["dual_blocks"], "vectors_per_thread": kinfo["dual_trips"], "achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
                     "avg_launch_us": 1e6 * dual_s}
             dual["frac"] = dual["achieved"] / 8000.0
             # HBM traffic from the PMC counters is NOT measured by this run (rocprofv3 --pmc needs passes of its own): it is
@@ -277,7 +378,7 @@ def main():
             # the kernel sources this run executes; traffic_source says where the number comes from
             traffic, traffic_source = {}, {"measured_in_this_run": False, "file": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and args.workload == "barcelona493" and precision == "f64" and not sharded:
+            if os.path.exists(tpath) and workload == "barcelona493" and precision == "f64" and not sharded:
                 try:
                     from rapidnet_amd import build as _b
 
@@ -291,8 +392,8 @@ def main():
                 except Exception:
                     traffic = {}
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
-                roofline = {"kernel": "k_dual_stage", "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
-                            "frac": dual["frac"], "traffic": traffic.get("k_dual_stage_bytes_per_launch"), "traffic_source": traffic_source,
+                roofline = {"kernel": dual_kernel, "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
+                            "frac": dual["frac"], "traffic": traffic.get("k_dual_stage_bytes_per_launch") if kinfo["dual_stage"] else None, "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
                 if copy_ceiling:
                     roofline.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
@@ -307,15 +408,15 @@ def main():
                     roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
                     dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
-        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
+        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
                "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}
         s.close()
         return res
 
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
-    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid)
-    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid) if (args.structured or (not sharded and not args.dense_only)) else None
+    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats)
+    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats if args.structured else 0) if (args.structured or (not sharded and not args.dense_only)) else None
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
@@ -340,7 +441,8 @@ def main():
                 "parallelism": "1 GPU" if not sharded else ("subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage if not fallback_reason[0]
                                                             else "subtree sharding below stage %d, FALLBACK exchange through torch.distributed, step-wise (%s)" % (cut_stage, fallback_reason[0]))},
             "local_nodes": int(tree["nodes"][0]),
-            "rccl": None if not sharded else {"ranks": world, "library": rccl_library, "communicator": "one per device, owned by librapidnet_hip (rn_comm_init); "
+            "timing_spread": head["spread"],
+            "rccl": None if not sharded else {"ranks": world, "ranks_seen_by_rccl": comm_ranks[0], "library": rccl_library, "communicator": "one per device, owned by librapidnet_hip (rn_comm_init); "
                                               "ncclUniqueId and barriers travel over torch.distributed/gloo",
                                               "exchange": "torch.distributed fallback: " + fallback_reason[0] if fallback_reason[0] else "ncclAllReduce on the solver's stream"},
             "roofline": roofline, "kernel_classes": classes, "batch_counters": head["batch_counters"],
@@ -351,6 +453,28 @@ def main():
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
+        # the other single-GPU configurations of BASELINE.json, timed in the same run (dense per-node blocks, the same protocol:
+        # W warm-up steps, K timed steps, the per-launch hipEvent pass); each with its own roofline object and CPU leg
+        others = [w for w in args.other_configs.split(",") if w and w != args.workload] if (not sharded and not args.structured and args.workload == "barcelona493") else []
+        if others:
+            out["configs"] = []
+        for w in others:
+            prec_w = "f32" if w.startswith("wide") else "f64"
+            entry = {"workload": w, "dtype": prec_w}
+            try:
+                pw = synth.make_problem(w)
+                r = run_mode(False, args.steps, args.warmup, args.profile_steps, None, repeats=min(args.repeats, 4), problem=pw, tree=pw["tree"],
+                             precision=prec_w, workload=w, control_step=False)
+                nxw, nuw, nvw, ndw, Nw = r["dims"]
+                entry.update({"config": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (w, nxw, nuw, nvw, ndw, Nw, int(pw["tree"]["K"][0]), int(pw["tree"]["nodes"][0])),
+                              "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"], "steps": args.steps, "warmup": args.warmup,
+                              "timing_spread": r["spread"], "roofline": r["roofline"], "kernel_classes": r["kernel_classes"]})
+                if not args.no_cpu_baseline:
+                    entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
+                del pw
+            except Exception as e:   # a config that does not fit this device / host is reported, not fatal for the headline
+                entry["error"] = "%s: %s" % (type(e).__name__, e)
+            out["configs"].append(entry)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

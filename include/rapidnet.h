@@ -202,6 +202,10 @@ int rn_lbfgs_column(rn_ctx *ctx, int set, int which, int col, double *host, size
 size_t rn_buffer_size(const rn_ctx *ctx, int buffer_id); /* element count, 0 for a bad id */
 int rn_get(rn_ctx *ctx, int buffer_id, double *host, size_t n);
 int rn_set(rn_ctx *ctx, int buffer_id, const double *host, size_t n);
+/* elements [first, first + n) only (e.g. the nx reals of node 0: first = 0, n = nx); dual-shaped buffers (RN_BUF_XI ...
+ * RN_BUF_UMAX and the FBE vectors) are addressed in whole nodes (first and n multiples of the per-node dimension) */
+int rn_get_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, double *host);
+int rn_set_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, const double *host);
 /* one node's operator block, reference layout (col-major, ld = nv) */
 int rn_get_operator(rn_ctx *ctx, int op_id, int node, double *host, size_t n);
 
@@ -214,6 +218,10 @@ int rn_profile_reset(rn_ctx *ctx);
 int rn_profile_read(rn_ctx *ctx, double ms[4], long launches[4]);
 /* algorithmic HBM bytes of ONE launch of the dominant kernels, as defined in DESIGN.md */
 int rn_algorithmic_bytes(const rn_ctx *ctx, double *backwardStageBytesTotal, double *dualUpdateBytes);
+/* which kernels an iteration of this context launches: info = {1 if k_dual_stage is the main pass of the fused dual update
+ * (0: the flat k_dual_fused), its workgroups, vectors per thread, pipeline depth, k_stream_gemv columns per span, slots per
+ * thread and span, first chain stage c*, 1 if the v / Lv products run as the fused slab kernel k_gemm_vlv} */
+int rn_get_kernel_info(rn_ctx *ctx, int info[8]);
 /* streaming ceilings of THIS device measured with do-nothing kernels (16 B per lane per load, non-temporal): flat
  * grid-stride read-only GB/s and copy GB/s (read + written bytes), best of `reps` passes over `bytes`.
  * bench.py reports them beside the 8 TB/s spec peak as the practical denominator. */
@@ -264,6 +272,65 @@ int rn_get_counters(rn_ctx *ctx, long out[4]);
  * id128 == NULL records rank / nranks without creating an RCCL communicator. */
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase);
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n);
+
+/* ---- multi-GPU through the boundary: partition + communicator + cut stage in one call --------------------------------
+ * The reference is single-GPU: its seam for a whole solver is `Engine(SmpcConfiguration*)` / `SmpcController(string)`
+ * (Engine.cuh:68, SmpcController.cuh:57-87).  A sharded solver is created the same way, one per process / GPU, from the
+ * FULL scenario tree plus (rank, nranks): the library cuts the tree, keeps the rank's subtrees and
+ * the replicated crown, creates the RCCL communicator and installs the static children moments -- the host classes pass
+ * rank / nranks straight through (Engine(config, precision, device, rank, nranks, id128)). */
+
+/* First stage at which the tree has all its K scenario chains (the most balanced cut: K subtrees dealt round-robin);
+ * max(1, N-1) for a tree that branches until the end.  Negative RN_E_* on bad input. */
+int rn_default_cut_stage(const rn_dims *dims, const rn_tree *tree);
+
+/* The rank-local scenario tree of a subtree partition.  Nodes of stages < cutStage (the crown) are replicated on every
+ * rank, the subtrees rooted at stage cutStage are dealt round-robin by position; local nodes keep their stage-by-stage
+ * order, so a local tree is an ordinary scenario tree (ScenarioTree.cuh:92-154 conventions: 1-based ancestor, nChildren
+ * lists the non-leaf nodes -- a cut parent without local children is a local leaf).  All arrays are owned by the
+ * partition object and stay valid until rn_partition_destroy. */
+typedef struct {
+    rn_dims dims;                 /* local: nodes, K (local leaves), nNonLeafNodes; nx..N as given                    */
+    rn_tree tree;                 /* local tree arrays                                                                 */
+    const int *globalNode;        /* [dims.nodes] index of every local node in the full tree                          */
+    const double *errorDemandNode, *errorPriceNode; /* local rows of the full tree's errors (NULL if none were given)  */
+    int rank, nranks, cutStage, nCutParents;
+    /* static children moments of the cut parents over ALL their children (rn_set_cut_children_moments): the replacement
+     * of the children loop of calculateZeta (Utilities.cu:100-131) for nodes whose children live on other ranks */
+    const double *momE;           /* [nCutParents][nd]  sum_c p_c errorDemand_c   (NULL if no errors were given)        */
+    const double *momP;           /* [nCutParents]      sum_c p_c                                                      */
+    void *owner;                  /* internal */
+} rn_partition;
+int rn_partition_create(const rn_dims *dims, const rn_tree *tree, const double *errorDemandNode /* nodes*nd or NULL */,
+                        const double *errorPriceNode /* nodes*nu or NULL */, int rank, int nranks,
+                        int cutStage /* <= 0: rn_default_cut_stage */, rn_partition *out);
+void rn_partition_destroy(rn_partition *p);
+
+/* rn_create for rank `rank` of `nranks`: partition (above) + rn_create on the local tree + rn_set_tree_errors (local rows)
+ * + rn_comm_init + rn_set_cut_stage + rn_set_cut_children_moments.  id128 = the ncclUniqueId of rn_comm_unique_id (rank 0's,
+ * distributed by the caller); NULL creates no RCCL communicator (the exchange is then a test's job: rn_debug_* hooks or
+ * rn_debug_local_group_join).  nranks == 1 gives a plain unsharded context. */
+int rn_create_sharded(const rn_dims *dims, const rn_tree *tree, const double *errorDemandNode, const double *errorPriceNode,
+                      int precision, int device, int rank, int nranks, int cutStage, const void *id128, rn_ctx **out);
+/* what a sharded context is: info = {rank, nranks, cut stage (-1: none), cut parents, ranks the RCCL communicator itself
+ * reports (ncclCommCount; 0 without a communicator), local nodes, nodes of the full tree} */
+int rn_shard_info(rn_ctx *ctx, int info[7]);
+/* index in the FULL tree of every local node (rn_get returns local node-major arrays); identity for unsharded contexts */
+int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
+
+/* Test facility: an in-process stand-in for the communicator, so that the device-resident sharded path (checkpoint, dist^2
+ * tail, verdict vote, replay) can run with several ranks on a box where RCCL cannot (one GPU: "Duplicate GPU detected").
+ * rn_debug_set_allreduce installs a callback that is called wherever the library would call ncclAllReduce(sum, in place):
+ * devBuf / count / isF64 describe the payload, stream is the context's hipStream_t; it must return 0 after the reduced
+ * values are (or are stream-ordered to be) in devBuf.  rn_debug_local_group_* is such a callback inside the library for
+ * `nranks` contexts of ONE process, each driven by its own host thread: stream sync, barrier, every rank sums the payloads
+ * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s fails the others with
+ * RN_E_COMM instead of hanging them. */
+typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, void *stream);
+int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
+int rn_debug_local_group_create(int nranks, void **group);
+int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);
+int rn_debug_local_group_destroy(void *group);
 
 #ifdef __cplusplus
 }

@@ -51,14 +51,18 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+def _hip_deps():
+    """Everything librapidnet_hip.so is compiled from (first entry = the translation unit)."""
+    return kernel_sources() + [os.path.join(CSRC, "partition.hpp"), os.path.join(ROOT, "include", "rapidnet.h")]
+
+
 def build_hip(force=False, verbose=False, defines=(), out=None):
     """librapidnet_hip.so: the C-ABI (include/rapidnet.h) + every HIP kernel, for gfx950 only.
 
     `defines` / `out` build tuning variants (e.g. RN_STREAM_G=6) next to the default library; capi.load() picks the
     library named by $RAPIDNET_LIB when set."""
     out = out or LIB_HIP
-    srcs = [os.path.join(CSRC, "rapidnet_capi.hip"), os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "fbe_kernels.hpp"),
-            os.path.join(CSRC, "fbe_methods.inc"), os.path.join(ROOT, "include", "rapidnet.h")]
+    srcs = _hip_deps()
     if force or _stale(out, srcs, defines):
         tmp = "%s.tmp.%d" % (out, os.getpid())   # compile beside the target, then rename: a concurrent loader never sees a partial file
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
@@ -76,8 +80,7 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
 
 
 def hip_is_stale():
-    srcs = kernel_sources() + [os.path.join(ROOT, "include", "rapidnet.h")]
-    return _stale(LIB_HIP, [srcs[0], srcs[1], srcs[2], srcs[3], srcs[4]])
+    return _stale(LIB_HIP, _hip_deps())
 
 
 LIB_HOST = os.path.join(HERE, "librapidnet_host.so")
@@ -99,7 +102,7 @@ def build_host(force=False):
     test_src = os.path.join(ROOT, "tests", "cpp", "test_host.cpp")
     os.makedirs(BIN_DIR, exist_ok=True)
     if force or _stale(TEST_HOST, [test_src] + deps + hdr):
-        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-o", TEST_HOST, test_src, "-L" + HERE, "-lrapidnet_host",
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-pthread", "-o", TEST_HOST, test_src, "-L" + HERE, "-lrapidnet_host",
                                "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN/.."])
         _stamp(TEST_HOST, [test_src] + deps + hdr)
     return LIB_HOST

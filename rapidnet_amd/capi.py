@@ -33,6 +33,8 @@ SYMBOLS = [
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
+    "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
+    "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
 ]
 
 
@@ -49,6 +51,14 @@ class RnSystem(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("matB", "matGd", "matL", "matLhat", "costW", "matDiagPrecnd", "vecXmin",
                                          "vecXmax", "vecXsafe", "vecUmin", "vecUmax", "costAlpha1")]
 
+
+class RnPartition(C.Structure):
+    _fields_ = [("dims", RnDims), ("tree", RnTree), ("globalNode", C.POINTER(C.c_int)), ("errorDemandNode", C.POINTER(C.c_double)),
+                ("errorPriceNode", C.POINTER(C.c_double)), ("rank", C.c_int), ("nranks", C.c_int), ("cutStage", C.c_int),
+                ("nCutParents", C.c_int), ("momE", C.POINTER(C.c_double)), ("momP", C.POINTER(C.c_double)), ("owner", C.c_void_p)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 _LIB = None
 
@@ -115,6 +125,8 @@ def load():
     lib.rn_get.argtypes = [vp, ip, dp, C.c_size_t]
     lib.rn_set.argtypes = [vp, ip, dp, C.c_size_t]
     lib.rn_get_operator.argtypes = [vp, ip, ip, dp, C.c_size_t]
+    lib.rn_get_range.argtypes = [vp, ip, C.c_size_t, C.c_size_t, dp]
+    lib.rn_set_range.argtypes = [vp, ip, C.c_size_t, C.c_size_t, dp]
     lib.rn_profile_enable.argtypes = [vp, ip]
     lib.rn_profile_reset.argtypes = [vp]
     lib.rn_profile_read.argtypes = [vp, dp, dp]
@@ -127,6 +139,7 @@ def load():
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
     lib.rn_get_counters.argtypes = [vp, dp]
+    lib.rn_get_kernel_info.argtypes = [vp, dp]
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
     lib.rn_set_operator_mode.argtypes = [vp, ip]
     lib.rn_set_warm_start.argtypes = [vp, ip]
@@ -145,6 +158,17 @@ def load():
     lib.rn_line_search_ame_lbfgs_update.argtypes = [vp, C.c_double, dp]
     lib.rn_lbfgs_state.argtypes = [vp, ip, dp, dp, dp, dp]
     lib.rn_lbfgs_column.argtypes = [vp, ip, ip, ip, dp, C.c_size_t]
+    lib.rn_default_cut_stage.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree)]
+    lib.rn_partition_create.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree), dp, dp, ip, ip, ip, C.POINTER(RnPartition)]
+    lib.rn_partition_destroy.argtypes = [C.POINTER(RnPartition)]
+    lib.rn_partition_destroy.restype = None
+    lib.rn_create_sharded.argtypes = [C.POINTER(RnDims), C.POINTER(RnTree), dp, dp, ip, ip, ip, ip, ip, dp, C.POINTER(vp)]
+    lib.rn_shard_info.argtypes = [vp, dp]
+    lib.rn_shard_global_nodes.argtypes = [vp, dp, C.c_size_t]
+    lib.rn_debug_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.rn_debug_local_group_create.argtypes = [ip, C.POINTER(vp)]
+    lib.rn_debug_local_group_join.argtypes = [vp, vp, ip]
+    lib.rn_debug_local_group_destroy.argtypes = [vp]
     _LIB = lib
     return lib
 
@@ -173,7 +197,11 @@ class Solver:
     through the C-ABI.  `problem` dicts use the reference's JSON schema.
     """
 
-    def __init__(self, network, tree, config, precision="f64", device=0, structured=False):
+    def __init__(self, network, tree, config, precision="f64", device=0, structured=False, rank=0, nranks=1, cut_stage=0,
+                 unique_id=None):
+        """nranks > 1: `tree` is the FULL scenario tree and the context is rank `rank`'s shard of it (rn_create_sharded:
+        partition, communicator from `unique_id` -- None = none, the exchange is a test's job --, cut stage, children
+        moments); self.nodes is then the LOCAL node count and self.global_nodes maps local -> full-tree node ids."""
         self.lib = load()
         self.structured = bool(structured)
         self.network, self.tree, self.config = network, tree, config
@@ -182,23 +210,31 @@ class Solver:
         self.N, self.K, self.nodes = (int(_s(tree, k)) for k in ("N", "K", "nodes"))
         self.ny = 2 * self.nx + self.nu
         self.max_iterations = int(_s(config, "maxIterations"))
-        dims = RnDims(self.nx, self.nu, self.nv, self.nd, self.N, self.K, self.nodes, int(_s(tree, "nNonLeafNodes")))
-        keep = [_i32(tree[k]) for k in ("stages", "nodesPerStage", "nodesPerStageCumul", "ancestor", "nChildren", "nChildrenCumul")]
-        keep.append(_f64(tree["probNode"]))
-        if len(keep[1]) < self.N + 1 or len(keep[2]) < self.N + 2:
-            raise RapidNetError("nodesPerStage needs N+1 and nodesPerStageCumul N+2 entries (ScenarioTree.cu:66-75)")
-        t = RnTree(*[a.ctypes.data for a in keep])
+        dims, t, keep = tree_structs(tree, self.nx, self.nu, self.nv, self.nd)
+        ed, ep = _f64(tree["errorDemandNode"]), _f64(tree["errorPriceNode"])
         h = C.c_void_p()
-        rc = self.lib.rn_create(C.byref(dims), C.byref(t), RN_F64 if precision == "f64" else RN_F32, int(device), C.byref(h))
-        if rc != 0:
-            raise RapidNetError("rn_create failed (%d): %s" % (rc, self.lib.rn_last_error(None).decode()))
-        self.h = h
+        prec = RN_F64 if precision == "f64" else RN_F32
+        self.rank, self.nranks = int(rank), int(nranks)
+        if self.nranks > 1:
+            idbuf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+            rc = self.lib.rn_create_sharded(C.byref(dims), C.byref(t), ed.ctypes.data, ep.ctypes.data, prec, int(device), self.rank, self.nranks,
+                                            int(cut_stage), C.cast(idbuf, C.c_void_p) if idbuf is not None else None, C.byref(h))
+            if rc != 0:
+                raise RapidNetError("rn_create_sharded failed (%d): %s" % (rc, self.lib.rn_last_error(None).decode()))
+            self.h = h
+            info = self.shardInfo()
+            self.full_nodes, self.nodes = self.nodes, info["local_nodes"]
+            self.global_nodes = self.shardGlobalNodes()
+        else:
+            rc = self.lib.rn_create(C.byref(dims), C.byref(t), prec, int(device), C.byref(h))
+            if rc != 0:
+                raise RapidNetError("rn_create failed (%d): %s" % (rc, self.lib.rn_last_error(None).decode()))
+            self.h = h
+            self._check(self.lib.rn_set_tree_errors(self.h, ed.ctypes.data, ep.ctypes.data))
         self._check(self.lib.rn_set_parameters(self.h, float(_s(config, "stepSize")), float(_s(config, "penaltyStateX")),
                                                float(_s(config, "penaltySafetyX"))))
         if self.structured:
             self._check(self.lib.rn_set_operator_mode(self.h, 1))
-        ed, ep = _f64(tree["errorDemandNode"]), _f64(tree["errorPriceNode"])
-        self._check(self.lib.rn_set_tree_errors(self.h, ed.ctypes.data, ep.ctypes.data))
 
     def close(self):
         if getattr(self, "h", None):
@@ -385,6 +421,15 @@ class Solver:
         v = _f64(values)
         self._check(self.lib.rn_set(self.h, buf, v.ctypes.data, v.size))
 
+    def getRange(self, buf, first, n):
+        out = np.zeros(n)
+        self._check(self.lib.rn_get_range(self.h, buf, int(first), int(n), out.ctypes.data))
+        return out
+
+    def setRange(self, buf, first, values):
+        v = _f64(values)
+        self._check(self.lib.rn_set_range(self.h, buf, int(first), v.size, v.ctypes.data))
+
     def getOperator(self, op, node):
         nx, nu, nv = self.nx, self.nu, self.nv
         n = {OP_PHI: nv * 2 * nx, OP_D: nv * 2 * nx, OP_PSI: nv * nu, OP_F: nv * nu, OP_OMEGA: nv * nv, OP_THETA: nv * nx,
@@ -451,6 +496,31 @@ class Solver:
             E, P = _f64(moments[0]), _f64(moments[1])
             self._check(self.lib.rn_set_cut_children_moments(self.h, E.ctypes.data, P.ctypes.data, P.size))
 
+    def shardInfo(self):
+        out = np.zeros(7, dtype=np.int32)
+        self._check(self.lib.rn_shard_info(self.h, out.ctypes.data))
+        return dict(zip(("rank", "nranks", "cut_stage", "cut_parents", "comm_ranks", "local_nodes", "full_nodes"), (int(v) for v in out)))
+
+    def shardGlobalNodes(self):
+        n = self.shardInfo()["local_nodes"]
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.rn_shard_global_nodes(self.h, out.ctypes.data, n))
+        return out
+
+    def debugSetAllreduce(self, fn):
+        """fn(dev_ptr, count, is_f64, stream) -> 0; called in place of ncclAllReduce (test facility)."""
+        self._ar_cb = ALLREDUCE_FN(lambda user, buf, count, f64, stream: int(fn(buf, count, f64, stream))) if fn is not None else C.cast(None, ALLREDUCE_FN)
+        self._check(self.lib.rn_debug_set_allreduce(self.h, self._ar_cb, None))
+
+    def joinLocalGroup(self, group, rank):
+        self._check(self.lib.rn_debug_local_group_join(self.h, group, int(rank)))
+
+    def kernelInfo(self):
+        out = np.zeros(8, dtype=np.int32)
+        self._check(self.lib.rn_get_kernel_info(self.h, out.ctypes.data))
+        keys = ("dual_stage", "dual_blocks", "dual_trips", "dual_pipe", "stream_G", "stream_NL", "chain_stage", "vlv_slab")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def counters(self):
         """rn_apg_iterate batch bookkeeping: dict(optimistic, exact, replayed, hold)."""
         out = np.zeros(4, dtype=np.int64)
@@ -461,6 +531,70 @@ class Solver:
         out = np.zeros(4 * n)
         self._check(self.lib.rn_get_history_parts(self.h, int(first), int(n), out.ctypes.data))
         return out.reshape(n, 4)
+
+
+def tree_structs(tree, nx, nu, nv, nd):
+    """(RnDims, RnTree, arrays to keep alive) of a tree dict in the reference's JSON schema."""
+    N, K, nodes = (int(_s(tree, k)) for k in ("N", "K", "nodes"))
+    dims = RnDims(nx, nu, nv, nd, N, K, nodes, int(_s(tree, "nNonLeafNodes")))
+    keep = [_i32(tree[k]) for k in ("stages", "nodesPerStage", "nodesPerStageCumul", "ancestor", "nChildren", "nChildrenCumul")]
+    keep.append(_f64(tree["probNode"]))
+    if len(keep[1]) < N + 1 or len(keep[2]) < N + 2:
+        raise RapidNetError("nodesPerStage needs N+1 and nodesPerStageCumul N+2 entries (ScenarioTree.cu:66-75)")
+    return dims, RnTree(*[a.ctypes.data for a in keep]), keep
+
+
+def default_cut_stage(tree, nx=1, nu=1, nv=1, nd=1):
+    dims, t, _keep = tree_structs(tree, nx, nu, nv, nd)
+    c = load().rn_default_cut_stage(C.byref(dims), C.byref(t))
+    if c < 0:
+        raise RapidNetError("rn_default_cut_stage failed (%d)" % c)
+    return c
+
+
+def partition_tree(tree, rank, nranks, cut_stage=0):
+    """rn_partition_create on a tree dict: returns a dict with the local tree (reference JSON schema, like
+    rapidnet_amd.partition.local_tree), 'globalNode', 'cutStage', 'momE' [parents, nd], 'momP' [parents]."""
+    lib = load()
+    nd, nu = int(_s(tree, "dimDemand")), int(_s(tree, "dimPrice"))
+    dims, t, _keep = tree_structs(tree, 1, nu, 1, nd)
+    ed, ep = _f64(tree["errorDemandNode"]), _f64(tree["errorPriceNode"])
+    part = RnPartition()
+    rc = lib.rn_partition_create(C.byref(dims), C.byref(t), ed.ctypes.data, ep.ctypes.data, int(rank), int(nranks), int(cut_stage), C.byref(part))
+    if rc != 0:
+        raise RapidNetError("rn_partition_create failed (%d): %s" % (rc, lib.rn_last_error(None).decode()))
+    try:
+        n, N = part.dims.nodes, part.dims.N
+        iarr = lambda ptr, cnt: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int)), (cnt,)).copy() if cnt else np.zeros(0, np.int32)
+        darr = lambda ptr, cnt: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (cnt,)).copy() if cnt else np.zeros(0)
+        local = {
+            "N": [N], "K": [part.dims.K], "dimDemand": [nd], "dimPrice": [nu], "nodes": [n], "nChildrenTot": [n - 1],
+            "nNonLeafNodes": [part.dims.nNonLeafNodes],
+            "stages": iarr(part.tree.stages, n).tolist(), "nodesPerStage": iarr(part.tree.nodesPerStage, N + 1).tolist(),
+            "nodesPerStageCumul": iarr(part.tree.nodesPerStageCumul, N + 2).tolist(), "ancestor": iarr(part.tree.ancestor, n).tolist(),
+            "nChildren": iarr(part.tree.nChildren, part.dims.nNonLeafNodes).tolist(), "nChildrenCumul": iarr(part.tree.nChildrenCumul, n).tolist(),
+            "probNode": darr(part.tree.probNode, n).tolist(),
+            "errorDemandNode": darr(part.errorDemandNode, n * nd).tolist(), "errorPriceNode": darr(part.errorPriceNode, n * nu).tolist(),
+        }
+        cc = np.bincount(np.asarray(local["ancestor"])[1:] - 1, minlength=n)
+        local["leaves"] = (np.flatnonzero(cc == 0) + 1).tolist()
+        local["children"] = [i + 1 for i in range(1, n)]
+        return {"tree": local, "globalNode": iarr(part.globalNode, n), "cutStage": part.cutStage,
+                "momE": darr(part.momE, part.nCutParents * nd).reshape(part.nCutParents, nd), "momP": darr(part.momP, part.nCutParents)}
+    finally:
+        lib.rn_partition_destroy(C.byref(part))
+
+
+def local_group_create(nranks):
+    g = C.c_void_p()
+    rc = load().rn_debug_local_group_create(int(nranks), C.byref(g))
+    if rc != 0:
+        raise RapidNetError("rn_debug_local_group_create failed (%d)" % rc)
+    return g
+
+
+def local_group_destroy(group):
+    load().rn_debug_local_group_destroy(group)
 
 
 def comm_library():

@@ -19,7 +19,32 @@ Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguratio
     create(precision, device);
 }
 
-void Engine::create(int precision, int device) {
+Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *id128, int cutStage) : ctx(nullptr) {
+    ptrMySmpcConfig = smpcConfig;
+    ptrMyNetwork = new DwnNetwork(smpcConfig->getPathToNetwork());
+    ptrMyScenarioTree = new ScenarioTree(smpcConfig->getPathToScenarioTree());
+    create(precision, device, rank, nranks, id128, cutStage);
+}
+
+Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks,
+               const void *id128, int cutStage) : ctx(nullptr) {
+    ptrMyNetwork = network; ptrMyScenarioTree = scenarioTree; ptrMySmpcConfig = smpcConfig;
+    create(precision, device, rank, nranks, id128, cutStage);
+}
+
+uint_t Engine::getNumLocalNodes() {
+    int info[7];
+    check(rn_shard_info(ctx, info), "rn_shard_info");
+    return (uint_t)info[5];
+}
+std::vector<int> Engine::getGlobalNodes() {
+    std::vector<int> g(getNumLocalNodes());
+    check(rn_shard_global_nodes(ctx, g.data(), g.size()), "rn_shard_global_nodes");
+    return g;
+}
+
+void Engine::create(int precision, int device, int rank, int nranks, const void *id128, int cutStage) {
+    myRank = rank; numRanks = nranks;
     priceUncertaintyFlag = true; demandUncertaintyFlag = true;
     const string alg = ptrMySmpcConfig->getOptimisationAlgorithm();   // Engine.cu:151-163
     globalFbeFlag = (alg == "globalFbeAlgorithm");
@@ -36,11 +61,12 @@ void Engine::create(int precision, int device) {
     t.nodesPerStageCumul = ptrMyScenarioTree->getNodesPerStageCumul(); t.ancestor = ptrMyScenarioTree->getAncestorArray();
     t.nChildren = ptrMyScenarioTree->getNumChildren(); t.nChildrenCumul = ptrMyScenarioTree->getNumChildrenCumul();
     t.probNode = ptrMyScenarioTree->getProbArray();
-    const int rc = rn_create(&d, &t, precision, device, &ctx);
-    if (rc != RN_OK) throw std::runtime_error(string("rn_create: ") + rn_last_error(nullptr));
+    // one entry point for both cases: nranks == 1 is a plain rn_create + rn_set_tree_errors
+    const int rc = rn_create_sharded(&d, &t, ptrMyScenarioTree->getErrorDemandArray(), ptrMyScenarioTree->getErrorPriceArray(), precision, device,
+                                     rank, nranks, cutStage, id128, &ctx);
+    if (rc != RN_OK) throw std::runtime_error(string("rn_create_sharded: ") + rn_last_error(nullptr));
     check(rn_set_parameters(ctx, ptrMySmpcConfig->getStepSize(), ptrMySmpcConfig->getPenaltyState(), ptrMySmpcConfig->getPenaltySafety()),
           "rn_set_parameters");
-    check(rn_set_tree_errors(ctx, ptrMyScenarioTree->getErrorDemandArray(), ptrMyScenarioTree->getErrorPriceArray()), "rn_set_tree_errors");
     if (!apgFlag)   // SmpcController::allocateGlobalFbeAlgorithm / allocateNamaAlgorithm / allocateLbfgsBuffer (SmpcController.cu:234-330)
         check(rn_set_algorithm(ctx, globalFbeFlag ? RN_ALG_GLOBAL_FBE : RN_ALG_NAMA, (int)ptrMySmpcConfig->getLbfgsBufferSize()), "rn_set_algorithm");
 }
@@ -73,6 +99,8 @@ void Engine::setDemandUncertaintyFlag(bool f) {
 size_t Engine::getBufferSize(int id) { return rn_buffer_size(ctx, id); }
 void Engine::getBuffer(int id, real_t *host) { check(rn_get(ctx, id, host, rn_buffer_size(ctx, id)), "rn_get"); }
 void Engine::setBuffer(int id, const real_t *host) { check(rn_set(ctx, id, host, rn_buffer_size(ctx, id)), "rn_set"); }
+void Engine::getBufferRange(int id, size_t first, size_t n, real_t *host) { check(rn_get_range(ctx, id, first, n, host), "rn_get_range"); }
+void Engine::setBufferRange(int id, size_t first, size_t n, const real_t *host) { check(rn_set_range(ctx, id, first, n, host), "rn_set_range"); }
 void Engine::getOperator(int op, uint_t node, real_t *host, size_t n) { check(rn_get_operator(ctx, op, node, host, n), "rn_get_operator"); }
 
 void Engine::calculateMatLandMatLhat() {

@@ -16,6 +16,20 @@ public:
     // (Engine.cu:126-132).  precision: RN_F64 (default) or RN_F32; device: HIP device ordinal.
     explicit Engine(SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0);
     Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0);
+    // Multi-GPU (new; the reference is single-GPU): rank `rank` of `nranks`, one process and one GPU per rank.  The engine is
+    // given the FULL network / tree / configuration exactly as above; the library keeps this rank's subtrees plus the
+    // replicated crown (rn_create_sharded: partition below `cutStage`, 0 = the most balanced cut), creates the RCCL
+    // communicator from `ncclUniqueId128` (rn_comm_unique_id on rank 0, distributed by the caller; NULL: no communicator, the
+    // exchange is a test's job) and all-reduces the cut parents' children sums once per APG iteration.  Everything else --
+    // factorStep, updateStateControl, eliminateInputDistubanceCoupling, the controller -- is called as on one GPU; node-major
+    // buffers are local (getNumLocalNodes() nodes; getGlobalNodes() maps them to nodes of the full tree).
+    Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *ncclUniqueId128, int cutStage = 0);
+    Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks,
+           const void *ncclUniqueId128, int cutStage = 0);
+    int getRank() { return myRank; }
+    int getNumRanks() { return numRanks; }
+    uint_t getNumLocalNodes();                       // nodes this rank holds (= the tree's node count on one GPU)
+    std::vector<int> getGlobalNodes();               // index in the full tree of every local node
     void eliminateInputDistubanceCoupling(real_t *nominalDemand, real_t *nominalPrices);  // Engine.cu:1147
     void updateStateControl(real_t *currentX, real_t *prevU, real_t *prevDemand);        // Engine.cu:1300
     void factorStep();                                                                    // Engine.cu:671
@@ -42,11 +56,14 @@ public:
     size_t getBufferSize(int bufferId);
     void getBuffer(int bufferId, real_t *host);
     void setBuffer(int bufferId, const real_t *host);
+    void getBufferRange(int bufferId, size_t first, size_t n, real_t *host);         // elements [first, first + n) only
+    void setBufferRange(int bufferId, size_t first, size_t n, const real_t *host);
     void getOperator(int opId, uint_t node, real_t *host, size_t n);
     ~Engine();
 
 private:
-    void create(int precision, int device);
+    void create(int precision, int device, int rank = 0, int nranks = 1, const void *id128 = nullptr, int cutStage = 0);
+    int myRank = 0, numRanks = 1;
     void check(int rc, const char *what);
     DwnNetwork *ptrMyNetwork;
     ScenarioTree *ptrMyScenarioTree;

@@ -27,6 +27,18 @@ SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false),
     economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
 
+SmpcController::SmpcController(string pathToConfigFile, int rank, int nranks, const void *id128, int device, int precision, int cutStage)
+    : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
+    ptrMySmpcConfig = new SmpcConfiguration(pathToConfigFile);
+    ptrMyForecaster = new Forecaster(ptrMySmpcConfig->getPathToForecaster());
+    ptrMyEngine = new Engine(ptrMySmpcConfig, precision, device, rank, nranks, id128, cutStage);
+    stepSize = ptrMySmpcConfig->getStepSize();
+    vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
+    vecValueFbe.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0); vecTau.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
+    lastControl.assign(ptrMySmpcConfig->getNU(), 0.0);
+    economicKpi = smoothKpi = safeKpi = networkKpi = 0;
+}
+
 // the reference never deletes the objects its path-constructor news (SmpcController.cu:2091-2102); callers that want
 // them gone delete them through the getters, exactly as the reference's tests do (Testing.cu:515-520)
 SmpcController::~SmpcController() {}
@@ -87,16 +99,16 @@ void SmpcController::moveForewardInTime() {
     }
     DwnNetwork *net = ptrMyEngine->getDwnNetwork();
     const uint_t nx = net->getNumTanks(), nu = net->getNumControls(), nd = net->getNumDemands();
-    std::vector<real_t> e(ptrMyEngine->getBufferSize(RN_BUF_E));
-    ptrMyEngine->getBuffer(RN_BUF_E, e.data());
+    std::vector<real_t> e(nx);                                  // only node 0's rows travel (rn_get_range / rn_set_range)
+    ptrMyEngine->getBufferRange(RN_BUF_E, 0, nx, e.data());
     std::vector<real_t> next(ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getCurrentX() + nx);
     if (simulatorDisturbance) {
         for (uint_t i = 0; i < nx; i++) next[i] += e[i];
     } else {
-        std::vector<real_t> xAll(ptrMyEngine->getBufferSize(RN_BUF_X));
-        ptrMyEngine->getBuffer(RN_BUF_X, xAll.data());
-        for (uint_t i = 0; i < nx; i++) xAll[i] += e[i];
-        ptrMyEngine->setBuffer(RN_BUF_X, xAll.data());
+        std::vector<real_t> x0(nx);
+        ptrMyEngine->getBufferRange(RN_BUF_X, 0, nx, x0.data());
+        for (uint_t i = 0; i < nx; i++) x0[i] += e[i];
+        ptrMyEngine->setBufferRange(RN_BUF_X, 0, nx, x0.data());
     }
     const real_t *B = net->getMatB();
     for (uint_t j = 0; j < nu; j++)                             // column sweep, like the gemv it stands for

@@ -11,6 +11,8 @@ class SmpcController {
 public:
     SmpcController(Forecaster *myForecaster, Engine *myEngine, SmpcConfiguration *mySmpcConfig);
     explicit SmpcController(string pathToConfigFile);
+    // Multi-GPU (new): rank `rank` of `nranks`, see Engine's sharded constructor.  Same configuration file on every rank.
+    SmpcController(string pathToConfigFile, int rank, int nranks, const void *ncclUniqueId128, int device = 0, int precision = RN_F64, int cutStage = 0);
     void initialiseSmpcController();                        // SmpcController.cu:476-487
     void controllerSmpc();                                  // :1593-1599
     uint_t controlAction(real_t *u);                        // :1607-1625  (1 = ok)

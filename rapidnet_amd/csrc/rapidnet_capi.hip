@@ -11,11 +11,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/rapidnet.h"
 #include "fbe_kernels.hpp"
+#include "partition.hpp"
 
 #ifndef RN_FIXUP_BLOCKS
 #define RN_FIXUP_BLOCKS 64
@@ -75,6 +79,7 @@ struct NcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string path;   // file the bound image was loaded from (rn_comm_library)
     bool load() {
@@ -88,6 +93,7 @@ struct NcclApi {
         GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
         AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
         CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+        CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
         GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
         Dl_info info;
         if (AllReduce && dladdr((void *)AllReduce, &info) && info.dli_fname) path = info.dli_fname;
@@ -121,6 +127,8 @@ struct CtxBase {
     virtual int get(int, double *, size_t) = 0;
     virtual int set(int, const double *, size_t) = 0;
     virtual int get_operator(int, int, double *, size_t) = 0;
+    virtual int get_range(int, size_t, size_t, double *) = 0;
+    virtual int set_range(int, size_t, size_t, const double *) = 0;
     virtual int profile_enable(int) = 0;
     virtual int profile_reset() = 0;
     virtual int profile_read(double *, long *) = 0;
@@ -131,6 +139,7 @@ struct CtxBase {
     virtual int set_cut_stage(int) = 0;
     virtual int hist_parts(int, int, double *) = 0;
     virtual int counters(long *) = 0;
+    virtual int kernel_info(int *) = 0;
     virtual int sweep_phase(int) = 0;
     virtual int set_operator_mode(int) = 0;
     virtual int set_warm_start(int) = 0;
@@ -154,7 +163,73 @@ struct CtxBase {
     virtual int algorithm_fbe_nama(int, double *, double *, double *) = 0;
     virtual int lbfgs_state(int, int *, int *, double *, double *) = 0;
     virtual int lbfgs_column(int, int, int, double *, size_t) = 0;
+    // multi-GPU through the boundary
+    virtual int set_allreduce(rn_allreduce_fn, void *) = 0;
+    virtual int shard_info(int *) = 0;
+    virtual int shard_global_nodes(int *, size_t) = 0;
+    virtual void set_global_nodes(const int *, int, int) = 0;
+    virtual int device_ordinal() const = 0;
+    virtual int join_local_group(struct LocalGroup *, int) = 0;
 };
+
+// ---- in-process stand-in for the communicator (rn_debug_local_group_*): `n` contexts of one process, one host thread each ----
+struct LocalGroup {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long gen = 0;
+    bool broken = false;
+    std::vector<void *> bufs;
+    std::vector<size_t> counts;
+    std::vector<int> f64;
+    // false: a rank did not arrive in time (or the group is already broken) -- every waiter gives up with an error
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const long g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
+        return !broken;
+    }
+};
+struct LocalMember { LocalGroup *g = nullptr; int rank = 0; void *recv = nullptr; size_t recvBytes = 0; };
+constexpr int LOCAL_GROUP_MAX = 16;
+struct PeerPtrs { const void *p[LOCAL_GROUP_MAX]; };
+template <typename T>
+__global__ void k_sum_ranks(T *out, PeerPtrs peers, int n, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        T s = reinterpret_cast<const T *>(peers.p[0])[i];
+        for (int r = 1; r < n; r++) s += reinterpret_cast<const T *>(peers.p[r])[i];   // rank order: the same bits on every rank
+        out[i] = s;
+    }
+}
+static int local_allreduce(void *user, void *devBuf, size_t count, int isF64, void *streamHandle) {
+    LocalMember *me = static_cast<LocalMember *>(user);
+    LocalGroup *g = me->g;
+    hipStream_t stream = (hipStream_t)streamHandle;
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;          // this rank's payload is complete
+    g->bufs[me->rank] = devBuf; g->counts[me->rank] = count; g->f64[me->rank] = isF64;
+    if (!g->barrier()) return 2;                                        // ... and so is everybody else's
+    for (int r = 0; r < g->n; r++)
+        if (g->counts[r] != count || g->f64[r] != isF64) { std::lock_guard<std::mutex> lk(g->m); g->broken = true; g->cv.notify_all(); return 3; }
+    const size_t bytes = count * (isF64 ? 8 : 4);
+    if (bytes > me->recvBytes) {
+        if (me->recv) (void)hipFree(me->recv);
+        me->recv = nullptr; me->recvBytes = 0;
+        if (hipMalloc(&me->recv, bytes * 2) != hipSuccess) return 4;
+        me->recvBytes = bytes * 2;
+    }
+    PeerPtrs pp{};
+    for (int r = 0; r < g->n; r++) pp.p[r] = g->bufs[r];
+    const int blocks = (int)std::min<size_t>(256, (count + 255) / 256);
+    if (isF64) hipLaunchKernelGGL(k_sum_ranks<double>, dim3(blocks), dim3(256), 0, stream, (double *)me->recv, pp, g->n, count);
+    else hipLaunchKernelGGL(k_sum_ranks<float>, dim3(blocks), dim3(256), 0, stream, (float *)me->recv, pp, g->n, count);
+    if (hipStreamSynchronize(stream) != hipSuccess) return 5;
+    if (!g->barrier()) return 6;                                        // nobody still reads this rank's payload
+    if (hipMemcpyAsync(devBuf, me->recv, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 7;
+    return 0;
+}
 
 // dense host helpers (fp64, column-major) ---------------------------------------------------------------
 static void h_gemm(bool ta, bool tb, int m, int n, int k, const double *A, int lda, const double *B, int ldb, double *C) {
@@ -258,10 +333,29 @@ struct Ctx : CtxBase {
     // multi-GPU
     void *comm = nullptr;
     int rank = 0, nranks = 1, cutStage = -1;
+    rn_allreduce_fn arHook = nullptr;   // rn_debug_set_allreduce: called in place of ncclAllReduce
+    void *arUser = nullptr;
+    LocalMember *localMember = nullptr; // rn_debug_local_group_join (owned)
+    std::vector<int> globalNode;        // sharded through rn_create_sharded: index of every local node in the full tree
+    int fullNodes = 0;
+    bool has_comm() const { return comm != nullptr || arHook != nullptr; }
+    // sum all-reduce, in place, on the solver's stream: the library's RCCL communicator, or the installed stand-in
+    int all_reduce(void *buf, size_t count, bool f64, const char *what) {
+        if (arHook) {
+            const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, (void *)stream);
+            RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + ": the installed all-reduce callback failed (" + std::to_string(rc) + ")");
+            return RN_OK;
+        }
+        RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
+        const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, 0 /*ncclSum*/, comm, stream);
+        RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+        return RN_OK;
+    }
 
     ~Ctx() override {
         if (comm && g_nccl.CommDestroy) g_nccl.CommDestroy(comm);
         (void)hipSetDevice(device);
+        if (localMember) { if (localMember->recv) (void)hipFree(localMember->recv); delete localMember; }
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         for (auto e : freeEvents) (void)hipEventDestroy(e);
@@ -756,12 +850,9 @@ struct Ctx : CtxBase {
             if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
             pendingFin = false;
-            if (phase == 1 || !comm) return RN_OK;     // emulation, or a single-rank "sharded" run
+            if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
-            const int rc = g_nccl.AllReduce(d_cut, d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/,
-                                            0 /*ncclSum*/, comm, stream);
-            RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclAllReduce failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
-            return RN_OK;
+            return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
         };
         // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
         // launch is the slab kernel and stage 0 is neither the whole crown nor the multi-GPU exchange stage
@@ -803,6 +894,7 @@ struct Ctx : CtxBase {
         constexpr int VN = 16 / (int)sizeof(T);
         if (!RN_DUAL_REGEN || !RN_DUAL_STAGE || ny % VN) return;
         const int vpn = ny / VN, cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs], node0 = h_stageCum[cs];
+        if (vpn < 2) return;   // one vector per node: floor(2^32 / 1) + 1 does not fit the 32-bit magic -- the flat kernel runs
         const unsigned long long lim = (1ull << 32) / (unsigned)vpn;          // range in which umulhi(j, magic) == j / vpn
         if ((unsigned long long)K * vpn >= lim || (unsigned long long)node0 * vpn >= lim || (unsigned long long)d.nodes * vpn >= (1ull << 31)) return;
         int forced = 0;
@@ -812,7 +904,7 @@ struct Ctx : CtxBase {
         // vectors that do not fit the 256 MiB Infinity Cache stream from HBM: there 4x as many (smaller) workgroups and the
         // double-buffered variant measured best (wide4096 fp32, 1.3 GB per launch: 279 -> 257 us)
         const bool cacheResident = 5.0 * (double)ntot() * sizeof(T) <= 256.0 * 1024 * 1024;
-        const long long resident = (long long)numCUs * (cacheResident ? 8 : 32);
+        const long long resident = std::min<long long>((long long)numCUs * (cacheResident ? 8 : 32), RN_DUAL_STAGE_MAX_BLOCKS);   // d_partials holds that many
         for (int pass = 0; pass < 2 && dualU == 0; pass++)
             for (int trips : {1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64}) {
                 if (forced > 0 && trips != forced) continue;
@@ -955,12 +1047,10 @@ struct Ctx : CtxBase {
         }
         carryTail = false;
         if (n > 0) {   // the last iteration's distances: one 2-element all-reduce per BATCH
-            const int rc = g_nccl.AllReduce(d_cut + tail, d_cut + tail, 2, sizeof(T) == 8 ? 8 : 7, 0, comm, stream);
-            RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist tail) failed");
+            if (int rc = all_reduce(d_cut + tail, 2, sizeof(T) == 8, "ncclAllReduce(dist tail)")) return rc;
             // the ranks agree on the verdict (sum of the per-rank flags): one more 1-element all-reduce per BATCH
             hipLaunchKernelGGL(k_check_dist<T>, dim3(1), dim3(1), 0, stream, d_cut + tail, d_state, penX / stepSize, penXs / stepSize, d_cut + tail);
-            const int rc2 = g_nccl.AllReduce(d_cut + tail, d_cut + tail, 1, sizeof(T) == 8 ? 8 : 7, 0, comm, stream);
-            RN_CHECK(rc2 == 0, RN_E_COMM, "ncclAllReduce(verdict) failed");
+            if (int rc = all_reduce(d_cut + tail, 1, sizeof(T) == 8, "ncclAllReduce(verdict)")) return rc;
         }
         RN_HIP(hipGetLastError());
         int violated = 0;
@@ -1047,16 +1137,16 @@ struct Ctx : CtxBase {
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
-    int set_exchange_mode(int mode) override { RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic"); optimistic = mode; return RN_OK; }
+    int set_exchange_mode(int mode) override { RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic"); optimistic = mode; optHold = 0; return RN_OK; }
     int apg_iterate(int n, double *primalInfs) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
         RN_HIP(hipSetDevice(device));
         // optimistic batches (prox as a pure projection, verified afterwards); after a replay the next RN_OPT_BACKOFF batches
         // go straight through the exact path (every rank sees the same verdicts, so sharded ranks stay in step)
-        const bool wantOptSharded = comm && cutStage > 0 && optimistic && n > 0;
+        const bool wantOptSharded = has_comm() && cutStage > 0 && optimistic && n > 0;
         // single GPU: worth a checkpoint (3 vector copies) and a read-back per batch once the batch is long enough
-        const bool wantOptLocal = !comm && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN;
+        const bool wantOptLocal = !has_comm() && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN;
         if ((wantOptSharded || wantOptLocal) && optHold > 0 && !inReplay) optHold--;
         else if (wantOptSharded) { optBatches++; return apg_iterate_optimistic(n, primalInfs); }
         else if (wantOptLocal) { optBatches++; return apg_iterate_optimistic_local(n, primalInfs); }
@@ -1072,14 +1162,13 @@ struct Ctx : CtxBase {
             if (int rc = launch_sweep(0, nullptr, last)) return rc;
             DualArgs<T> a = dual_args();
             const hipEvent_t *e2 = prof_begin(2);
-            const bool exactSharded = comm && cutStage > 0;   // its fix-up pass and k_finalize fold eltBlocks partials: flat kernel
+            const bool exactSharded = has_comm() && cutStage > 0;   // its fix-up pass and k_finalize fold eltBlocks partials: flat kernel
             launch_dual_main(a, last, exactSharded);
             prof_end(e2);
             const hipEvent_t *e3 = prof_begin(3);
             if (exactSharded) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
                 hipLaunchKernelGGL(k_reduce_dist, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
-                const int rc = g_nccl.AllReduce(d_dist2, d_dist2, 2, 8 /*ncclFloat64*/, 0 /*ncclSum*/, comm, stream);
-                RN_CHECK(rc == 0, RN_E_COMM, "ncclAllReduce(dist) failed");
+                if (int rc = all_reduce(d_dist2, 2, true, "ncclAllReduce(dist)")) return rc;
                 hipLaunchKernelGGL(k_decide_from, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
@@ -1103,6 +1192,21 @@ struct Ctx : CtxBase {
             RN_HIP(hipStreamSynchronize(stream));
             RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         }
+        return RN_OK;
+    }
+    // which kernels a batch of this context launches (bench.py names them in its JSON line instead of assuming)
+    int kernel_info(int *out) override {
+        RN_CHECK(out, RN_E_ARG, "rn_get_kernel_info: null output");
+        int G = 0, NL = 0;
+        stream_shape(&G, &NL);
+        const bool exactSharded = has_comm() && cutStage > 0 && !optimistic;
+        out[0] = (dualU > 0 && !exactSharded) ? 1 : 0;   // 1: k_dual_stage is the main pass of the fused dual update, 0: the flat k_dual_fused
+        out[1] = (dualU > 0 && !exactSharded) ? dualBlocks : eltBlocks;
+        out[2] = dualU > 0 ? dshape.trips : 0;
+        out[3] = dualU;                                  // 2: double-buffered variant
+        out[4] = G; out[5] = NL;                         // k_stream_gemv: columns per span, 16-byte slots per thread and span
+        out[6] = chainStage;
+        out[7] = v_lv_is_slab() ? 1 : 0;                 // 1: k_gemm_vlv (slab), 0: two k_gemm_shared launches
         return RN_OK;
     }
     int counters(long *out) override {
@@ -1299,6 +1403,43 @@ struct Ctx : CtxBase {
         if (id == RN_BUF_UHAT || id == RN_BUF_E || id == RN_BUF_BETA) { affine_ready = true; aux_dirty = true; }
         return upload(p, host, n);
     }
+    // elements [first, first + n) of a buffer in the reference's node-major layout; dual-shaped buffers: whole nodes only
+    int get_range(int id, size_t first, size_t n, double *host) override {
+        RN_CHECK(host, RN_E_ARG, "rn_get_range: null host pointer");
+        RN_HIP(hipSetDevice(device));
+        T *b; int off, dim; size_t cnt;
+        if (ymap(id, &b, &off, &dim)) {
+            RN_CHECK(first % dim == 0 && n % dim == 0 && first + n <= (size_t)d.nodes * dim, RN_E_ARG, "rn_get_range: dual-shaped buffers are addressed in whole nodes");
+            hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b + (first / dim) * ny, d_tmp, ny, off, dim, (long long)(n / dim), 0);
+            RN_HIP(hipGetLastError());
+            return download(host, d_tmp, n);
+        }
+        T *p = plain(id, &cnt);
+        RN_CHECK(p != nullptr, RN_E_ARG, "rn_get_range: unknown buffer id");
+        RN_CHECK(first + n <= cnt, RN_E_ARG, "rn_get_range: range outside the buffer");
+        return download(host, p + first, n);
+    }
+    int set_range(int id, size_t first, size_t n, const double *host) override {
+        RN_CHECK(host, RN_E_ARG, "rn_set_range: null host pointer");
+        RN_HIP(hipSetDevice(device));
+        T *b; int off, dim; size_t cnt;
+        if (ymap(id, &b, &off, &dim)) {
+            RN_CHECK(id < RN_BUF_XMIN || id > RN_BUF_UMAX, RN_E_ARG, "rn_set_range: the scaled bounds are read-only");
+            RN_CHECK(first % dim == 0 && n % dim == 0 && first + n <= (size_t)d.nodes * dim, RN_E_ARG, "rn_set_range: dual-shaped buffers are addressed in whole nodes");
+            if (int rc = upload(d_tmp, host, n)) return rc;
+            hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b + (first / dim) * ny, d_tmp, ny, off, dim, (long long)(n / dim), 1);
+            RN_HIP(hipGetLastError());
+            RN_HIP(hipStreamSynchronize(stream));
+            if (id == RN_BUF_ACC_XI || id == RN_BUF_ACC_PSI) { if (p_acc_view != p_acc) std::swap(p_acc, p_acc_other); acc_ready = true; }
+            else if (id == RN_BUF_XI || id == RN_BUF_PSI || id == RN_BUF_UPD_XI || id == RN_BUF_UPD_PSI) acc_ready = false;
+            return RN_OK;
+        }
+        T *p = plain(id, &cnt);
+        RN_CHECK(p != nullptr, RN_E_ARG, "rn_set_range: unknown buffer id");
+        RN_CHECK(first + n <= cnt, RN_E_ARG, "rn_set_range: range outside the buffer");
+        if (id == RN_BUF_UHAT || id == RN_BUF_E || id == RN_BUF_BETA) { affine_ready = true; aux_dirty = true; }
+        return upload(p + first, host, n);
+    }
     int get_operator(int op, int node, double *host, size_t n) override {
         RN_CHECK(factored, RN_E_STATE, "rn_get_operator before rn_factor_step");
         RN_CHECK(host && node >= 0 && node < d.nodes, RN_E_ARG, "rn_get_operator: bad node");
@@ -1341,6 +1482,7 @@ struct Ctx : CtxBase {
     int comm_init(int rk, int nr, const void *id) override {
         RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
         rank = rk; nranks = nr;
+        optHold = 0;                       // every rank starts its batches aligned (the back-off counter decides which path a batch takes)
         if (id == nullptr) return RN_OK;   // id == NULL: bookkeeping only (tests emulate the exchange)
         RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
         RN_HIP(hipSetDevice(device));
@@ -1350,6 +1492,31 @@ struct Ctx : CtxBase {
         const int rc = f(&comm, nr, u, rk);
         RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
+    }
+    int set_allreduce(rn_allreduce_fn fn, void *user) override { arHook = fn; arUser = user; optHold = 0; return RN_OK; }
+    int shard_info(int *info) override {
+        RN_CHECK(info, RN_E_ARG, "rn_shard_info: null output");
+        info[0] = rank; info[1] = nranks; info[2] = cutStage;
+        info[3] = cutStage > 0 ? h_stageCum[cutStage] - h_stageCum[cutStage - 1] : 0;
+        int cnt = 0;
+        if (comm && g_nccl.CommCount) { if (g_nccl.CommCount(comm, &cnt) != 0) cnt = -1; }
+        info[4] = cnt; info[5] = d.nodes; info[6] = fullNodes > 0 ? fullNodes : d.nodes;
+        return RN_OK;
+    }
+    int shard_global_nodes(int *out, size_t n) override {
+        RN_CHECK(out && n == (size_t)d.nodes, RN_E_ARG, "rn_shard_global_nodes: one entry per local node expected");
+        for (int i = 0; i < d.nodes; i++) out[i] = globalNode.empty() ? i : globalNode[i];
+        return RN_OK;
+    }
+    void set_global_nodes(const int *g, int n, int full) override { globalNode.assign(g, g + n); fullNodes = full; }
+    int device_ordinal() const override { return device; }
+    int join_local_group(LocalGroup *g, int rk) override {
+        RN_CHECK(g && rk >= 0 && rk < g->n, RN_E_ARG, "rn_debug_local_group_join: bad rank");
+        RN_CHECK(comm == nullptr, RN_E_STATE, "rn_debug_local_group_join: the context already has an RCCL communicator");
+        if (!localMember) localMember = new LocalMember();
+        localMember->g = g; localMember->rank = rk;
+        rank = rk; nranks = g->n;
+        return set_allreduce(local_allreduce, localMember);
     }
     int sweep_phase(int phase) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_debug_sweep_phase before the factor step / affine terms");
@@ -1517,6 +1684,8 @@ int rn_get_prox_distances(rn_ctx *ctx, double *a, double *b) { RN_GUARD(ctx); re
 size_t rn_buffer_size(const rn_ctx *ctx, int id) { return (ctx && ctx->impl) ? ctx->impl->buffer_size(id) : 0; }
 int rn_get(rn_ctx *ctx, int id, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->get(id, h, n); }
 int rn_set(rn_ctx *ctx, int id, const double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->set(id, h, n); }
+int rn_get_range(rn_ctx *ctx, int id, size_t first, size_t n, double *h) { RN_GUARD(ctx); return ctx->impl->get_range(id, first, n, h); }
+int rn_set_range(rn_ctx *ctx, int id, size_t first, size_t n, const double *h) { RN_GUARD(ctx); return ctx->impl->set_range(id, first, n, h); }
 int rn_get_operator(rn_ctx *ctx, int op, int node, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->get_operator(op, node, h, n); }
 int rn_profile_enable(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->profile_enable(on); }
 int rn_profile_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->profile_reset(); }
@@ -1537,6 +1706,7 @@ int rn_comm_library(char *buf, size_t n) {
 }
 int rn_set_cut_stage(rn_ctx *ctx, int stage) { RN_GUARD(ctx); return ctx->impl->set_cut_stage(stage); }
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out) { RN_GUARD(ctx); return ctx->impl->hist_parts(first, n, out); }
+int rn_get_kernel_info(rn_ctx *ctx, int info[8]) { RN_GUARD(ctx); return ctx->impl->kernel_info(info); }
 int rn_get_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->counters(out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
@@ -1560,6 +1730,65 @@ int rn_lbfgs_state(rn_ctx *ctx, int set, int *col, int *mem, double *H, double *
 int rn_lbfgs_column(rn_ctx *ctx, int set, int which, int col, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->lbfgs_column(set, which, col, h, n); }
 int rn_debug_sweep_phase(rn_ctx *ctx, int phase) { RN_GUARD(ctx); return ctx->impl->sweep_phase(phase); }
 int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n) { RN_GUARD(ctx); return ctx->impl->cut_buffer(write, host, n); }
+
+// ---- multi-GPU through the boundary ------------------------------------------------------------------------------------
+int rn_default_cut_stage(const rn_dims *dims, const rn_tree *tree) { return rn::default_cut_stage(dims, tree); }
+int rn_partition_create(const rn_dims *dims, const rn_tree *tree, const double *errD, const double *errP, int rank, int nranks, int cutStage,
+                        rn_partition *out) {
+    return rn::build_partition(dims, tree, errD, errP, rank, nranks, cutStage, out, g_create_error);
+}
+void rn_partition_destroy(rn_partition *p) {
+    if (!p || !p->owner) return;
+    delete static_cast<rn::PartitionData *>(p->owner);
+    std::memset(p, 0, sizeof *p);
+}
+int rn_create_sharded(const rn_dims *dims, const rn_tree *tree, const double *errD, const double *errP, int precision, int device, int rank,
+                      int nranks, int cutStage, const void *id128, rn_ctx **out) {
+    if (!dims || !tree || !out) return RN_E_ARG;
+    *out = nullptr;
+    if (nranks == 1) {   // a plain unsharded context
+        if (rank != 0) { g_create_error = "rn_create_sharded: bad rank"; return RN_E_ARG; }
+        if (int rc = rn_create(dims, tree, precision, device, out)) return rc;
+        if (errD && errP) {
+            const int rc = (*out)->impl->set_tree_errors(errD, errP);
+            if (rc != RN_OK) { g_create_error = (*out)->impl->err; rn_destroy(*out); *out = nullptr; return rc; }
+        }
+        return RN_OK;
+    }
+    rn_partition part;
+    if (int rc = rn::build_partition(dims, tree, errD, errP, rank, nranks, cutStage, &part, g_create_error)) return rc;
+    rn_ctx *ctx = nullptr;
+    int rc = rn_create(&part.dims, &part.tree, precision, device, &ctx);
+    if (rc == RN_OK) {
+        rn::CtxBase *c = ctx->impl;
+        c->set_global_nodes(part.globalNode, part.dims.nodes, dims->nodes);
+        if (part.errorDemandNode && part.errorPriceNode) rc = c->set_tree_errors(part.errorDemandNode, part.errorPriceNode);
+        if (rc == RN_OK) rc = c->comm_init(rank, nranks, id128);
+        if (rc == RN_OK) rc = c->set_cut_stage(part.cutStage);
+        if (rc == RN_OK) {
+            std::vector<double> zeros;
+            const double *E = part.momE;
+            if (!E) { zeros.assign((size_t)part.nCutParents * dims->nd, 0.0); E = zeros.data(); }
+            rc = c->set_cut_moments(E, part.momP, (size_t)part.nCutParents);
+        }
+        if (rc != RN_OK) { g_create_error = c->err; rn_destroy(ctx); ctx = nullptr; }
+    }
+    rn_partition_destroy(&part);
+    *out = ctx;
+    return rc;
+}
+int rn_shard_info(rn_ctx *ctx, int info[7]) { RN_GUARD(ctx); return ctx->impl->shard_info(info); }
+int rn_shard_global_nodes(rn_ctx *ctx, int *g, size_t n) { RN_GUARD(ctx); return ctx->impl->shard_global_nodes(g, n); }
+int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user) { RN_GUARD(ctx); return ctx->impl->set_allreduce(fn, user); }
+int rn_debug_local_group_create(int nranks, void **group) {
+    if (!group || nranks < 1 || nranks > rn::LOCAL_GROUP_MAX) return RN_E_ARG;
+    rn::LocalGroup *g = new rn::LocalGroup();
+    g->n = nranks; g->bufs.assign(nranks, nullptr); g->counts.assign(nranks, 0); g->f64.assign(nranks, 0);
+    *group = g;
+    return RN_OK;
+}
+int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank) { RN_GUARD(ctx); return ctx->impl->join_local_group(static_cast<rn::LocalGroup *>(group), rank); }
+int rn_debug_local_group_destroy(void *group) { if (!group) return RN_E_ARG; delete static_cast<rn::LocalGroup *>(group); return RN_OK; }
 
 }  // extern "C"
 

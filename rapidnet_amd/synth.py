@@ -39,6 +39,11 @@ CONFIGS = {
     # nv + 2 nx = 1200 components per crown node: more than the 1024 threads of a k_up_crown workgroup (and shared-operator
     # products far too large for the LDS slab kernels)
     "widecrown": (20, 400, 420, 30, 20, 4, [2, 2]),
+    # NON-UNIFORM branching: per-node child counts (the reference's solveSumChildren / solveChildNodesUpdate walk the
+    # nChildrenCumul offsets, Utilities.cu:142-201): root 3 -> (2, 4, 1) -> (1, 2, 1, 3, 1, 2, 1) -> 11 chains; subtrees of
+    # unequal size below stage 1 (4, 7 and 2 ... nodes per stage) for the sharded path
+    "ragged": (21, 6, 11, 5, 3, 9, [3, [2, 4, 1], [1, 2, 1, 3, 1, 2, 1]]),
+    "ragged2": (22, 4, 7, 5, 2, 7, [[2], [3, 1], [1, 1, 2, 4], [2, 1, 1, 1, 1, 3, 1, 1]]),
 }
 
 
@@ -50,12 +55,18 @@ STEP_SIZE_CACHE = {"wide4096": 1.5525146548810805e-06}
 def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
     """Stage-contiguous BFS tree that branches in the leading stages, then chains to N.
 
-    branching[k] = children per node of stage k (uniform per stage).  Returns the tree dict in the
-    reference schema.  The only shape the reference's operator aliasing supports (Engine.cu:210-221).
+    branching[k] = children per node of stage k: an int (uniform per stage) or a list with one count per node of the stage
+    (non-uniform trees: the reference supports per-node child counts through nChildren / nChildrenCumul,
+    Utilities.cu:142-201).  Returns the tree dict in the reference schema.  Branching only in the leading stages is the
+    only shape the reference's operator aliasing supports (Engine.cu:210-221).
     """
     per_stage = [1]
+    counts = []          # per stage: child count of every node
     for b in branching:
-        per_stage.append(per_stage[-1] * b)
+        cb = [int(b)] * per_stage[-1] if np.isscalar(b) else [int(v) for v in b]
+        assert len(cb) == per_stage[-1] and min(cb) >= 1, "one child count (>= 1) per node of the stage"
+        counts.append(cb)
+        per_stage.append(int(sum(cb)))
     while len(per_stage) < N:
         per_stage.append(per_stage[-1])
     per_stage = per_stage[:N]
@@ -69,10 +80,12 @@ def make_tree(N, branching, rng, nd, nu, err_scale=0.05, dhat=None, ahat=None):
     n_children = []
     children = []
     for k in range(N - 1):
-        b = branching[k] if k < len(branching) else 1
+        first = cumul[k + 1]
         for j in range(per_stage[k]):
             i = cumul[k] + j
-            first = cumul[k + 1] + j * b
+            b = counts[k][j] if k < len(counts) else 1
+            if j > 0:
+                first += counts[k][j - 1] if k < len(counts) else 1
             w = rng.dirichlet(np.ones(b) * 4.0) if b > 1 else np.ones(1)
             for c in range(b):
                 ancestor[first + c] = i + 1

@@ -5,12 +5,15 @@
 //                 testDualUpdate (src/test/TestSmpcController.cu:114-420) against smpcTest.json, same tolerance rule
 //   fbe / nama  : Testing::testSmpcFbeController / testSmpcNamaController (Testing.cu:536-590) against smpcFbeTest.json /
 //                 smpcNamaTest.json
-// usage: test_host <loaders|engine|controller|fbe|nama|closedloop|nullspace|warmstart> <directory with the fixture JSON files>
+//   sharded     : (new capability, no reference counterpart) N rank-local controllers of ONE problem, created through the sharded
+//                 constructors (rank, nranks) of SmpcController / Engine, one host thread each, on one GPU, against the unsharded controller
+// usage: test_host <loaders|engine|controller|fbe|nama|closedloop|nullspace|warmstart|sharded> <directory with the fixture JSON files> [ranks]
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 #include "../../rapidnet_amd/csrc/host/SmpcController.hpp"
 
@@ -461,6 +464,97 @@ static void testWarmStart(const string &dir) {
     }
 }
 
+// Multi-GPU through the C++ class surface.  `world` controllers are constructed exactly as a launcher would construct them,
+// one per rank -- SmpcController(path, rank, world, ncclUniqueId) -- from the SAME configuration file; the library partitions
+// the tree, replicates the crown and all-reduces the cut parents' children sums once per APG iteration.  A one-GPU box cannot
+// host several RCCL ranks, so the ranks are threads of this process, the unique id is NULL and the in-process stand-in
+// (rn_debug_local_group_join) is called wherever ncclAllReduce would be.  Every rank runs the reference's own entry points
+// (initialiseSmpcController, controlAction) -- a device-resident batch of maxIterations iterations with checkpoint, dist^2
+// tail and verdict vote -- and the reassembled x, u, duals must equal the unsharded controller's at 1e-9.
+class ShardedController : public SmpcController {
+public:
+    ShardedController(const string &cfg, int rank, int world) : SmpcController(cfg, rank, world, nullptr) {}
+    explicit ShardedController(const string &cfg) : SmpcController(cfg) {}
+    using SmpcController::getVector;
+};
+static void testSharded(const string &dir, int world) {
+    const string cfgPath = dir + "/controllerConfig.json";
+    ShardedController ref(cfgPath);
+    ref.getForecaster()->predictDemand(0); ref.getForecaster()->predictPrices(0);
+    ref.initialiseSmpcController();
+    const uint_t nx = ref.getSmpcConfiguration()->getNX(), nu = ref.getSmpcConfiguration()->getNU();
+    const uint_t nodes = ref.getScenarioTree()->getNumNodes();
+    std::vector<real_t> uRef(nu);
+    CHECK(ref.controlAction(uRef.data()) == 1);
+    void *group = nullptr;
+    CHECK(rn_debug_local_group_create(world, &group) == RN_OK);
+    std::vector<ShardedController *> rk(world, nullptr);
+    for (int r = 0; r < world; r++) {
+        rk[r] = new ShardedController(cfgPath, r, world);
+        CHECK(rn_debug_local_group_join(rk[r]->getEngine()->getContext(), group, r) == RN_OK);
+        CHECK(rk[r]->getEngine()->getRank() == r && rk[r]->getEngine()->getNumRanks() == world);
+    }
+    std::vector<std::vector<real_t>> u0(world, std::vector<real_t>(nu));
+    std::vector<int> ok(world, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++)
+        th.emplace_back([&, r]() {
+            try {
+                rk[r]->getForecaster()->predictDemand(0); rk[r]->getForecaster()->predictPrices(0);
+                rk[r]->initialiseSmpcController();
+                ok[r] = (int)rk[r]->controlAction(u0[r].data());
+            } catch (const std::exception &e) { std::cerr << "rank " << r << ": " << e.what() << "\n"; ok[r] = 0; }
+        });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < world; r++) CHECK(ok[r] == 1);
+    // the root's control is replicated: identical bits on every rank, and the unsharded controller's value
+    real_t un = 0;
+    for (uint_t i = 0; i < nu; i++) un = std::max(un, std::fabs(uRef[i]));
+    for (int r = 0; r < world; r++) {
+        CHECK(std::memcmp(u0[r].data(), u0[0].data(), nu * sizeof(real_t)) == 0);
+        CHECK(closeAbs(u0[r].data(), uRef.data(), nu, 1e-9 * un, "u0"));
+    }
+    // reassemble the node-major iterates through the ranks' global node maps
+    struct Buf { int id; uint_t dim; const char *name; };
+    const Buf bufs[] = {{RN_BUF_X, nx, "X"}, {RN_BUF_U, nu, "U"}, {RN_BUF_UPD_XI, 2 * nx, "updateXi"}, {RN_BUF_UPD_PSI, nu, "updatePsi"},
+                        {RN_BUF_DUAL_XI, 2 * nx, "dualXi"}};
+    std::vector<int> owners(nodes, 0);
+    for (const Buf &b : bufs) {
+        std::vector<real_t> full((size_t)nodes * b.dim, 0.0), want((size_t)nodes * b.dim);
+        ref.getVector(b.id, want.data());
+        for (int r = 0; r < world; r++) {
+            const std::vector<int> g = rk[r]->getEngine()->getGlobalNodes();
+            std::vector<real_t> loc((size_t)g.size() * b.dim);
+            CHECK(rk[r]->getEngine()->getBufferSize(b.id) == loc.size());
+            rk[r]->getVector(b.id, loc.data());
+            for (size_t l = 0; l < g.size(); l++) {
+                std::memcpy(&full[(size_t)g[l] * b.dim], &loc[l * b.dim], b.dim * sizeof(real_t));
+                if (b.id == RN_BUF_X) owners[g[l]]++;
+            }
+        }
+        real_t scale = 0;
+        for (real_t v : want) scale = std::max(scale, std::fabs(v));
+        CHECK(closeAbs(full.data(), want.data(), full.size(), 1e-9 * scale, b.name));
+    }
+    int info[7];
+    CHECK(rn_shard_info(rk[0]->getEngine()->getContext(), info) == RN_OK);
+    const uint_t crown = ref.getScenarioTree()->getNodesPerStageCumul()[info[2]];
+    for (uint_t i = 0; i < nodes; i++) CHECK(owners[i] == (i < crown ? world : 1));   // crown replicated, every other node owned once
+    long cnt[4];
+    CHECK(rn_get_counters(rk[0]->getEngine()->getContext(), cnt) == RN_OK);
+    std::cout << "sharded: " << world << " ranks, cut stage " << info[2] << ", " << info[3] << " cut parents, crown " << crown << " nodes, batches optimistic/exact/replayed "
+              << cnt[0] << "/" << cnt[1] << "/" << cnt[2] << "\n";
+    for (int r = 0; r < world; r++) {
+        long c2[4];
+        CHECK(rn_get_counters(rk[r]->getEngine()->getContext(), c2) == RN_OK);
+        CHECK(c2[0] == cnt[0] && c2[1] == cnt[1] && c2[2] == cnt[2] && c2[3] == cnt[3]);   // every rank took the same path through the batches
+        delete rk[r]->getEngine();
+        delete rk[r];
+    }
+    CHECK(rn_debug_local_group_destroy(group) == RN_OK);
+    delete ref.getEngine();
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) { std::cerr << "usage: test_host <loaders|engine|controller|closedloop> <fixture dir>\n"; return 2; }
     const string mode = argv[1], dir = argv[2];
@@ -481,6 +575,7 @@ int main(int argc, char **argv) {
         else if (mode == "closedloop_dump") dumpClosedLoop(dir, argc > 3 ? (uint_t)std::atoi(argv[3]) : 3, argc > 4 && std::atoi(argv[4]) != 0);
         else if (mode == "nullspace") testNullSpace(dir);
         else if (mode == "warmstart") testWarmStart(dir);
+        else if (mode == "sharded") testSharded(dir, argc > 3 ? std::atoi(argv[3]) : 2);
         else { std::cerr << "unknown mode\n"; return 2; }
     } catch (const std::exception &e) {
         std::cerr << "EXCEPTION: " << e.what() << "\n";

@@ -18,7 +18,7 @@ from rapidnet_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "synthetic")
 CASES = {"toy": (1, 10, 50), "tiny": (1, 10, 50), "small": (1, 10, 50), "odd": (1, 10, 50), "medium": (1, 10, 50),
-         "barcelona31": (1, 10)}
+         "barcelona31": (1, 10), "ragged": (1, 10, 50)}
 
 
 def main():

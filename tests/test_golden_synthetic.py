@@ -9,7 +9,7 @@ from conftest import GOLDEN
 from oracle.oracle import Oracle
 from rapidnet_amd import synth
 
-CASES = [("toy", 50), ("tiny", 10), ("small", 50), ("odd", 10), ("medium", 10), ("barcelona31", 1)]
+CASES = [("toy", 50), ("tiny", 10), ("small", 50), ("odd", 10), ("medium", 10), ("barcelona31", 1), ("ragged", 50)]
 
 
 def _load(name):
@@ -37,7 +37,7 @@ def test_oracle_reproduces_golden(name, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,k", [("toy", 50), ("tiny", 50), ("small", 50), ("odd", 50), ("medium", 50), ("barcelona31", 10)])
+@pytest.mark.parametrize("name,k", [("toy", 50), ("tiny", 50), ("small", 50), ("odd", 50), ("medium", 50), ("barcelona31", 10), ("ragged", 50)])
 def test_hip_path_matches_golden(name, k):
     from rapidnet_amd import capi
 

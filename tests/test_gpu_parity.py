@@ -212,7 +212,10 @@ def test_counters_on_a_clean_run():
 # trees that branch in the leading stages and then chain: for late branching, for N = 1 and for trees that branch up to
 # the last stage it indexes before the start of devMatOmega.  The HIP path derives every block from the node's own
 # probability, so for those shapes the oracle is run with the aliasing off (same formulas, per-node blocks).
-EDGE_SHAPES = [("deep", True), ("fan", True), ("tall", True), ("widecrown", True), ("late", False), ("horizon1", False), ("horizon2", False)]
+# "ragged" / "ragged2": NON-UNIFORM branching, per-node child counts (solveSumChildren / solveChildNodesUpdate walk nChildrenCumul,
+# Utilities.cu:142-201); ragged2 also branches again after a single-child stage, so its oracle runs with the aliasing off.
+EDGE_SHAPES = [("deep", True), ("fan", True), ("tall", True), ("widecrown", True), ("late", False), ("horizon1", False), ("horizon2", False),
+               ("ragged", True), ("ragged2", False)]
 
 
 @pytest.mark.parametrize("structured", [False, True])

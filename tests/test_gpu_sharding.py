@@ -26,11 +26,14 @@ def lambdas(n):
 
 
 @pytest.mark.parametrize("name,cut,world,structured", [("medium", 2, 2, False), ("medium", 1, 2, False), ("small", 3, 2, False),
-                                                        ("medium", 2, 3, False), ("medium", 2, 2, True)])
+                                                        ("medium", 2, 3, False), ("medium", 2, 2, True),
+                                                        # non-uniform trees: subtrees of unequal size per rank (cut at 1 and 2), cut at the chain stage
+                                                        ("ragged", 1, 2, False), ("ragged", 1, 3, False), ("ragged", 2, 2, False), ("ragged", 2, 3, True),
+                                                        ("ragged", 3, 4, False), ("ragged2", 1, 2, False), ("ragged2", 3, 3, False)])
 def test_shards_on_one_gpu_match_full_tree(name, cut, world, structured):
     p = synth.make_problem(name)
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    o = Oracle(p["network"], p["tree"], p["config"])
+    o = Oracle(p["network"], p["tree"], p["config"], alias_operators=(name != "ragged2"))
     o.initialise(dh, ah)
     iters = 8
     o.apg(iters)

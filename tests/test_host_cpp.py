@@ -9,11 +9,11 @@ from conftest import REF_FIXTURE, ROOT
 from rapidnet_amd import build
 
 
-def _run(mode, directory=REF_FIXTURE):
+def _run(mode, directory=REF_FIXTURE, *extra):
     exe = build.TEST_HOST
     if not os.path.exists(exe):
         build.build_host()
-    r = subprocess.run([exe, mode, directory], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, mode, directory] + [str(e) for e in extra], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "test_host %s failed (rc %d):\n%s\n%s" % (mode, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     return r.stdout
 
@@ -62,3 +62,19 @@ def test_null_space_basis_invariance_cpp():
 @pytest.mark.gpu
 def test_warm_start_cpp():
     _run("warmstart")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,kw,replayed", [("medium", 2, {}, 0), ("medium", 8, {}, 0), ("ragged", 3, {}, 0),
+                                                    ("medium", 4, {"penalty_x": 20.0, "penalty_xs": 5.0}, 1)])
+def test_sharded_controllers_cpp(tmp_path, name, world, kw, replayed):
+    """Multi-GPU through the C++ class surface: `world` SmpcController(path, rank, world, id) objects of
+    one process, one thread each, against the unsharded controller -- see testSharded in tests/cpp/test_host.cpp.  With the
+    small penalties the soft-constraint thresholds trip, so the optimistic batch is replayed through the exact
+    two-collective path on all ranks together."""
+    from rapidnet_amd import synth
+
+    synth.write_problem(synth.make_problem(name, max_iterations=40, **kw), str(tmp_path))
+    out = _run("sharded", str(tmp_path), world)
+    assert "sharded: %d ranks" % world in out and "all checks passed" in out
+    assert ("optimistic/exact/replayed 1/0/%d" % replayed) in out, out

@@ -38,7 +38,11 @@ def _worker(rank, world, port, name, cut, iters, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p = synth.make_problem(name)
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    ltree, gids = partition.local_tree(p["tree"], rank, world, cut)
+    # the rank-local tree comes from the partitioner behind the C-ABI (rn_partition_create), the one the product uses
+    from rapidnet_amd import capi
+
+    part = capi.partition_tree(p["tree"], rank, world, cut)
+    ltree, gids = part["tree"], part["globalNode"]
     o = Oracle(p["network"], ltree, p["config"], alias_operators=False)
     o.initialise(dh, ah)
     # beta of the cut parents needs ALL their children (calculateZeta); the product gets that from static tree
@@ -66,7 +70,12 @@ def _worker(rank, world, port, name, cut, iters, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,cut", [("medium", 2), ("medium", 1)])
+# ragged: non-uniform tree, subtrees of unequal size per rank.  Only cuts whose rank-local trees are trees the REFERENCE can
+# represent run here, because every rank runs the reference-faithful oracle on its local tree: the reference decides
+# "branching stage" by node counts (SmpcController.cu:661, nk > pn) and indexes nChildren by node id, both of which break
+# when a cut parent has no local child (ragged cut at 2 or 3).  The HIP path reads explicit child ranges; those cuts are
+# covered on the GPU against the oracle of the FULL tree (tests/test_gpu_sharding.py, tests/test_gpu_sharded_batched.py).
+@pytest.mark.parametrize("name,cut", [("medium", 2), ("medium", 1), ("ragged", 1)])
 def test_two_rank_sharded_solve_matches_single_process(tmp_path, name, cut):
     import torch.multiprocessing as mp
 
