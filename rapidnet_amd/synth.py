@@ -43,6 +43,8 @@ CONFIGS = {
     # nChildrenCumul offsets, Utilities.cu:142-201): root 3 -> (2, 4, 1) -> (1, 2, 1, 3, 1, 2, 1) -> 11 chains; subtrees of
     # unequal size below stage 1 (4, 7 and 2 ... nodes per stage) for the sharded path
     "ragged": (21, 6, 11, 5, 3, 9, [3, [2, 4, 1], [1, 2, 1, 3, 1, 2, 1]]),
+    # non-uniform two-stage crown (root 3 -> 2, 4, 1 chains) with an even ny: the chain-local sweep's crown kernel on unequal children counts
+    "small2": (23, 5, 10, 6, 3, 8, [3, [2, 4, 1]]),
     "ragged2": (22, 4, 7, 5, 2, 7, [[2], [3, 1], [1, 1, 2, 4], [2, 1, 1, 1, 1, 3, 1, 1]]),
 }
 

@@ -254,6 +254,48 @@ def test_fp32_path():
     compare_all(s, o, FP32_TOL, "fp32")
 
 
+@pytest.mark.parametrize("name", ["medium", "barcelona31"])
+def test_fp32_long_run_within_the_fp32_oracles_own_sensitivity(name, capsys):
+    """The reference's native precision (Configuration.h:31) for 100 iterations.  In fp32 the roundings themselves are 6e-8 per
+    operation, and two fp32 implementations that sum in different orders drift apart at the rate the iteration amplifies
+    such differences; the yardstick is therefore the fp32 oracle's OWN sensitivity: the oracle run twice, beta scaled by
+    1 + 2^-22 (a quarter of an fp32 ulp per entry on average).  Stated tolerance: HIP-vs-oracle error <= max(FP32_TOL, 20 x
+    that sensitivity) at every checkpoint, x / u / both dual parts, relative to the vector's largest entry."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    cks = (10, 25, 50, 100)
+    names = ("x", "u", "updXi", "updPsi")
+    bids = {"x": capi.BUF_X, "u": capi.BUF_U, "updXi": capi.BUF_UPD_XI, "updPsi": capi.BUF_UPD_PSI}
+
+    def oracle_run(perturb):
+        o = Oracle(p["network"], p["tree"], p["config"], precision="f32")
+        o.initialise(dh, ah)
+        if perturb:
+            o.set("beta", o.get("beta") * (1.0 + perturb))
+        o.apg_reset()
+        th, out, done = [1.0, 1.0], [], 0
+        for total in cks:
+            th = o.apg_continue(total - done, th); done = total
+            out.append({k: o.get(k).copy() for k in names})
+        return out
+
+    base, pert = oracle_run(0.0), oracle_run(2.0 ** -22)
+    s = capi.Solver(p["network"], p["tree"], p["config"], precision="f32")
+    s.initialiseSmpcController(dh, ah)
+    s.apgReset()
+    done, rows = 0, []
+    for k, total in enumerate(cks):
+        s.apgIterate(total - done, history=False); done = total
+        e_gpu = max(relmax(s.get(bids[n]), base[k][n]) for n in names)
+        e_self = max(relmax(pert[k][n], base[k][n]) for n in names)
+        rows.append((total, e_gpu, e_self))
+        assert e_gpu < max(FP32_TOL, 20 * e_self), (name, total, e_gpu, e_self)
+    with capsys.disabled():
+        print("\n[%s, fp32] iterations: HIP-vs-oracle max rel. error | fp32-oracle-vs-perturbed-fp32-oracle (beta * (1 + 2^-22))" % name)
+        for r in rows:
+            print("    %4d: %.2e | %.2e" % r)
+
+
 def test_barcelona31_full_size():
     """BASELINE.json configs[1] at full size (714 nodes): 5 iterations against the oracle."""
     p, o, s = make_pair("barcelona31")
