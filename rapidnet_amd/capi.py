@@ -81,19 +81,31 @@ def load():
         # image).  Under a launcher only local rank 0 compiles, before any GPU call; the others wait for the finished file
         # (build_hip renames it into place).  There is no CPU fallback.
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        failed = path + ".buildfailed"      # left by local rank 0 when its build fails, so that the waiting ranks abort at once
         try:
             if local_rank == 0:
-                _build.build_hip()
+                if os.path.exists(failed):
+                    os.remove(failed)
+                try:
+                    _build.build_hip()
+                except Exception as e:
+                    with open(failed, "w") as f:
+                        f.write(str(e))
+                    raise
             else:
                 import time
 
                 for _ in range(1800):
                     if not _build.hip_is_stale():
                         break
+                    if os.path.exists(failed):
+                        raise RuntimeError("local rank 0 could not build librapidnet_hip.so: %s" % open(failed).read().strip())
                     time.sleep(0.5)
+                else:   # every rank must run the same binary: a library that is still stale after 15 minutes is an error, not a fallback
+                    raise RuntimeError("librapidnet_hip.so is still older than its sources after waiting 900 s for local rank 0 to rebuild it")
         except Exception as e:
-            if not os.path.exists(path):
-                raise RuntimeError("librapidnet_hip.so is missing (%s) and could not be built (%s); run __graft_entry__.build() -- "
+            if local_rank != 0 or not os.path.exists(path):
+                raise RuntimeError("librapidnet_hip.so (%s) is missing or stale and could not be built (%s); run __graft_entry__.build() -- "
                                    "there is no CPU fallback" % (path, e))
             import warnings
 

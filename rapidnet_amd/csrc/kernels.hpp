@@ -453,63 +453,104 @@ constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the r
 struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; double thrX, thrS; };
 template <typename T>
 __device__ void finalize_optimistic_body(const FinArgs &fin);
+// one component t (< nv + nx) of chain s: walks the chain from the leaf to its top, writes s_i / kappa_i of every node and
+// rho, kappa, q of the top; the top's three values are also returned (t < nv: rho in r0; otherwise kappa in r0, q in r1)
 template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
-    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
-    const int s = blockIdx.x;                      // chain = position within the stage
+__device__ __forceinline__ void up_chain_walk(const SweepArgs<T> &a, int s, int t, T &r0, T &r1) {
     const int nv = a.nv, nx = a.nx;
     const int top = a.chainStage;
     const T *__restrict__ beta = a.beta;
     const T *__restrict__ my = a.my;
     const T *__restrict__ qa = a.qa;
     const int *__restrict__ cum = a.tr.stageCum;
-    for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
-        if (t < nv) {
-            T rho = 0;
-            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-                T b[CHAIN_PF], m[CHAIN_PF];
+    if (t < nv) {
+        T rho = 0;
+        for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+            T b[CHAIN_PF], m[CHAIN_PF];
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k - j >= top ? k - j : top;
-                    const size_t node = (size_t)cum[kk] + s;
-                    b[j] = beta[node * nv + t];
-                    m[j] = my[node * 2 * nv + nv + t];
-                }
+            for (int j = 0; j < CHAIN_PF; j++) {
+                const int kk = k - j >= top ? k - j : top;
+                const size_t node = (size_t)cum[kk] + s;
+                b[j] = beta[node * nv + t];
+                m[j] = my[node * 2 * nv + nv + t];
+            }
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
-                        const T sv = b[j] + rho;                   // s_i
-                        rho = sv + m[j];
-                        a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
-                    }
+            for (int j = 0; j < CHAIN_PF; j++) {
+                if (k - j >= top) {
+                    const size_t node = (size_t)cum[k - j] + s;
+                    const T sv = b[j] + rho;                   // s_i
+                    rho = sv + m[j];
+                    a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
                 }
             }
-            a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
-        } else {
-            const int j0 = t - nv;
-            T kap = 0, q = 0;
-            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-                T av[CHAIN_PF];
-#pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k - j >= top ? k - j : top;
-                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
-                }
-#pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
-                        kap += q;                                  // kappa_i = kappa_c + q_c
-                        a.sk[node * (nv + nx) + nv + j0] = kap;
-                        q += av[j];                                // q_i = a_i + q_c
-                    }
-                }
-            }
-            const size_t ntop = (size_t)cum[top] + s;
-            a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
-            a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
         }
+        a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
+        r0 = rho; r1 = 0;
+    } else {
+        const int j0 = t - nv;
+        T kap = 0, q = 0;
+        for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+            T av[CHAIN_PF];
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) {
+                const int kk = k - j >= top ? k - j : top;
+                av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+            }
+#pragma unroll
+            for (int j = 0; j < CHAIN_PF; j++) {
+                if (k - j >= top) {
+                    const size_t node = (size_t)cum[k - j] + s;
+                    kap += q;                                  // kappa_i = kappa_c + q_c
+                    a.sk[node * (nv + nx) + nv + j0] = kap;
+                    q += av[j];                                // q_i = a_i + q_c
+                }
+            }
+        }
+        const size_t ntop = (size_t)cum[top] + s;
+        a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
+        a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
+        r0 = kap; r1 = q;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
+    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
+    const int s = blockIdx.x;                      // chain = position within the stage
+    for (int t = threadIdx.x; t < a.nv + a.nx; t += CHAIN_THREADS) {
+        T r0, r1;
+        up_chain_walk<T>(a, s, t, r0, r1);
+    }
+}
+// Sharded runs whose cut lies right above the chains, few local chains per cut parent (an 8-way split of the 17 x 29 tree: 3 or 4):
+// ONE workgroup per CUT PARENT walks all its local chains side by side and sums their tops through LDS -- the all-reduce
+// payload [parent][rho | kappa | q] comes out of this launch and k_cut_partial_sums (a dependent launch of ~5 us that reads
+// 62 x 223 values back) disappears.  Children are added in ascending order, as k_cut_partial_sums does.  One more workgroup
+// (blockIdx = nParents, when fin.partials != nullptr) does the bookkeeping of the previous iteration's dual update.
+constexpr int UPCUT_THREADS = 1024;
+template <typename T>
+__global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, T *out, int nParents, int lanesPer, FinArgs fin) {
+    if ((int)blockIdx.x >= nParents) {
+        if (threadIdx.x >= ELT_THREADS) return;      // the bookkeeping is written for ELT_THREADS threads
+        finalize_optimistic_body<T>(fin);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sh = reinterpret_cast<T *>(smem_raw);         // [slots][nv + 2 nx]
+    const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
+    const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    const int slot = threadIdx.x / lanesPer, t = threadIdx.x % lanesPer;
+    if (slot < nc && t < nv + nx) {
+        T r0, r1;
+        up_chain_walk<T>(a, c0 + slot - a.tr.stageCum[a.chainStage], t, r0, r1);
+        if (t < nv) sh[slot * w + t] = r0;
+        else { sh[slot * w + t] = r0; sh[slot * w + nx + t] = r1; }
+    }
+    __syncthreads();
+    for (int tt = threadIdx.x; tt < w; tt += UPCUT_THREADS) {
+        T sum = 0;
+        for (int c = 0; c < nc; c++) sum += sh[c * w + tt];
+        out[(size_t)blockIdx.x * w + tt] = sum;
     }
 }
 // Crown region (stages < c*), one node: children are summed explicitly (loads batched CHAIN_PF at a time).

@@ -801,6 +801,18 @@ struct Ctx : CtxBase {
     int fold_crown_mode(int cs, bool sharded) const {
         return (RN_FOLD_CROWN_DOWN && cs >= 1 && cs <= CROWN_MAX_DEPTH) ? (sharded ? (h_stageCum[cs] <= 256 ? 2 : 0) : 1) : 0;
     }
+    // lanes per chain of k_up_chain_cut, or 0 when the merged launch does not apply: the cut lies right above the chains and every
+    // cut parent's local chains fit side by side in one workgroup
+    int up_cut_lanes() const {
+        if (cutStage <= 0 || cutStage < chainStage) return 0;
+        const int lanesPer = (d.nv + d.nx + 63) / 64 * 64;
+        if (lanesPer > UPCUT_THREADS) return 0;
+        int most = 0;
+        for (int i = h_stageCum[cutStage - 1]; i < h_stageCum[cutStage]; i++) most = std::max(most, h_childCount[i]);
+        if (most * lanesPer > UPCUT_THREADS) return 0;
+        if (const char *e = std::getenv("RAPIDNET_UP_CUT")) { if (std::atoi(e) == 0) return 0; }   // tuning runs: the two-launch form
+        return lanesPer;
+    }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
     // assuming the summed payload is in d_cut (tests emulate the all-reduce between two contexts on one GPU)
     // hessianInput != nullptr: SmpcController::computeHessianOracalGlobalFbe (SmpcController.cu:884-1055) -- the same
@@ -834,7 +846,17 @@ struct Ctx : CtxBase {
         }
         e1 = prof_begin(1);
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
-        if (phase != 2) {
+        // sharded, cut right above the chains, few local chains per cut parent: one launch does the chain walks AND the cut
+        // parents' local children sums (k_up_chain_cut)
+        const bool mergedCut = phase != 2 && a.cutSums && up_cut_lanes() > 0;
+        if (mergedCut) {
+            const int k = cutStage - 1, lanesPer = up_cut_lanes();
+            FinArgs fin{};
+            if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
+            const size_t ldsCut = (size_t)(UPCUT_THREADS / lanesPer) * (nv + 2 * nx) * sizeof(T);
+            hipLaunchKernelGGL(k_up_chain_cut<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+            pendingFin = false;
+        } else if (phase != 2) {
             // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
             FinArgs fin{};
             const bool ride = pendingFin && !a.cutSums;
@@ -846,10 +868,12 @@ struct Ctx : CtxBase {
         auto all_reduce_cut = [&](int k) -> int {   // multi-GPU: all-reduce the children sums of the cut parents
             if (phase == 2) return RN_OK;              // payload already summed by the caller
             // optimistic exchange: the bookkeeping of the previous iteration's dual update rides in this launch
-            FinArgs fin{};
-            if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
-            hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
-            pendingFin = false;
+            if (!mergedCut) {   // (k_up_chain_cut has already left the payload in d_cut)
+                FinArgs fin{};
+                if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
+                hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
+                pendingFin = false;
+            }
             if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
             return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
