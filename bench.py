@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=7, help="further timed regions of --steps steps after the contract's one (median / min / max in the JSON line)")
     ap.add_argument("--other-configs", default="barcelona31,wide4096", help="comma list of further BASELINE.json configs timed in the same run on 1 GPU "
                     "(their own roofline objects, in the `configs` array of the JSON line); '' = none")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure the HBM traffic of the dominant kernels in this run (two short rocprofv3 --pmc child runs, "
+                    "started before this process touches the GPU); roofline.traffic then falls back to profiles/traffic.json if its kernel fingerprint matches")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the child run the counters are collected on
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
     return ap.parse_args()
@@ -60,6 +63,83 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def _pmc_medians(directory, counter):
+    """kernel name -> median counter value per dispatch, from a rocprofv3 --pmc run's counter_collection.csv files."""
+    import csv
+    import glob
+    import statistics
+
+    out = {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") != counter:
+                continue
+            d = out.setdefault(row["Kernel_Name"], {})
+            d[row.get("Dispatch_Id")] = d.get(row.get("Dispatch_Id"), 0.0) + float(row["Counter_Value"])
+    return {k: (statistics.median(v.values()), len(v)) for k, v in out.items()}
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of k_stream_gemv and of the fused dual update FROM THE PMC COUNTERS OF THIS RUN, collected as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: FETCH_SIZE and WRITE_SIZE in separate passes
+    (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-probe ...`, the program itself behind `--`),
+    FETCH_SIZE doubled (gfx950 tallies a 128-byte request of a wide streaming read at 64 B), WRITE_SIZE as reported, KiB x 1024,
+    medians over the dispatches.  The two child runs are started BEFORE this process makes any GPU call.  Returns
+    (traffic dict, source dict); on any failure the dict is empty and the source says why."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    src = {"measured_in_this_run": False, "how": None}
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        src["why_not"] = "rocprofv3 not found"
+        return {}, src
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        src["why_not"] = "this run is itself being profiled"
+        return {}, src
+    tmp = tempfile.mkdtemp(prefix="rn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    probe = ["python3", os.path.abspath(__file__), "--traffic-probe", "--workload", args.workload, "--steps", "12", "--warmup", "3"]
+    if args.precision:
+        probe += ["--precision", args.precision]
+    med = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + probe,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+            if r.returncode != 0:
+                src["why_not"] = "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, r.stderr[-300:])
+                return {}, src
+            med[counter] = _pmc_medians(out, counter)
+    except Exception as e:   # noqa: BLE001 -- a missing profiler must not fail the benchmark
+        src["why_not"] = "%s: %s" % (type(e).__name__, e)
+        return {}, src
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def total(prefix):
+        for k, (f, n) in med["FETCH_SIZE"].items():
+            if k.startswith(prefix) and n >= 4:
+                w = med["WRITE_SIZE"].get(k, (0.0, 0))[0]
+                return 1024.0 * (2.0 * f + w), n
+        return None, 0
+
+    t = {}
+    for key, prefix in (("k_stream_gemv_bytes_per_launch", "void rn::k_stream_gemv<"), ("k_dual_stage_bytes_per_launch", "void rn::k_dual_stage<"),
+                        ("k_dual_fused_bytes_per_launch", "void rn::k_dual_fused<")):
+        v, n = total(prefix)
+        if v is not None:
+            t[key] = v
+            t[key.replace("bytes_per_launch", "dispatches")] = n
+    src.update({"measured_in_this_run": True,
+                "how": "two child runs of this bench.py under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, 15 iterations of the same "
+                       "workload each), median per dispatch, bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM) prescribes for "
+                       "16-byte-per-lane streaming reads on gfx950"})
+    return t, src
 
 
 def spawn_ranks(args):
@@ -169,6 +249,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))     # one child process per rank, started before anything touches the GPU
+    if args.traffic_probe:              # the run the PMC counters are collected on: iterations only
+        args.no_cpu_baseline, args.dense_only, args.profile_steps, args.repeats, args.other_configs, args.no_traffic = True, True, 0, 0, "", True
+    measured_traffic, measured_source = ({}, None)
+    if world == 1 and args.gpus == 1 and not args.no_traffic and not args.structured and not args.force_shard and args.emulate_world == 0:
+        measured_traffic, measured_source = measure_traffic(args)   # child processes; nothing in this process has touched the GPU yet
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
@@ -375,12 +460,15 @@ def main():
             dual = {"kernel": dual_kernel, "workgroups": kinfo["dual_blocks"], "vectors_per_thread": kinfo["dual_trips"], "achieved": dual_bytes / dual_s / 1e9 if dual_s > 0 else 0.0, "algorithmic_bytes_per_launch": dual_bytes,
                     "avg_launch_us": 1e6 * dual_s}
             dual["frac"] = dual["achieved"] / 8000.0
-            # HBM traffic from the PMC counters is NOT measured by this run (rocprofv3 --pmc needs passes of its own): it is
-            # carried over from profiles/traffic.json, and only if that file was collected on this workload with exactly
-            # the kernel sources this run executes; traffic_source says where the number comes from
+            dual["traffic"] = None   # filled below once the source of the counters is known
+            # HBM traffic from the PMC counters: measured by this run's own rocprofv3 child passes (measure_traffic, started before
+            # the GPU was touched); if that was not possible, carried over from profiles/traffic.json, and only if that file was
+            # collected on this workload with exactly the kernel sources this run executes; traffic_source says which
             traffic, traffic_source = {}, {"measured_in_this_run": False, "file": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and workload == "barcelona493" and precision == "f64" and not sharded:
+            if measured_traffic and workload == args.workload and not sharded:
+                traffic, traffic_source = measured_traffic, measured_source
+            elif os.path.exists(tpath) and workload == "barcelona493" and precision == "f64" and not sharded:
                 try:
                     from rapidnet_amd import build as _b
 
@@ -391,11 +479,14 @@ def main():
                                       "how": t.get("source")}
                     if t.get("kernels_sha256") == cur:
                         traffic = t
+                    if measured_source and measured_source.get("why_not"):
+                        traffic_source["not_measured_in_this_run_because"] = measured_source["why_not"]
                 except Exception:
                     traffic = {}
+            dual["traffic"] = traffic.get("k_dual_stage_bytes_per_launch" if kinfo["dual_stage"] else "k_dual_fused_bytes_per_launch")
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
                 roofline = {"kernel": dual_kernel, "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",
-                            "frac": dual["frac"], "traffic": traffic.get("k_dual_stage_bytes_per_launch") if kinfo["dual_stage"] else None, "traffic_source": traffic_source,
+                            "frac": dual["frac"], "traffic": traffic.get("k_dual_stage_bytes_per_launch" if kinfo["dual_stage"] else "k_dual_fused_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": dual_bytes, "avg_launch_us": dual["avg_launch_us"], "launches_per_step": 1}
                 if copy_ceiling:
                     roofline.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})

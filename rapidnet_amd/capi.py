@@ -104,7 +104,7 @@ def load():
                 else:   # every rank must run the same binary: a library that is still stale after 15 minutes is an error, not a fallback
                     raise RuntimeError("librapidnet_hip.so is still older than its sources after waiting 900 s for local rank 0 to rebuild it")
         except Exception as e:
-            if local_rank != 0 or not os.path.exists(path):
+            if local_rank != 0 or not os.path.exists(path) or int(os.environ.get("WORLD_SIZE", "1")) > 1:   # ranks never run different binaries
                 raise RuntimeError("librapidnet_hip.so (%s) is missing or stale and could not be built (%s); run __graft_entry__.build() -- "
                                    "there is no CPU fallback" % (path, e))
             import warnings

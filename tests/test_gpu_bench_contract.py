@@ -34,11 +34,26 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert 0.5 < r["frac"] < 1.0, "the streaming kernel should sit between 50 % and 100 % of the HBM peak"
     # achieved = algorithmic bytes per launch / average launch time; the PMC traffic may not be far above the algorithmic bytes
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
-    # traffic is carried over from profiles/traffic.json (a rocprofv3 --pmc pass of its own), never measured by this run:
-    # the line must say so, and must drop the number when the kernels have changed since it was collected
+    # traffic comes from the PMC counters of THIS run (two rocprofv3 --pmc child passes started before the GPU is touched);
+    # only if the profiler cannot run it is carried over from profiles/traffic.json, and dropped when the kernels have
+    # changed since that file was collected.  Either way the line says which.
     ts = r["traffic_source"]
-    assert ts["measured_in_this_run"] is False
-    assert (r["traffic"] is not None) == bool(ts.get("matches_current_kernels"))
+    if ts["measured_in_this_run"]:
+        assert r["traffic"] is not None and "FETCH_SIZE" in ts["how"]
+        # the streaming kernel reads every byte once: PMC traffic within 3 % of the algorithmic bytes
+        assert 0.97 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.03, r["traffic"] / r["algorithmic_bytes_per_launch"]
+        du = r["dual_update"]
+        assert du["traffic"] is not None and 0.9 < du["traffic"] / du["algorithmic_bytes_per_launch"] < 1.1
+    else:
+        assert (r["traffic"] is not None) == bool(ts.get("matches_current_kernels"))
+    # the timed region is repeated: spread over the regions, and the other single-GPU configs of BASELINE.json ride along
+    sp = d["timing_spread"]
+    assert sp["regions"] >= 5 and sp["ms_per_step_min"] <= sp["ms_per_step_median"] <= sp["ms_per_step_max"]
+    names = [c.get("workload") for c in d.get("configs", [])]
+    assert names == ["barcelona31", "wide4096"], names
+    for c in d["configs"]:
+        assert "error" not in c, c
+        assert c["roofline"]["kernel"] == "k_stream_gemv" and 0.3 < c["roofline"]["frac"] < 1.0 and c["cpu_baseline"]["value"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
