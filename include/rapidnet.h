@@ -172,7 +172,9 @@ int rn_get_prox_distances(rn_ctx *ctx, double *distanceXcst, double *distanceXs)
 /* ---- SmpcController: the global-FBE and NAMA loops --------------------- */
 /* Engine's algorithm flags (Engine.cu:151-163, "algorithmName" of the controller configuration).  Selecting FBE or
  * NAMA allocates their vectors and the L-BFGS buffers (SmpcController::allocateGlobalFbeAlgorithm /
- * allocateNamaAlgorithm / allocateLbfgsBuffer, SmpcController.cu:234-330) and runs rn_fbe_reset.  Single GPU. */
+ * allocateNamaAlgorithm / allocateLbfgsBuffer, SmpcController.cu:234-330) and runs rn_fbe_reset.  On a sharded context
+ * (rn_create_sharded) every dot product, value term and prox distance of the loops is all-reduced over the ranks (the
+ * replicated crown counted once), so all ranks take the same skip / line-search decisions. */
 enum { RN_ALG_APG = 0, RN_ALG_GLOBAL_FBE = 1, RN_ALG_NAMA = 2 };
 int rn_set_algorithm(rn_ctx *ctx, int algorithm, int lbfgsBufferSize);
 /* SmpcController::initialiseAlgorithm (FBE / NAMA part, :436-449) + initaliseLbfgBuffer (:453-468) */
@@ -321,12 +323,12 @@ int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
 /* Test facility: an in-process stand-in for the communicator, so that the device-resident sharded path (checkpoint, dist^2
  * tail, verdict vote, replay) can run with several ranks on a box where RCCL cannot (one GPU: "Duplicate GPU detected").
  * rn_debug_set_allreduce installs a callback that is called wherever the library would call ncclAllReduce(sum, in place):
- * devBuf / count / isF64 describe the payload, stream is the context's hipStream_t; it must return 0 after the reduced
+ * devBuf / count / isF64 / op describe the payload and the reduction, stream is the context's hipStream_t; it must return 0 after the reduced
  * values are (or are stream-ordered to be) in devBuf.  rn_debug_local_group_* is such a callback inside the library for
  * `nranks` contexts of ONE process, each driven by its own host thread: stream sync, barrier, every rank sums the payloads
  * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s fails the others with
  * RN_E_COMM instead of hanging them. */
-typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, void *stream);
+typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, int op /* 0 = sum, 2 = max (ncclRedOp_t) */, void *stream);
 int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
 int rn_debug_local_group_create(int nranks, void **group);
 int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);

@@ -58,7 +58,7 @@ class RnPartition(C.Structure):
                 ("nCutParents", C.c_int), ("momE", C.POINTER(C.c_double)), ("momP", C.POINTER(C.c_double)), ("owner", C.c_void_p)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 _LIB = None
 
@@ -520,8 +520,8 @@ class Solver:
         return out
 
     def debugSetAllreduce(self, fn):
-        """fn(dev_ptr, count, is_f64, stream) -> 0; called in place of ncclAllReduce (test facility)."""
-        self._ar_cb = ALLREDUCE_FN(lambda user, buf, count, f64, stream: int(fn(buf, count, f64, stream))) if fn is not None else C.cast(None, ALLREDUCE_FN)
+        """fn(dev_ptr, count, is_f64, op, stream) -> 0; called in place of ncclAllReduce (test facility)."""
+        self._ar_cb = ALLREDUCE_FN(lambda user, buf, count, f64, op, stream: int(fn(buf, count, f64, op, stream))) if fn is not None else C.cast(None, ALLREDUCE_FN)
         self._check(self.lib.rn_debug_set_allreduce(self.h, self._ar_cb, None))
 
     def joinLocalGroup(self, group, rank):

@@ -22,6 +22,7 @@ struct DotArgs {
     int cnt;
     long long n;
     double *partials;   // [blocks][DOT_MAX]
+    long long first;    // sharded contexts: elements below `first` (the replicated crown) do not count on ranks other than 0
 };
 // up to DOT_MAX dot products <a_j, b_j> over the same index range in ONE pass; fp64 accumulation, fixed reduction
 // order (a last-block-folds variant that saves the k_dots_finish launch was measured: the per-block agent-scope release
@@ -61,13 +62,13 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
             if (j < g.cnt) {
                 const VT av = reinterpret_cast<const VT *>(g.a[j])[i], bv = reinterpret_cast<const VT *>(g.b[j])[i];
 #pragma unroll
-                for (int e = 0; e < VN; e++) acc[j] += (double)av[e] * (double)bv[e];
+                for (int e = 0; e < VN; e++) acc[j] += (i * VN + e >= g.first) ? (double)av[e] * (double)bv[e] : 0.0;
             }
     }
     for (long long i = nvec * VN + (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < g.n; i += (long long)gridDim.x * ELT_THREADS) {
 #pragma unroll
         for (int j = 0; j < DOT_MAX; j++)
-            if (j < g.cnt) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
+            if (j < g.cnt && i >= g.first) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
     }
     dots_block_reduce(acc, g.partials);
 }
@@ -117,7 +118,7 @@ __global__ void k_lbfgs_diffs(T *S, T *Y, const T *y, const T *yPrev, const T *g
 //   next != nullptr: partials[block][0] = <next, dir_new> over the block's elements (k_dots order), for k_dots_finish
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *src, const T *vec, const double *scal, double rho, double *alphaArr, int c,
-                                                             int mode, T scale, const T *next, double *partials, long long n) {
+                                                             int mode, T scale, const T *next, double *partials, long long n, long long first) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     T coef = 0;
@@ -147,14 +148,14 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
         if (next) {
             const VT nv = reinterpret_cast<const VT *>(next)[i];
 #pragma unroll
-            for (int e = 0; e < VN; e++) acc[0] += (double)nv[e] * (double)d[e];
+            for (int e = 0; e < VN; e++) acc[0] += (i * VN + e >= first) ? (double)nv[e] * (double)d[e] : 0.0;
         }
     }
     for (long long i = nvec * VN + gid; i < n; i += stride) {
         T d;
         if (mode < 0) d = scale * src[i]; else { d = dir[i]; d += coef * vec[i]; }
         dir[i] = d;
-        if (next) acc[0] += (double)next[i] * (double)d;
+        if (next && i >= first) acc[0] += (double)next[i] * (double)d;
     }
     // the coefficient of the first loop is kept for the second one; written after every block has read scal / alphaArr is not
     // required: nobody reads alphaArr[c] in mode 0, and the next launch is stream-ordered behind this one
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
 // S = y - yPrev, Y = g - gPrev (SmpcController::updateLbfgsBuffer, :1119-1130) and the four dot products its skip rule and
 // H0 scaling need (<g,g>, <S,Y>, <Y,Y>, <S,S>, :1131-1156) in the same pass
 template <typename T>
-__global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, const T *y, const T *yPrev, const T *g, const T *gPrev, double *partials, long long n) {
+__global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, const T *y, const T *yPrev, const T *g, const T *gPrev, double *partials, long long n,
+                                                                  long long first) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     double acc[DOT_MAX];
@@ -180,18 +182,20 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, co
         for (int e = 0; e < VN; e++) { sv[e] = yv[e] - ypv[e]; dv[e] = gv[e] - gpv[e]; }
         reinterpret_cast<VT *>(S)[i] = sv;
         reinterpret_cast<VT *>(Y)[i] = dv;
+        if (i * VN + VN - 1 < first) continue;    // replicated crown elements: counted on rank 0 only (first = 0 there)
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (double)gv[e] * (double)gv[e];
+        for (int e = 0; e < VN; e++) acc[0] += (i * VN + e >= first) ? (double)gv[e] * (double)gv[e] : 0.0;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (double)sv[e] * (double)dv[e];
+        for (int e = 0; e < VN; e++) acc[1] += (i * VN + e >= first) ? (double)sv[e] * (double)dv[e] : 0.0;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[2] += (double)dv[e] * (double)dv[e];
+        for (int e = 0; e < VN; e++) acc[2] += (i * VN + e >= first) ? (double)dv[e] * (double)dv[e] : 0.0;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[3] += (double)sv[e] * (double)sv[e];
+        for (int e = 0; e < VN; e++) acc[3] += (i * VN + e >= first) ? (double)sv[e] * (double)sv[e] : 0.0;
     }
     for (long long i = nvec * VN + gid; i < n; i += stride) {
         const T sv = y[i] - yPrev[i], dv = g[i] - gPrev[i];
         S[i] = sv; Y[i] = dv;
+        if (i < first) continue;
         acc[0] += (double)g[i] * (double)g[i]; acc[1] += (double)sv * (double)dv; acc[2] += (double)dv * (double)dv; acc[3] += (double)sv * (double)sv;
     }
     dots_block_reduce(acc, partials);
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg
             z[e] = t < lo[e] ? lo[e] : (t > hi[e] ? hi[e] : t);
             r[e] = hx[e] - z[e];
             gn[e] = -r[e];
-            const double diff = (double)(t - z[e]);
+            const double diff = (a.countCrown || i * VN + e >= a.crownElems) ? (double)(t - z[e]) : 0.0;   // sharded: the replicated crown counts on rank 0 only
             if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
             if (++c == ny) c = 0;
         }
@@ -233,9 +237,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg
         reinterpret_cast<VT *>(a.res)[i] = r;
         if (gneg) reinterpret_cast<VT *>(gneg)[i] = gn;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (double)w[e] * (double)r[e];
+        for (int e = 0; e < VN; e++) acc[0] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)w[e] * (double)r[e] : 0.0;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (double)r[e] * (double)r[e];
+        for (int e = 0; e < VN; e++) acc[1] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)r[e] * (double)r[e] : 0.0;
         c0 += cstep; if (c0 >= ny) c0 -= ny;
     }
     for (long long i = nvec * VN + gid; i < a.n; i += stride) {
@@ -245,6 +249,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg
         const T r = a.hx[i] - z;
         a.z[i] = z; a.res[i] = r;
         if (gneg) gneg[i] = -r;
+        if (!a.countCrown && i < a.crownElems) continue;
         const double diff = (double)(t - z);
         if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
         acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r;
@@ -285,11 +290,14 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_soft_res(DualArgs<T> a, T 
 #pragma unroll
         for (int e = 0; e < VN; e++) r[e] = one(i * VN + e);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (double)a.w[i * VN + e] * (double)r[e];
+        for (int e = 0; e < VN; e++) acc[0] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)a.w[i * VN + e] * (double)r[e] : 0.0;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (double)r[e] * (double)r[e];
+        for (int e = 0; e < VN; e++) acc[1] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)r[e] * (double)r[e] : 0.0;
     }
-    for (long long i = nvec * VN + gid; i < a.n; i += stride) { const T r = one(i); acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r; }
+    for (long long i = nvec * VN + gid; i < a.n; i += stride) {
+        const T r = one(i);
+        if (a.countCrown || i >= a.crownElems) { acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r; }
+    }
     dots_block_reduce(acc, dotPartials);
 }
 
@@ -341,7 +349,7 @@ constexpr int VALUE_RPW = VALUE_TILE / (VALUE_THREADS / 64);   // node rows per 
 constexpr int VALUE_TC = 2;                                      // 64-wide column chunks requested together
 template <typename T>
 __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const T *prevU, const int *parent, const T *prob, const T *W,
-                                                              const T *alpha, int nu, int nodes, double *partials) {
+                                                              const T *alpha, int nu, int nodes, double *partials, int firstNode) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char fbe_smem[];
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const
 #pragma unroll
             for (int r = 0; r < VALUE_RPW; r++) {
                 const int n = wave * VALUE_RPW + r;
-                nodeOf[r] = n < cnt ? n0 + n : -1;
+                nodeOf[r] = (n < cnt && n0 + n >= firstNode) ? n0 + n : -1;   // sharded: the replicated crown counts on rank 0 only
                 const int nc = n < cnt ? n0 + n : n0;
                 par[r] = parent[nc]; pb[r] = prob[nc];
             }

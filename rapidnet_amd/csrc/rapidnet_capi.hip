@@ -197,14 +197,17 @@ struct LocalMember { LocalGroup *g = nullptr; int rank = 0; void *recv = nullptr
 constexpr int LOCAL_GROUP_MAX = 16;
 struct PeerPtrs { const void *p[LOCAL_GROUP_MAX]; };
 template <typename T>
-__global__ void k_sum_ranks(T *out, PeerPtrs peers, int n, size_t count) {
+__global__ void k_sum_ranks(T *out, PeerPtrs peers, int n, size_t count, int op) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         T s = reinterpret_cast<const T *>(peers.p[0])[i];
-        for (int r = 1; r < n; r++) s += reinterpret_cast<const T *>(peers.p[r])[i];   // rank order: the same bits on every rank
+        for (int r = 1; r < n; r++) {                                    // rank order: the same bits on every rank
+            const T v = reinterpret_cast<const T *>(peers.p[r])[i];
+            s = op == 2 ? (v > s ? v : s) : s + v;
+        }
         out[i] = s;
     }
 }
-static int local_allreduce(void *user, void *devBuf, size_t count, int isF64, void *streamHandle) {
+static int local_allreduce(void *user, void *devBuf, size_t count, int isF64, int op, void *streamHandle) {
     LocalMember *me = static_cast<LocalMember *>(user);
     LocalGroup *g = me->g;
     hipStream_t stream = (hipStream_t)streamHandle;
@@ -223,8 +226,8 @@ static int local_allreduce(void *user, void *devBuf, size_t count, int isF64, vo
     PeerPtrs pp{};
     for (int r = 0; r < g->n; r++) pp.p[r] = g->bufs[r];
     const int blocks = (int)std::min<size_t>(256, (count + 255) / 256);
-    if (isF64) hipLaunchKernelGGL(k_sum_ranks<double>, dim3(blocks), dim3(256), 0, stream, (double *)me->recv, pp, g->n, count);
-    else hipLaunchKernelGGL(k_sum_ranks<float>, dim3(blocks), dim3(256), 0, stream, (float *)me->recv, pp, g->n, count);
+    if (isF64) hipLaunchKernelGGL(k_sum_ranks<double>, dim3(blocks), dim3(256), 0, stream, (double *)me->recv, pp, g->n, count, op);
+    else hipLaunchKernelGGL(k_sum_ranks<float>, dim3(blocks), dim3(256), 0, stream, (float *)me->recv, pp, g->n, count, op);
     if (hipStreamSynchronize(stream) != hipSuccess) return 5;
     if (!g->barrier()) return 6;                                        // nobody still reads this rank's payload
     if (hipMemcpyAsync(devBuf, me->recv, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 7;
@@ -340,14 +343,14 @@ struct Ctx : CtxBase {
     int fullNodes = 0;
     bool has_comm() const { return comm != nullptr || arHook != nullptr; }
     // sum all-reduce, in place, on the solver's stream: the library's RCCL communicator, or the installed stand-in
-    int all_reduce(void *buf, size_t count, bool f64, const char *what) {
+    int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */) {
         if (arHook) {
-            const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, (void *)stream);
+            const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, op, (void *)stream);
             RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + ": the installed all-reduce callback failed (" + std::to_string(rc) + ")");
             return RN_OK;
         }
         RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
-        const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, 0 /*ncclSum*/, comm, stream);
+        const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
         RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
     }
@@ -1313,6 +1316,17 @@ struct Ctx : CtxBase {
             if (p.absXi > aX || (p.absXi == aX && p.idxXi < iX)) { aX = p.absXi; vX = p.valXi; iX = p.idxXi; }
             if (p.absPsi > aP || (p.absPsi == aP && p.idxPsi < iP)) { aP = p.absPsi; vP = p.valPsi; iP = p.idxPsi; }
         }
+        if (cutStage > 0 && has_comm() && d_scal) {
+            // sharded quasi-Newton loops: the tree-global arg-max from the ranks' local ones.  A max all-reduce of (v, -v) per
+            // part gives the largest magnitude and its sign (equal magnitudes of opposite sign on two ranks: the positive one)
+            double h[4] = {vX, -vX, vP, -vP};
+            RN_HIP(hipMemcpyAsync(d_scal + 32, h, sizeof h, hipMemcpyHostToDevice, stream));
+            if (int rc = all_reduce(d_scal + 32, 4, true, "ncclAllReduce(primal infeasibility)", 2 /* ncclMax */)) return rc;
+            RN_HIP(hipMemcpyAsync(h, d_scal + 32, sizeof h, hipMemcpyDeviceToHost, stream));
+            RN_HIP(hipStreamSynchronize(stream));
+            vX = h[0] >= h[1] ? h[0] : -h[1];
+            vP = h[2] >= h[3] ? h[2] : -h[3];
+        }
         *value = vX > vP ? vX : vP;
         return RN_OK;
     }
@@ -1654,7 +1668,6 @@ struct Ctx : CtxBase {
     }
     int set_cut_stage(int c) override {
         RN_CHECK(c == -1 || (c >= 1 && c < d.N), RN_E_ARG, "rn_set_cut_stage: stage out of range");
-        RN_CHECK(c == -1 || algorithm == RN_ALG_APG, RN_E_STATE, "rn_set_cut_stage: the FBE / NAMA loops are single-GPU");
         cutStage = c; moments_set = false;
         return RN_OK;
     }
