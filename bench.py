@@ -397,6 +397,13 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
+        # clock ramp (untimed, before the contract's W warm-up steps): a GPU that has idled through the host-side set-up (or the
+        # CPU baseline of the previous config) needs tens of milliseconds of work to reach its clocks -- the first timed region of a
+        # 0.1 ms-per-step config otherwise measures the ramp (seen: 0.28 ms per step in region 1, 0.098 in regions 2-5)
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.08:
+            iterate(10)
+            s.synchronize()
         iterate(warmup)
         barrier()
         t0 = time.perf_counter()

@@ -453,72 +453,65 @@ constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the r
 struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; double thrX, thrS; };
 template <typename T>
 __device__ void finalize_optimistic_body(const FinArgs &fin);
-// one component t (< nv + nx) of chain s: walks the chain from the leaf to its top, writes s_i / kappa_i of every node and
-// rho, kappa, q of the top; the top's three values are also returned (t < nv: rho in r0; otherwise kappa in r0, q in r1)
+// (the walk is spelled out twice, here and in k_up_chain_cut: shared through a device function it measured 8 us slower on the
+//  493-scenario tree -- 20.1 instead of 11.8 us)
 template <typename T>
-__device__ __forceinline__ void up_chain_walk(const SweepArgs<T> &a, int s, int t, T &r0, T &r1) {
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
+    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
+    const int s = blockIdx.x;                      // chain = position within the stage
     const int nv = a.nv, nx = a.nx;
     const int top = a.chainStage;
     const T *__restrict__ beta = a.beta;
     const T *__restrict__ my = a.my;
     const T *__restrict__ qa = a.qa;
     const int *__restrict__ cum = a.tr.stageCum;
-    if (t < nv) {
-        T rho = 0;
-        for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-            T b[CHAIN_PF], m[CHAIN_PF];
+    for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
+        if (t < nv) {
+            T rho = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T b[CHAIN_PF], m[CHAIN_PF];
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                const int kk = k - j >= top ? k - j : top;
-                const size_t node = (size_t)cum[kk] + s;
-                b[j] = beta[node * nv + t];
-                m[j] = my[node * 2 * nv + nv + t];
-            }
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    const size_t node = (size_t)cum[kk] + s;
+                    b[j] = beta[node * nv + t];
+                    m[j] = my[node * 2 * nv + nv + t];
+                }
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                if (k - j >= top) {
-                    const size_t node = (size_t)cum[k - j] + s;
-                    const T sv = b[j] + rho;                   // s_i
-                    rho = sv + m[j];
-                    a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        const T sv = b[j] + rho;                   // s_i
+                        rho = sv + m[j];
+                        a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
+                    }
                 }
             }
-        }
-        a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
-        r0 = rho; r1 = 0;
-    } else {
-        const int j0 = t - nv;
-        T kap = 0, q = 0;
-        for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-            T av[CHAIN_PF];
+            a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T av[CHAIN_PF];
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                const int kk = k - j >= top ? k - j : top;
-                av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
-            }
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+                }
 #pragma unroll
-            for (int j = 0; j < CHAIN_PF; j++) {
-                if (k - j >= top) {
-                    const size_t node = (size_t)cum[k - j] + s;
-                    kap += q;                                  // kappa_i = kappa_c + q_c
-                    a.sk[node * (nv + nx) + nv + j0] = kap;
-                    q += av[j];                                // q_i = a_i + q_c
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        kap += q;                                  // kappa_i = kappa_c + q_c
+                        a.sk[node * (nv + nx) + nv + j0] = kap;
+                        q += av[j];                                // q_i = a_i + q_c
+                    }
                 }
             }
+            const size_t ntop = (size_t)cum[top] + s;
+            a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
+            a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
         }
-        const size_t ntop = (size_t)cum[top] + s;
-        a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
-        a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
-        r0 = kap; r1 = q;
-    }
-}
-template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
-    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
-    const int s = blockIdx.x;                      // chain = position within the stage
-    for (int t = threadIdx.x; t < a.nv + a.nx; t += CHAIN_THREADS) {
-        T r0, r1;
-        up_chain_walk<T>(a, s, t, r0, r1);
     }
 }
 // Sharded runs whose cut lies right above the chains, few local chains per cut parent (an 8-way split of the 17 x 29 tree: 3 or 4):
@@ -539,12 +532,65 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
-    const int slot = threadIdx.x / lanesPer, t = threadIdx.x % lanesPer;
+    // lanesPer is a whole number of waves: the chain a wave works on is wave-uniform, and telling the compiler so keeps the node
+    // indices and the stage-table loads on the scalar unit, as in k_up_chain
+    const int slot = __builtin_amdgcn_readfirstlane((int)threadIdx.x / lanesPer), t = (int)threadIdx.x - slot * lanesPer;
     if (slot < nc && t < nv + nx) {
-        T r0, r1;
-        up_chain_walk<T>(a, c0 + slot - a.tr.stageCum[a.chainStage], t, r0, r1);
-        if (t < nv) sh[slot * w + t] = r0;
-        else { sh[slot * w + t] = r0; sh[slot * w + nx + t] = r1; }
+        const int s = c0 + slot - a.tr.stageCum[a.chainStage];
+        const int top = a.chainStage;
+        const T *__restrict__ beta = a.beta;
+        const T *__restrict__ my = a.my;
+        const T *__restrict__ qa = a.qa;
+        const int *__restrict__ cum = a.tr.stageCum;
+        if (t < nv) {
+            T rho = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T b[CHAIN_PF], m[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    const size_t node = (size_t)cum[kk] + s;
+                    b[j] = beta[node * nv + t];
+                    m[j] = my[node * 2 * nv + nv + t];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        const T sv = b[j] + rho;                   // s_i
+                        rho = sv + m[j];
+                        a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
+                    }
+                }
+            }
+            a.rkq[((size_t)cum[top] + s) * w + t] = rho;
+            sh[slot * w + t] = rho;
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
+                T av[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k - j >= top) {
+                        const size_t node = (size_t)cum[k - j] + s;
+                        kap += q;                                  // kappa_i = kappa_c + q_c
+                        a.sk[node * (nv + nx) + nv + j0] = kap;
+                        q += av[j];                                // q_i = a_i + q_c
+                    }
+                }
+            }
+            const size_t ntop = (size_t)cum[top] + s;
+            a.rkq[ntop * w + nv + j0] = kap;
+            a.rkq[ntop * w + nv + nx + j0] = q;
+            sh[slot * w + nv + j0] = kap;
+            sh[slot * w + nv + nx + j0] = q;
+        }
     }
     __syncthreads();
     for (int tt = threadIdx.x; tt < w; tt += UPCUT_THREADS) {
