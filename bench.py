@@ -400,10 +400,15 @@ def main():
         # clock ramp (untimed, before the contract's W warm-up steps): a GPU that has idled through the host-side set-up (or the
         # CPU baseline of the previous config) needs tens of milliseconds of work to reach its clocks -- the first timed region of a
         # 0.1 ms-per-step config otherwise measures the ramp (seen: 0.28 ms per step in region 1, 0.098 in regions 2-5)
-        t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < 0.08:
-            iterate(10)
+        if sharded:   # every rank must issue the same number of collectives: a fixed count, never a time-based loop
+            for _ in range(8):
+                iterate(10)
             s.synchronize()
+        else:
+            t_ramp = time.perf_counter()
+            while time.perf_counter() - t_ramp < 0.08:
+                iterate(10)
+                s.synchronize()
         iterate(warmup)
         barrier()
         t0 = time.perf_counter()
