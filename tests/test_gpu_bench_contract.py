@@ -60,3 +60,37 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "iterations/s" and c["value"] > 0
     assert c["scaled_by_nodes"] is False and "10864 nodes" in c["sample"]     # timed on the bench workload itself
     assert d["value"] > 10 * c["value"]                  # north_star: >= 10x the host-CPU baseline at 1 GPU
+
+
+def _devices():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+def test_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (a child `torch.distributed.run`, before the
+    parent touches the GPU).  On a box with fewer GPUs than ranks the run must die INSIDE RCCL -- which refuses two ranks on one
+    device -- with a non-zero exit code and no JSON line; with --allow-oversubscribe it rehearses the whole launcher path (two
+    processes, gloo rendezvous, rn_create_sharded on both, agreed fallback exchange, max-over-ranks timing) and labels the
+    line as a fallback.  With two or more GPUs the plain form simply has to produce a sharded result."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "0", "--repeats", "1"]
+    if _devices() >= 2:
+        p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
+        assert d["n_gpus"] == 2 and d["rccl"]["ranks_seen_by_rccl"] == 2 and "FALLBACK" not in d["config"]["parallelism"]
+        return
+    p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")], "no result line for a run that could not create its communicator"
+    err = p.stderr.decode()
+    assert "ncclCommInitRank failed" in err and "RCCL refused the communicator" in err, err[-2000:]
+    p = subprocess.run(base + ["--allow-oversubscribe"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "FALLBACK" in d["config"]["parallelism"] and d["rccl"]["ranks"] == 2 and d["rccl"]["ranks_seen_by_rccl"] == 0
+    assert d["local_nodes"] in (5452, 5430)        # half of the 493 chains + the 18 replicated crown nodes
