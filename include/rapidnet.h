@@ -326,8 +326,8 @@ int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
  * devBuf / count / isF64 / op describe the payload and the reduction, stream is the context's hipStream_t; it must return 0 after the reduced
  * values are (or are stream-ordered to be) in devBuf.  rn_debug_local_group_* is such a callback inside the library for
  * `nranks` contexts of ONE process, each driven by its own host thread: stream sync, barrier, every rank sums the payloads
- * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s fails the others with
- * RN_E_COMM instead of hanging them. */
+ * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s
+ * ($RAPIDNET_GROUP_TIMEOUT_S when the group is created) fails the others with RN_E_COMM instead of hanging them. */
 typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, int op /* 0 = sum, 2 = max (ncclRedOp_t) */, void *stream);
 int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
 int rn_debug_local_group_create(int nranks, void **group);

@@ -180,6 +180,7 @@ struct LocalGroup {
     int arrived = 0;
     long gen = 0;
     bool broken = false;
+    int timeoutSeconds = 120;   // $RAPIDNET_GROUP_TIMEOUT_S at creation (tests of the failure path use a short one)
     std::vector<void *> bufs;
     std::vector<size_t> counts;
     std::vector<int> f64;
@@ -189,7 +190,7 @@ struct LocalGroup {
         if (broken) return false;
         const long g = gen;
         if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
-        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
+        if (!cv.wait_for(lk, std::chrono::seconds(timeoutSeconds), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
         return !broken;
     }
 };
@@ -1821,6 +1822,7 @@ int rn_debug_local_group_create(int nranks, void **group) {
     if (!group || nranks < 1 || nranks > rn::LOCAL_GROUP_MAX) return RN_E_ARG;
     rn::LocalGroup *g = new rn::LocalGroup();
     g->n = nranks; g->bufs.assign(nranks, nullptr); g->counts.assign(nranks, 0); g->f64.assign(nranks, 0);
+    if (const char *e = std::getenv("RAPIDNET_GROUP_TIMEOUT_S")) { const int t = std::atoi(e); if (t > 0) g->timeoutSeconds = t; }
     *group = g;
     return RN_OK;
 }

@@ -144,6 +144,56 @@ def test_barcelona493_batched_over_8_ranks():
 
 
 def test_a_missing_rank_fails_the_others_instead_of_hanging_them(monkeypatch):
-    """A rank that never issues its collective must not leave its peers waiting for ever (bounded by the group's timeout;
-    here one rank of two simply does not iterate and the other's call returns RN_E_COMM)."""
-    pytest.skip("covered by the 120 s timeout of the group barrier; not exercised in the suite to keep it short")
+    """A rank that never issues its collective must not leave its peers waiting for ever: the group's barrier gives up after
+    its timeout (120 s by default, 2 s here) and the waiting rank's call returns RN_E_COMM."""
+    import time
+
+    monkeypatch.setenv("RAPIDNET_GROUP_TIMEOUT_S", "2")
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    rk = Ranks(p, 2)
+    try:
+        for s in rk.shards:
+            s.initialiseSmpcController(dh, ah)
+            s.apgReset()
+        t0 = time.time()
+        with pytest.raises(capi.RapidNetError, match="all-reduce callback failed"):
+            rk.shards[0].apgIterate(20, history=False)          # rank 1 never arrives
+        assert time.time() - t0 < 30
+    finally:
+        rk.close()
+
+
+@pytest.mark.parametrize("world,cut", [(2, 0), (4, 0), (2, 2)])
+def test_wide_network_fp32_sharded(world, cut):
+    """BASELINE.json configs[4] is the wide network in fp32 ON 8 GPUs: the same network and precision on a 16-scenario tree
+    with a three-stage crown (7 crown nodes replicated; 512 lanes per chain in k_up_chain_cut, tile-kernel products,
+    stage-by-stage crown), sharded over 2 and 4 ranks below stage 3 (and below stage 2: subtrees of two chains), through
+    the device-resident path, against the fp32 oracle of the whole tree and the unsharded HIP solve."""
+    synth.CONFIGS.setdefault("wide16", (4, 200, 360, 280, 54, 24, [4, 2, 2]))
+    p = synth.make_problem("wide16")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"], precision="f32")
+    o.initialise(dh, ah)
+    o.apg(20)
+    full = capi.Solver(p["network"], p["tree"], p["config"], precision="f32")
+    full.initialiseSmpcController(dh, ah)
+    full.algorithmApg(20)
+    rk = Ranks(p, world, cut, precision="f32")
+    try:
+        def solve(s):
+            s.initialiseSmpcController(dh, ah)
+            s.apgReset()
+            s.apgIterate(20, history=False)
+            return s.counters()
+
+        counters = rk.run(solve)
+        assert all(c == {"optimistic": 1, "exact": 0, "replayed": 0, "hold": 0} for c in counters), counters
+        d = dims_of(full)
+        for bid, nm, dm in VECS:
+            got = rk.gathered(bid, d[dm])
+            assert relmax(got, o.get(nm)) < 2e-4, ("oracle", nm)
+            assert relmax(got, full.get(bid)) < 2e-5, ("unsharded", nm)       # same kernels, another summation order at the cut
+    finally:
+        rk.close()
+        full.close()
