@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <iostream>
 #include <thread>
 
@@ -536,12 +537,51 @@ static void testSharded(const string &dir, int world) {
         for (real_t v : want) scale = std::max(scale, std::fabs(v));
         CHECK(closeAbs(full.data(), want.data(), full.size(), 1e-9 * scale, b.name));
     }
+    // the closed loop of main.cu:45-63 on the shards: two more control steps with the in-built simulator in between.  The
+    // root's control is replicated, so every rank simulates the same plant and carries the same state, previous control,
+    // previous demand and KPIs as the unsharded controller.
+    auto closedLoop = [&](ShardedController *c, int tag, std::vector<real_t> &state, real_t kpi[4]) {
+        const string tmp = dir + "/controlOutput_" + std::to_string(tag) + ".tmp";
+        std::fstream out(tmp.c_str(), std::fstream::out);
+        bool good = true;
+        for (uint_t t = 0; t < 2; t++) {
+            c->getForecaster()->predictDemand(t); c->getForecaster()->predictPrices(t);
+            good = good && c->controlAction(out) == 1;
+            c->moveForewardInTime();
+        }
+        out.close(); std::remove(tmp.c_str());
+        SmpcConfiguration *cfg = c->getSmpcConfiguration();
+        state.assign(cfg->getCurrentX(), cfg->getCurrentX() + nx);
+        state.insert(state.end(), cfg->getPrevU(), cfg->getPrevU() + nu);
+        kpi[0] = c->getEconomicKpi(2); kpi[1] = c->getSmoothKpi(2); kpi[2] = c->getNetworkKpi(2); kpi[3] = c->getSafetyKpi(2);
+        return good;
+    };
+    std::vector<real_t> refState; real_t refKpi[4];
+    CHECK(closedLoop(&ref, 999, refState, refKpi));
+    std::vector<std::vector<real_t>> st(world); std::vector<std::array<real_t, 4>> kp(world);
+    std::vector<std::thread> th2;
+    for (int r = 0; r < world; r++)
+        th2.emplace_back([&, r]() {
+            try { ok[r] = closedLoop(rk[r], r, st[r], kp[r].data()) ? 1 : 0; }
+            catch (const std::exception &e) { std::cerr << "rank " << r << ": " << e.what() << "\n"; ok[r] = 0; }
+        });
+    for (auto &t : th2) t.join();
+    real_t sn = 0;
+    for (real_t v : refState) sn = std::max(sn, std::fabs(v));
+    for (int r = 0; r < world; r++) {
+        CHECK(ok[r] == 1);
+        CHECK(st[r].size() == refState.size() && closeAbs(st[r].data(), refState.data(), refState.size(), 1e-9 * sn, "closed-loop state / previous control"));
+        for (int k = 0; k < 4; k++) CHECK(std::fabs(kp[r][k] - refKpi[k]) <= 1e-9 * (1 + std::fabs(refKpi[k])));
+        CHECK(std::memcmp(st[r].data(), st[0].data(), st[0].size() * sizeof(real_t)) == 0);   // identical bits on every rank
+    }
     int info[7];
     CHECK(rn_shard_info(rk[0]->getEngine()->getContext(), info) == RN_OK);
     const uint_t crown = ref.getScenarioTree()->getNodesPerStageCumul()[info[2]];
     for (uint_t i = 0; i < nodes; i++) CHECK(owners[i] == (i < crown ? world : 1));   // crown replicated, every other node owned once
     long cnt[4];
     CHECK(rn_get_counters(rk[0]->getEngine()->getContext(), cnt) == RN_OK);
+    // (three control steps were run: three optimistic batches, or -- once a threshold has tripped -- one replayed batch and the
+    //  back-off's exact batches after it)
     std::cout << "sharded: " << world << " ranks, cut stage " << info[2] << ", " << info[3] << " cut parents, crown " << crown << " nodes, batches optimistic/exact/replayed "
               << cnt[0] << "/" << cnt[1] << "/" << cnt[2] << "\n";
     for (int r = 0; r < world; r++) {
