@@ -89,6 +89,25 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots_finish(const double *parti
     }
 }
 
+// The same fold by EVERY workgroup of a consumer kernel (k_lbfgs_fused): dot 0 of `nblocks` partials in exactly k_dots_finish's
+// order (thread-strided sums, then the LDS tree), so the value is bitwise the one a k_dots_finish launch would have left in
+// scal[0] -- and that launch (5 us of dependent-launch floor, 16 of them per two-loop recursion) is not needed.  All threads
+// of the workgroup call; every thread gets the sum.
+__device__ __forceinline__ double fold_dot0(const double *partials, int nblocks) {
+    __shared__ double fsh[ELT_THREADS];
+    double s = 0;
+    for (int b = threadIdx.x; b < nblocks; b += ELT_THREADS) s += partials[(size_t)b * DOT_MAX];
+    fsh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = ELT_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) fsh[threadIdx.x] += fsh[threadIdx.x + w];
+        __syncthreads();
+    }
+    const double r = fsh[0];
+    __syncthreads();
+    return r;
+}
+
 // L-BFGS two-loop updates (SmpcController::twoLoopRecursionLbfgs, SmpcController.cu:1175-1229); scal[0] holds the
 // dot product just reduced by k_dots_finish, alphaArr the first loop's coefficients.
 //   mode 0: alpha_c = rho_c <S_c, dir> ; dir -= alpha_c Y_c         (vec = Y_c)
@@ -118,12 +137,17 @@ __global__ void k_lbfgs_diffs(T *S, T *Y, const T *y, const T *yPrev, const T *g
 //   next != nullptr: partials[block][0] = <next, dir_new> over the block's elements (k_dots order), for k_dots_finish
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *src, const T *vec, const double *scal, double rho, double *alphaArr, int c,
-                                                             int mode, T scale, const T *next, double *partials, long long n, long long first) {
+                                                             int mode, T scale, const T *next, double *partials, long long n, long long first,
+                                                             const double *prevPartials, int nPrev) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     T coef = 0;
+    double dot0 = 0;
     if (mode >= 0) {
-        const T prod = (T)rho * (T)scal[0];
+        // the dot product the previous step reduced: folded here from its partials (prevPartials), or read from scal[0] where a
+        // k_dots_finish launch (and, on sharded contexts, the all-reduce) has left it
+        dot0 = prevPartials ? fold_dot0(prevPartials, nPrev) : scal[0];
+        const T prod = (T)rho * (T)dot0;
         coef = mode == 0 ? -prod : (T)alphaArr[c] - prod;
     }
     double acc[DOT_MAX];
@@ -159,7 +183,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
     }
     // the coefficient of the first loop is kept for the second one; written after every block has read scal / alphaArr is not
     // required: nobody reads alphaArr[c] in mode 0, and the next launch is stream-ordered behind this one
-    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) alphaArr[c] = (double)((T)rho * (T)scal[0]);
+    if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) alphaArr[c] = (double)((T)rho * (T)dot0);
     if (next) dots_block_reduce(acc, partials);
 }
 // S = y - yPrev, Y = g - gPrev (SmpcController::updateLbfgsBuffer, :1119-1130) and the four dot products its skip rule and
