@@ -63,9 +63,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 def _devices():
-    import torch
-
-    return torch.cuda.device_count()
+    # asked in a child process: importing torch into the process that also drives librapidnet_hip contexts (every other GPU test
+    # of the suite) ends in "double free or corruption" at interpreter exit
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, timeout=300)
+    return int(out.stdout.decode().strip().splitlines()[-1])
 
 
 def test_gpus_2_spawns_its_own_ranks():
