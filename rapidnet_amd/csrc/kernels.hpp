@@ -464,7 +464,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
     const T *__restrict__ beta = a.beta;
     const T *__restrict__ my = a.my;
     const T *__restrict__ qa = a.qa;
-    const int *__restrict__ cum = a.tr.stageCum;
+    // every stage >= c* has K nodes: the node of stage k in chain s is nodeTop + (k - c*) K -- no stage-table load per step
+    const size_t nodeTop = (size_t)a.tr.stageCum[top] + s;
     for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
         if (t < nv) {
             T rho = 0;
@@ -473,21 +474,21 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
-                    const size_t node = (size_t)cum[kk] + s;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         const T sv = b[j] + rho;                   // s_i
                         rho = sv + m[j];
                         a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
                     }
                 }
             }
-            a.rkq[((size_t)cum[top] + s) * (nv + 2 * nx) + t] = rho;
+            a.rkq[nodeTop * (nv + 2 * nx) + t] = rho;
         } else {
             const int j0 = t - nv;
             T kap = 0, q = 0;
@@ -496,19 +497,19 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
-                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+                    av[j] = qa[(nodeTop + (size_t)(kk - top) * a.K) * nx + j0];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         kap += q;                                  // kappa_i = kappa_c + q_c
                         a.sk[node * (nv + nx) + nv + j0] = kap;
                         q += av[j];                                // q_i = a_i + q_c
                     }
                 }
             }
-            const size_t ntop = (size_t)cum[top] + s;
+            const size_t ntop = nodeTop;
             a.rkq[ntop * (nv + 2 * nx) + nv + j0] = kap;
             a.rkq[ntop * (nv + 2 * nx) + nv + nx + j0] = q;
         }
@@ -536,12 +537,11 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
     // indices and the stage-table loads on the scalar unit, as in k_up_chain
     const int slot = __builtin_amdgcn_readfirstlane((int)threadIdx.x / lanesPer), t = (int)threadIdx.x - slot * lanesPer;
     if (slot < nc && t < nv + nx) {
-        const int s = c0 + slot - a.tr.stageCum[a.chainStage];
         const int top = a.chainStage;
         const T *__restrict__ beta = a.beta;
         const T *__restrict__ my = a.my;
         const T *__restrict__ qa = a.qa;
-        const int *__restrict__ cum = a.tr.stageCum;
+        const size_t nodeTop = (size_t)(c0 + slot);   // the chain's top node; every stage >= c* has K nodes
         if (t < nv) {
             T rho = 0;
             for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
@@ -549,21 +549,21 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
-                    const size_t node = (size_t)cum[kk] + s;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         const T sv = b[j] + rho;                   // s_i
                         rho = sv + m[j];
                         a.sk[node * (nv + nx) + t] = a.structured ? rho : sv;
                     }
                 }
             }
-            a.rkq[((size_t)cum[top] + s) * w + t] = rho;
+            a.rkq[nodeTop * w + t] = rho;
             sh[slot * w + t] = rho;
         } else {
             const int j0 = t - nv;
@@ -573,19 +573,19 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
-                    av[j] = qa[((size_t)cum[kk] + s) * nx + j0];
+                    av[j] = qa[(nodeTop + (size_t)(kk - top) * a.K) * nx + j0];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k - j >= top) {
-                        const size_t node = (size_t)cum[k - j] + s;
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         kap += q;                                  // kappa_i = kappa_c + q_c
                         a.sk[node * (nv + nx) + nv + j0] = kap;
                         q += av[j];                                // q_i = a_i + q_c
                     }
                 }
             }
-            const size_t ntop = (size_t)cum[top] + s;
+            const size_t ntop = nodeTop;
             a.rkq[ntop * w + nv + j0] = kap;
             a.rkq[ntop * w + nv + nx + j0] = q;
             sh[slot * w + nv + j0] = kap;
@@ -1295,6 +1295,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage;
     const int ntop = a.tr.stageCum[top] + s;
+    const size_t nodeTop = (size_t)ntop;   // every stage >= c* has K nodes: node of stage k in this chain = nodeTop + (k - c*) K
     const int par = a.tr.parent[ntop];
     const T sp = a.tr.sqrtp[ntop];   // p is constant along a chain
     const T *__restrict__ lvb = a.lvb;
@@ -1345,7 +1346,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k + j < a.N ? k + j : a.N - 1;
-                    const size_t node = (size_t)cum[kk] + s;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
                     uh[j] = uhat[node * nu + t];
                     d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t];
@@ -1353,7 +1354,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k + j < a.N) {
-                        const size_t node = (size_t)cum[k + j] + s;
+                        const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         run += dv[j];
                         const T uv = uh[j] + run;
                         if (a.writePrimal) a.u[node * nu + t] = uv;
@@ -1393,7 +1394,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     const int kk = k + j < a.N ? k + j : a.N - 1;
-                    const size_t node = (size_t)cum[kk] + s;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
                     ev[j] = eb[node * nx + j0];
                     d0[j] = dyAll[(size_t)kk * ny + j0];
@@ -1402,7 +1403,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k + j < a.N) {
-                        const size_t node = (size_t)cum[k + j] + s;
+                        const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         bw += dv[j];
                         xr += ev[j] + bw;
                         if (a.writePrimal) a.x[node * nx + j0] = xr;
