@@ -1291,7 +1291,11 @@ template <typename T>
 __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads);
 template <typename T>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, int foldCrown) {
-    const int s = blockIdx.x;
+    // foldCrown = 2 (sharded runs): the grid has one more workgroup per crown node behind the K chain workgroups; it writes that
+    // node (root -> node walk at the end of this kernel) while the chain workgroups walk their chains, instead of 18 of the 62
+    // chain workgroups doing it after their own chain (15.2 -> see DESIGN.md section 6 for the measured effect)
+    const bool crownWriter = (int)blockIdx.x >= a.K;
+    const int s = crownWriter ? 0 : (int)blockIdx.x;
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage;
     const int ntop = a.tr.stageCum[top] + s;
@@ -1319,7 +1323,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
             } else { anc[dd] = 0; writer[dd] = false; }
         }
     }
-    for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
+    for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
             T run;
             if (foldCrown) {
@@ -1418,7 +1422,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
         // sharded runs: crown node j is written by workgroup j mod gridDim, which walks root -> j itself (every input
         // of the path is already there: independent loads, then a short running sum with down_crown_node's association)
         const int nCrown = cum[top];
-        for (int j = blockIdx.x; j < nCrown; j += gridDim.x) {
+        for (int j = crownWriter ? (int)blockIdx.x - a.K : nCrown; j < nCrown; j += nCrown) {
             const int kj = a.tr.stageOf[j];
             int pth[CROWN_MAX_DEPTH];              // pth[0] = j, pth[kj] = root
             {

@@ -911,7 +911,8 @@ struct Ctx : CtxBase {
             if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
         }
-        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
+        // sharded (foldCrown = 2): one more workgroup per replicated crown node, which writes that node while the chains are walked
+        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K + (foldCrown == 2 ? h_stageCum[cs] : 0)), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
