@@ -321,7 +321,9 @@ class Solver:
         return u0
 
     def setExchangeMode(self, optimistic=True):
-        self._check(self.lib.rn_set_exchange_mode(self.h, 1 if optimistic else 0))
+        """False / 0: exact, True / 1: optimistic batches (default), 2: optimistic batches that keep the accelerated dual out of
+        memory between their iterations (include/rapidnet.h, rn_set_exchange_mode)."""
+        self._check(self.lib.rn_set_exchange_mode(self.h, int(optimistic)))
 
     def setWarmStart(self, on=True):
         self._check(self.lib.rn_set_warm_start(self.h, int(on)))

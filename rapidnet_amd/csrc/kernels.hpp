@@ -57,6 +57,10 @@ struct SweepArgs {
     const T *beta, *uhat, *e;
     const T *curX, *prevU, *prevUhat;
     const T *w;       // accelerated dual the sweep is evaluated at, [node][ny]
+    // wy1 != nullptr: w is NOT in memory (inner iterations of a device-resident batch, whose dual update does not store it):
+    // the consumers of w form  w = (1 + wLn) wy1 - wLn wy0  (extrap_elem: the very roundings of the dual update) from the two
+    // dual iterates y_t = wy1, y_{t-1} = wy0 on the fly
+    const T *wy1, *wy0; T wLn;
     int structured;   // 1: no per-node blocks; m2_i comes from a shared-operator GEMM, m1_i is folded into the v GEMM
     T *ab;            // structured: [node][nx+nu]  a_i = F_i' xi_i ; b_i = G_i' psi_i
     T *my;            // [node][2nv]  m1_i = Phi xi + Psi psi ; m2_i = D xi + Ftil psi
@@ -253,6 +257,14 @@ __device__ __forceinline__ DualOut<T> dual_elem(T hx, T w, T lo, T hi, T yp, T l
     o.wn = fma_rn(-ln, yp, a);
     return o;
 }
+// w = (1 + ln) y1 - ln y0 with exactly the roundings of dual_elem's wn: whoever derives the extrapolated dual from the two
+// iterates instead of reading it gets the bits the dual update would have stored (ln = 0, y0 = y1: returns y1 unchanged)
+template <typename T>
+__device__ __forceinline__ T extrap_elem(T y1, T y0, T ln) {
+#pragma clang fp contract(off)
+    const T a = ((T)1 + ln) * y1;
+    return fma_rn(-ln, y0, a);
+}
 
 template <typename T> struct Slot;
 template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
@@ -337,7 +349,11 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     const T spn = a.tr.sqrtp[node];
     const int tq = tid < nx ? tid : 0;
     const T dq0 = dyRow[tq], dq1 = dyRow[nx + tq];    // for a_i below
-    const T w0 = a.w[i0];
+    // the y column: w itself, or -- when the dual update did not store it -- the two dual iterates it is made of.  Branch-free:
+    // without the iterates both loads hit the same w element and extrap_elem(w, w, 0) returns w unchanged
+    const T *wA = a.wy1 ? a.wy1 : a.w, *wB = a.wy1 ? a.wy0 : a.w;
+    const T wLn = a.wy1 ? a.wLn : (T)0;
+    const T w0a = wA[i0], w0b = wB[i0];
     asm volatile("" ::: "memory");   // keep the request order: the compiler otherwise hoists the group's loads above the small ones
     {
         const int lastSlot = (int)blockSlots - 1;
@@ -353,8 +369,8 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     // a_i is STORED AT THE END of the kernel: stores count in the same in-order counter as the loads, so a store issued
     // here has to be acknowledged before the wave may consume any group of A_i requested after it
     T qa0 = 0;
-    if (has0) sh_y[tid] = w0;
-    for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = a.w[(size_t)node * ny + c];
+    if (has0) sh_y[tid] = extrap_elem(w0a, w0b, wLn);
+    for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = extrap_elem(wA[(size_t)node * ny + c], wB[(size_t)node * ny + c], wLn);
     __syncthreads();
     // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
     if (tid < nx) qa0 = stream_qa_elem(spn, dq0, sh_y[tid], dq1, sh_y[nx + tid]);
@@ -414,6 +430,11 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
 //   m2_i = D_i xi_i + Ftil_i psi_i = [Bbt | L'] [a_i; b_i],   a_i = F_i' xi_i,  b_i = G_i' psi_i     (elementwise + one GEMM)
 //   m1_i = -Rinv m2_i / (2 p_i)   is folded into  v_i = -(Rinv rho_i + Rinv Bbt kappa_i) / (2 p_i)
 // and no per-node block is ever stored or read.  This kernel is the elementwise part.
+// element i of the accelerated dual the sweep is evaluated at (SweepArgs::w, or derived from the two iterates)
+template <typename T>
+__device__ __forceinline__ T sweep_w(const SweepArgs<T> &a, size_t i) {
+    return a.wy1 ? extrap_elem(a.wy1[i], a.wy0[i], a.wLn) : a.w[i];
+}
 template <typename T>
 __global__ void k_struct_prep(SweepArgs<T> a) {
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nx + nu;
@@ -421,11 +442,11 @@ __global__ void k_struct_prep(SweepArgs<T> a) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int node = (int)(i / w), t = (int)(i % w);
         const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
-        const T *y = a.w + (size_t)node * ny;
+        const size_t y = (size_t)node * ny;
         const T sp = a.tr.sqrtp[node];
         T val;
-        if (t < nx) { val = sp * (dy[t] * y[t] + dy[nx + t] * y[nx + t]); a.qa[(size_t)node * nx + t] = val; }
-        else { const int j = t - nx; val = sp * dy[2 * nx + j] * y[2 * nx + j]; }
+        if (t < nx) { val = sp * (dy[t] * sweep_w(a, y + t) + dy[nx + t] * sweep_w(a, y + nx + t)); a.qa[(size_t)node * nx + t] = val; }
+        else { const int j = t - nx; val = sp * dy[2 * nx + j] * sweep_w(a, y + 2 * nx + j); }
         a.ab[i] = val;
     }
 }
@@ -1194,13 +1215,13 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
     for (int r = wave; r < 16; r += nw) {         // one slab row (node) per wave and pass
         const int node = node0 + (r < cnt ? r : 0);
         const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
-        const T *y = a.w + (size_t)node * ny;
+        const size_t y = (size_t)node * ny;
         const T sp = a.tr.sqrtp[node];
         for (int t = lane; t < SB; t += 64) {
             T val = 0;
             if (r < cnt && t < k) {
-                if (t < nx) { val = sp * (dy[t] * y[t] + dy[nx + t] * y[nx + t]); a.qa[(size_t)node * nx + t] = val; }
-                else { const int j = t - nx; val = sp * dy[2 * nx + j] * y[2 * nx + j]; }
+                if (t < nx) { val = sp * (dy[t] * sweep_w(a, y + t) + dy[nx + t] * sweep_w(a, y + nx + t)); a.qa[(size_t)node * nx + t] = val; }
+                else { const int j = t - nx; val = sp * dy[2 * nx + j] * sweep_w(a, y + 2 * nx + j); }
             }
             sB[r * SB + t] = val;
         }
@@ -1518,6 +1539,10 @@ template <typename T>
 struct DualArgs {
     const T *hx, *w, *yprev, *lo, *hi;
     T *ynew, *wnext, *z, *res;
+    // k_dual_stage with LAZY: `w` points at y_{t-1} (the buffer ynew overwrites, element by element, after reading it) and the
+    // accelerated dual of this iteration is formed on the fly, w_t = (1 + lnCur) yprev - lnCur y_{t-1} (extrap_elem: the bits a
+    // stored w_t would have); wview (last iteration of a batch only): where w_t is stored for the getters
+    T lnCur; T *wview;
     long long n;           // nodes * ny
     int nx, ny;
     T lambda, invLambda;
@@ -1777,7 +1802,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_fused(DualArgs<T> a) {
 // bookkeeping code.
 #ifndef RN_DUAL_ABL
 #define RN_DUAL_ABL 0   // timing ablations of k_dual_stage (tools/sweep_variants.sh; results are WRONG when set): bit 0 = no table loads,
-#endif                  // bit 1 = no reductions / partials, bit 2 = no stores
+#endif                  // bit 1 = no reductions / partials, bit 2 = no stores, bit 3 = no store of the extrapolated dual w (4 streams instead of 5)
 struct DualStageShape {
     int cs, K, node0;        // first regular stage, nodes per regular stage, first node of stage cs
     int bps, crownBlocks;    // workgroups per regular stage; leading workgroups that cover the nodes [0, node0)
@@ -1826,12 +1851,17 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
     s.bhi = *reinterpret_cast<const VT *>(a.bhi + s.c);
 #endif
 }
-template <typename T, bool MATERIALIZE>
+// LAZY = 0: w is read, y+ and w_next are stored.  Device-resident batches of more than one iteration keep the accelerated dual
+// out of memory between their iterations -- the next sweep and the next dual update derive it from the two iterates (4 streams
+// instead of 5, and 21 MB of dirty lines less in front of the streaming kernel): LAZY = 3 (first iteration): w is read, w_next not
+// stored; LAZY = 1 (inner iterations): w derived, w_next not stored; LAZY = 2 (last iteration): w derived, and both w_t (wview)
+// and w_next stored, so that the state a caller can observe is what it always was.
+template <typename T, bool MATERIALIZE, int LAZY>
 __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualArgs<T> &a, T ln, DualAcc<T> &r) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     if (!s.on) return;
-    VT yn, wn, z, res;
+    VT yn, wn, z, res, wcur;
     const long long i0 = s.iv * VN;
     const bool counted = a.countCrown || i0 >= a.crownElems;
 #pragma unroll
@@ -1841,7 +1871,8 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
         const T k = s.sp * s.dy[e];
         const T lo = k * s.blo[e];
         const T hi = (isXi && !isBox) ? s.bhi[e] : k * s.bhi[e];
-        const DualOut<T> o = dual_elem<T, false>(s.hx[e], s.w[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
+        wcur[e] = (LAZY == 1 || LAZY == 2) ? extrap_elem(s.yp[e], s.w[e], a.lnCur) : s.w[e];
+        const DualOut<T> o = dual_elem<T, false>(s.hx[e], wcur[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
         yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
 #if !(RN_DUAL_ABL & 2)
         const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
@@ -1859,14 +1890,18 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
     if (yn[0] == (T)1.2345e-30) reinterpret_cast<VT *>(a.ynew)[s.iv] = wn;
 #else
     reinterpret_cast<VT *>(a.ynew)[s.iv] = yn;
-    reinterpret_cast<VT *>(a.wnext)[s.iv] = wn;
+#if RN_DUAL_ABL & 8
+    if (yn[0] == (T)1.2345e-30)
+#endif
+    if (LAZY == 0 || LAZY == 2) reinterpret_cast<VT *>(a.wnext)[s.iv] = wn;
+    if (LAZY == 2) reinterpret_cast<VT *>(a.wview)[s.iv] = wcur;
     if (MATERIALIZE) { reinterpret_cast<VT *>(a.z)[s.iv] = z; reinterpret_cast<VT *>(a.res)[s.iv] = res; }
 #endif
     (void)counted;
 }
 // PIPE = 1: one vector at a time;  PIPE = 2: double-buffered -- the loads of trip t+1 are requested before trip t is consumed, so
 // a wave always has a trip in flight (the kernel lives on memory-level parallelism: its VALU phase is a gap in the streams)
-template <typename T, bool MATERIALIZE, int PIPE>
+template <typename T, bool MATERIALIZE, int PIPE, int LAZY>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualStageShape g) {
     __shared__ Partial sh_p[ELT_THREADS / 64];
     const T ln = (T)g.lnNext;
@@ -1888,7 +1923,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
         for (int t = 0; t < g.trips; t++) {
             DualSlot<T> s;
             dual_slot_load<T>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE>(s, a, ln, r);
+            dual_slot_use<T, MATERIALIZE, LAZY>(s, a, ln, r);
         }
     } else {
         DualSlot<T> sA, sB;
@@ -1896,9 +1931,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
         for (int t = 0; t < g.trips; t += 2) {
             const bool hasB = t + 1 < g.trips;
             if (hasB) dual_slot_load<T>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE>(sA, a, ln, r);
+            dual_slot_use<T, MATERIALIZE, LAZY>(sA, a, ln, r);
             if (t + 2 < g.trips) dual_slot_load<T>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
-            if (hasB) dual_slot_use<T, MATERIALIZE>(sB, a, ln, r);
+            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY>(sB, a, ln, r);
         }
     }
 #if RN_DUAL_ABL & 2
@@ -2021,7 +2056,7 @@ template <typename T>
 __global__ void k_extrapolate(T *acc, T *xi, const T *upd, T lambda, long long n) {   // SmpcController.cu:535-557
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const T y1 = upd[i];
-        acc[i] = ((T)1 + lambda) * y1 - lambda * xi[i];
+        acc[i] = extrap_elem(y1, xi[i], lambda);   // the roundings of the fused dual update's w_next
         xi[i] = y1;
     }
 }
