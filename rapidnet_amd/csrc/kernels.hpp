@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a
 enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2 };   // EPI_LV is also used for the structured m2_i = [Bbt | L'] [a_i; b_i]
 template <typename T>
 struct GemmArgs {
-    const T *M; int m, k;        // logical m x k; stored zero-padded, col-major, mp x kp with mp % 64 == 0, kp % 4 == 0
+    const T *M; int m, k;        // logical m x k; stored zero-padded, col-major, mp x kp with mp % 64 == 0, kp % (4 * RN_SLAB_KU) == 0
     int mp, kp;
     const T *in; int ldin;       // in_i = in + i*ldin (k entries)
     T *out; int ldout;           // out_i = out + i*ldout (m entries)
@@ -1052,14 +1052,13 @@ constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #define RN_SLAB_ROTATE 1
 #endif
 #ifndef RN_SLAB_KU
-#define RN_SLAB_KU 4   // k-steps whose operands a wave requests at once (measured: 4 beats 8 and 12 on the 493-scenario tree)
+#define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k)
 #endif
-template <typename T>
-__device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, int k, int kp, int node0, int cnt, int wave, int nw, int lane) {
-    // 64 consecutive elements of one row per wave-instruction, SLAB_LD requests in flight per wave; zero fill up to kp / 16 rows
-    constexpr int SLAB_LD = 8;
-    const int cpr = (kp + 63) / 64;
-    const int nChunks = 16 * cpr;
+template <typename T, int SLAB_LD = 8>
+__device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, int k, int kp, int node0, int cnt, int wave, int nw, int lane, int rows = 16) {
+    // 64 consecutive elements of one row per wave-instruction, SLAB_LD requests in flight per wave; zero fill up to kp / `rows` rows
+    const int cpr = (kp + 63) / 64;            // 64-element chunks per row: cover [0, kp) (kp <= SB; beyond k: zeros)
+    const int nChunks = rows * cpr;
     for (int c0 = wave; c0 < nChunks; c0 += nw * SLAB_LD) {
         T v[SLAB_LD];
         int dst[SLAB_LD];
@@ -1075,40 +1074,101 @@ __device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, 
         for (int u = 0; u < SLAB_LD; u++) if (dst[u] >= 0) sB[dst[u]] = v[u];
     }
 }
-// acc[j] = M[tile t0 + j*ts] * slab  for j < TG (tiles past `tiles` recompute tile t0; the caller drops them)
-template <typename T, int TG, int KU>
+// The MFMA loop of the slab products: acc[j][c] += A_tile_j (16 x K) * B_coltile_c (K x 16) over G groups of KU k-steps.
+// Software-pipelined by hand -- the compiler does not do it, and a loop that requests a group, waits for it and then issues
+// its MFMAs runs at a third of the matrix pipe's rate (round 3: 81 ns per v_mfma_f64_16x16x4_f64 and wave where the pipe
+// issues one per 27 ns, tools/probes/probe_mfma_f64.hip): the A fragments (global memory: the shared operator, L2-resident)
+// are requested TWO groups ahead, the B fragments (LDS) one group ahead, and the loop body has no guard of any kind: the
+// operators are stored with K padded by zero columns to a whole number of groups (host: pad_k), the LDS slab is zero beyond
+// k, and the prefetches past the last group re-read the last group (a scalar min on the group index, no branch).
+// Same order of accumulation over k as every earlier version of these kernels.
+template <typename T, int TG, int CT, int KU>
+__device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[TG][CT], const T *(&Ap)[TG], size_t aStep, const T *Bp,
+                                               int bTile, int G) {
+    T a0[KU][TG], a1[KU][TG], a2[KU][TG], b0[KU][CT], b1[KU][CT], b2[KU][CT];   // three rotating sets: no register copies of in-flight loads
+#define RN_LOAD_A(dst, g_)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TG; j++) dst[i][j] = Ap[j][((size_t)(g_) * KU + i) * aStep];
+#define RN_LOAD_B(dst, g_)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                     \
+        _Pragma("unroll") for (int c = 0; c < CT; c++) dst[i][c] = Bp[c * bTile + ((g_) * KU + i) * 4];
+    // one group: request A of group g + 2 and B of group g + 1, multiply group g, then PIN the operands of group g + 1 (an empty
+    // asm that uses them: they are registers here) -- without the pins the compiler sinks every request down to its first use
+    // in a later step and the loop is "request, wait, multiply" again; the scheduling barriers keep the requests in front of
+    // the MFMAs.  The A requests of group g + 2 stay in flight across the pin.
+#define RN_STEP(cur, nxt, far, bcur, bnxt, g_)                                                                         \
+    {                                                                                                                  \
+        const int gf_ = (g_) + 2 < gl ? (g_) + 2 : gl, gn_ = (g_) + 1 < gl ? (g_) + 1 : gl;                            \
+        RN_LOAD_A(far, gf_)                                                                                            \
+        RN_LOAD_B(bnxt, gn_)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < TG; j++)                                                             \
+                _Pragma("unroll") for (int c = 0; c < CT; c++) acc[j][c] = Mfma16<T>::run(cur[i][j], bcur[i][c], acc[j][c]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < KU; i++) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < TG; j++) asm volatile("" ::"v"(nxt[i][j]));                          \
+            _Pragma("unroll") for (int c = 0; c < CT; c++) asm volatile("" ::"v"(bnxt[i][c]));                         \
+        }                                                                                                              \
+    }
+    const int gl = G - 1;
+    RN_LOAD_A(a0, 0)
+    RN_LOAD_A(a1, (1 < gl ? 1 : gl))
+    RN_LOAD_B(b0, 0)
+    int g = 0;
+    for (; g + 3 <= G; g += 3) {
+        RN_STEP(a0, a1, a2, b0, b1, g)
+        RN_STEP(a1, a2, a0, b1, b2, g + 1)
+        RN_STEP(a2, a0, a1, b2, b0, g + 2)
+    }
+    if (g < G) RN_STEP(a0, a1, a2, b0, b1, g)
+    if (g + 1 < G) RN_STEP(a1, a2, a0, b1, b2, g + 1)
+#undef RN_STEP
+#undef RN_LOAD_A
+#undef RN_LOAD_B
+}
+// acc[j] = M[tile t0 + j*ts] * slab  for j < TG (tiles past `tiles` recompute tile t0; the caller drops them).
+// PIPE: the software-pipelined loop above (220 VGPRs: for launches with at most one workgroup per CU, where nothing else hides
+// the operand latency -- small and sharded trees); otherwise the lean loop (request a group, multiply it; 100 VGPRs), which
+// leaves the latency hiding to the three workgroups that share a CU when there are more slabs than CUs.
+template <typename T, int TG, int KU, bool PIPE>
 __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], const T *M, int mp, int t0, int ts, int tiles, int ksteps,
                                           const T *sB, int SB, int lane) {
     typedef typename Mfma16<T>::acc_t acc_t;
     const int col = lane & 15, kq = lane >> 4;
     const T *Ap[TG];
+    const T *Bp = sB + col * SB + kq;
+    if (PIPE) {
+        acc_t a2[TG][1];
+#pragma unroll
+        for (int j = 0; j < TG; j++) {
+            const int t = t0 + ts * j;
+            Ap[j] = M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
+            a2[j][0] = acc_t{0, 0, 0, 0};
+        }
+        slab_mfma_pipe<T, TG, 1, KU>(a2, Ap, (size_t)4 * mp, Bp, 0, ksteps / KU);
+#pragma unroll
+        for (int j = 0; j < TG; j++) acc[j] = a2[j][0];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TG; j++) {
         const int t = t0 + ts * j;
         Ap[j] = M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
         acc[j] = acc_t{0, 0, 0, 0};
     }
-    const T *Bp = sB + col * SB + kq;
-#ifndef RN_VLV_ABL
-#define RN_VLV_ABL 0   // timing ablations of the slab products (results WRONG when set): 1 = no A loads, 2 = no B loads, 4 = no MFMA
-#endif
-    for (int ks = 0; ks < ksteps; ks += KU) {
+    for (int ks = 0; ks < ksteps; ks += KU) {     // ksteps is a whole number of groups (K padded by the host)
         T av[KU][TG], bv[KU];
 #pragma unroll
         for (int i = 0; i < KU; i++) {
-            const bool on = ks + i < ksteps;
-            const int kc = on ? ks + i : ksteps - 1;
 #pragma unroll
-            for (int j = 0; j < TG; j++) av[i][j] = (RN_VLV_ABL & 1) ? (T)(lane + kc) : Ap[j][(size_t)kc * 4 * mp];
-            bv[i] = (RN_VLV_ABL & 2) ? (T)(lane - kc) : (on ? Bp[kc * 4] : (T)0);
+            for (int j = 0; j < TG; j++) av[i][j] = Ap[j][(size_t)(ks + i) * 4 * mp];
+            bv[i] = Bp[(ks + i) * 4];
         }
 #pragma unroll
         for (int i = 0; i < KU; i++)
 #pragma unroll
-            for (int j = 0; j < TG; j++) {
-                if (RN_VLV_ABL & 4) acc[j][0] += av[i][j] * bv[i];
-                else acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
-            }
+            for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
     }
 }
 // auxiliary operands of the epilogue (m1_i or e_i), requested BEFORE the MFMA loop so that their latency hides behind it
@@ -1155,7 +1215,7 @@ __device__ unsigned long long g_ktiming[8 * 16];
 #else
 #define RN_KT(slot) do { } while (0)
 #endif
-template <typename T, int EPI, int TG, int KU>
+template <typename T, int EPI, int TG, int KU, bool PIPE>
 __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int SB, int node0, int t0, int nw, int tiles, int ksteps, int lane,
                                           T *sOut, int SO) {
     typename Mfma16<T>::acc_t acc[TG];
@@ -1163,12 +1223,12 @@ __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int
     RN_KT(EPI == EPI_V ? 6 : 10);
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
     RN_KT(EPI == EPI_V ? 7 : 11);
-    slab_mfma<T, TG, KU>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
+    slab_mfma<T, TG, KU, PIPE>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
     RN_KT(EPI == EPI_V ? 8 : 12);
     slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
     RN_KT(EPI == EPI_V ? 9 : 13);
 }
-template <typename T, int EPI>
+template <typename T, int EPI, bool PIPE>
 __device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
     const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
     const int per = (tiles + nw - 1) / nw;               // tiles per wave
@@ -1183,12 +1243,16 @@ __device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, 
 #endif
     constexpr int KU = RN_SLAB_KU;
     for (int t0 = owner; t0 < tiles; t0 += nw * tg) {
-        if (tg == 3) slab_pass<T, EPI, 3, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
-        else if (tg == 2) slab_pass<T, EPI, 2, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
-        else slab_pass<T, EPI, 1, KU>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        // tiles this wave really has in this pass (a wave whose last tile would lie past the end does not multiply a dummy: on a
+        // 12-tile operator and 8 waves that dummy was a third of the SIMDs' MFMA time)
+        const int have = (tiles - t0 + nw - 1) / nw;
+        const int now = have < tg ? have : tg;
+        if (now == 3) slab_pass<T, EPI, 3, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else if (now == 2) slab_pass<T, EPI, 2, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
+        else slab_pass<T, EPI, 1, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
     }
 }
-template <typename T, int EPI>
+template <typename T, int EPI, bool PIPE>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -1198,12 +1262,12 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_slab(GemmArgs<T> g
     const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
     slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
     __syncthreads();
-    slab_product<T, EPI>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI, PIPE>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // Structured operator mode, first product of the sweep: m2_i = [Bbt | L'] [a_i; b_i] with a_i = F_i' xi_i, b_i = G_i' psi_i
 // (F_i, G_i diagonal).  The slab of [a; b] is built in LDS straight from the duals (what k_struct_prep + a slab load
 // would do in two launches and one HBM round trip); a_i is also written out (the q recursion of k_up_chain needs it).
-template <typename T>
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T> g, SweepArgs<T> a, int SB) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB]
@@ -1227,13 +1291,13 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
         }
     }
     __syncthreads();
-    slab_product<T, EPI_LV>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI_LV, PIPE>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 // v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  in ONE launch: the v tile stays in LDS as the B operand
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
-template <typename T>
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
@@ -1280,10 +1344,112 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     for (int i = threadIdx.x; i < 16 * SV; i += blockDim.x) sV[i] = (T)0;
     __syncthreads();
     RN_KT(3);
-    slab_product<T, EPI_V>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
+    slab_product<T, EPI_V, PIPE>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
     __syncthreads();
     RN_KT(4);
-    slab_product<T, EPI_LV>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+    slab_product<T, EPI_LV, PIPE>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
+#ifdef RN_KTIMING
+    __syncthreads();
+    RN_KT(5);
+#endif
+}
+
+// The same two products for trees with MORE slabs than the chip has CUs (the 493-scenario tree: 679 slabs on 256 CUs).  There
+// k_gemm_vlv puts three workgroups on most CUs, and each of them streams the shared operators (RT: 124 KB, [L; BL]: 137 KB)
+// from L2 through the CU's one vector-memory pipe: 890 KB of A fragments per CU and launch, as long a stream as the fp64 MFMAs of
+// the three slabs themselves -- and the two overlap imperfectly (section 3 of DESIGN.md: 31 us against a 12.4 us matrix-pipe floor).
+// Here ONE workgroup per CU owns CT consecutive slabs (CT * 16 nodes): a wave owns a 16-row tile of the operator over the full K
+// and keeps CT accumulators, so every A fragment it loads feeds CT MFMAs (B fragments: LDS, as before) -- a third of the
+// operand stream at CT = 3, with the next group of A fragments requested before the current group's MFMAs are issued.
+// Every output element is the same chain of MFMAs over k as in k_gemm_vlv: bitwise the same results.
+#ifndef RN_WIDE_KU
+#define RN_WIDE_KU RN_SLAB_KU
+#endif
+#ifndef RN_WIDE_THREADS
+#define RN_WIDE_THREADS 512
+#endif
+#ifndef RN_WIDE_LD
+#define RN_WIDE_LD 18     // slab rows x 64-element chunks a wave requests at once (48 rows x 3 chunks over 8 waves: one round trip)
+#endif
+template <typename T, int CT, int KU>
+__device__ __forceinline__ void wide_mfma(typename Mfma16<T>::acc_t (&acc)[CT], const T *M, int mp, int t, int ksteps, const T *sB, int SB, int lane) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    const int col = lane & 15, kq = lane >> 4;
+    const T *Ap[1] = {M + (size_t)t * 16 + col + (size_t)kq * mp};
+    acc_t a2[1][CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) a2[0][c] = acc_t{0, 0, 0, 0};
+    slab_mfma_pipe<T, 1, CT, KU>(a2, Ap, (size_t)4 * mp, sB + col * SB + kq, 16 * SB, ksteps / KU);
+#pragma unroll
+    for (int c = 0; c < CT; c++) acc[c] = a2[0][c];
+}
+template <typename T, int EPI, int CT>
+__device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
+    const int col = lane & 15;
+    for (int t = wave; t < tiles; t += nw) {
+        acc_t acc[CT];
+        T auxv[CT][4], scale[CT];
+        RN_KT(EPI == EPI_V ? 6 : 10);
+        // the epilogue's operands (m1_i) are requested before the MFMA loop: their latency hides behind it
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const int node = node0 + c * 16 + col;
+            const int nodeC = node < g.nodes ? node : g.nodes - 1;
+            scale[c] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                auxv[c][reg] = (EPI != EPI_LV) ? g.aux[(size_t)nodeC * g.ldaux + (gr < g.m ? gr : g.m - 1)] : (T)0;
+            }
+        }
+        RN_KT(EPI == EPI_V ? 7 : 11);
+        wide_mfma<T, CT, RN_WIDE_KU>(acc, g.M, g.mp, t, ksteps, sB, SB, lane);
+        RN_KT(EPI == EPI_V ? 8 : 12);
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const int node = node0 + c * 16 + col;
+            const bool nodeOk = node < g.nodes;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                T r = acc[c][reg];
+                if (EPI == EPI_V) r = auxv[c][reg] + scale[c] * r;
+                if (EPI == EPI_Z) r = auxv[c][reg] + r;
+                const bool live = gr < g.m;
+                if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
+                if (sOut && live) sOut[(c * 16 + col) * SO + gr] = nodeOk ? r : (T)0;
+            }
+        }
+        RN_KT(EPI == EPI_V ? 9 : 13);
+    }
+}
+template <typename T, int CT>
+__global__ void __launch_bounds__(RN_WIDE_THREADS) k_gemm_vlv_wide(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
+    extern __shared__ unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [CT * 16][SB] slabs of [s; kappa]
+    T *sV = sB + CT * 16 * SB;                   // [CT * 16][SV] v of the slabs, zero beyond gV.m
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    RN_KT(0);
+    RN_KT(1);
+    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv); foldRoot = 2 never comes here
+        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();
+        __syncthreads();
+    }
+    RN_KT(2);
+    const int node0 = blockIdx.x * 16 * CT;
+    const int cnt = gV.nodes - node0 < 16 * CT ? gV.nodes - node0 : 16 * CT;
+    slab_load<T, RN_WIDE_LD>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane, 16 * CT);
+    for (int i = threadIdx.x; i < CT * 16 * SV; i += blockDim.x) sV[i] = (T)0;
+    __syncthreads();
+    RN_KT(3);
+    wide_product<T, EPI_V, CT>(gV, sB, SB, node0, wave, nw, lane, sV, SV);
+    __syncthreads();
+    RN_KT(4);
+    wide_product<T, EPI_LV, CT>(gL, sV, SV, node0, wave, nw, lane, nullptr, 0);
 #ifdef RN_KTIMING
     __syncthreads();
     RN_KT(5);

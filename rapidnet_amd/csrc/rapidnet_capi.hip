@@ -395,7 +395,7 @@ struct Ctx : CtxBase {
     }
 
     static int pad16(int v) { return (v + 63) / 64 * 64; }   // rows padded to one wave tile (GEMM_RT * 16)
-    static int pad4(int v) { return (v + 3) / 4 * 4; }
+    static int pad4(int v) { return (v + 4 * RN_SLAB_KU - 1) / (4 * RN_SLAB_KU) * (4 * RN_SLAB_KU); }   // pad_k: K of the shared operators in whole groups of the MFMA loop (zero columns)
     int upload_padded(T *dst, const double *src, int m, int k) {   // col-major m x k -> zero-padded pad16(m) x pad4(k)
         const int mp = pad16(m), kp = pad4(k);
         std::vector<double> tmp((size_t)mp * kp, 0.0);
@@ -736,6 +736,14 @@ struct Ctx : CtxBase {
     // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
     // time on idle tile slots (throughput).  Few slabs (small or sharded trees: every workgroup has a CU to itself): the
     // count with the shortest critical path per workgroup (latency).
+    // which MFMA loop the slab kernels run (slab_mfma): the software-pipelined one when a launch has at most one workgroup per CU
+    // (small or sharded trees: nothing else hides the operand latency) and in fp32 (half the registers: the workgroups still share
+    // a CU); the lean one otherwise.  Measured, k_gemm_vlv, lean | pipelined: 31-scenario tree 14.0 | 12.5 us, 1/8 shard 19.4 |
+    // 17.7, 1/2 shard (340 slabs) 27.3 | 28.1, whole 493-scenario tree 30.0 | 35.8; fp32 wide network (k_gemm_prep_m2) 954 | 574.
+    bool few_slabs() const {
+        static const int force = [] { const char *e = std::getenv("RAPIDNET_SLAB_PIPE"); return e ? std::atoi(e) : -1; }();   // tuning runs
+        return force >= 0 ? force != 0 : ((d.nodes + 15) / 16 <= numCUs || sizeof(T) == 4);
+    }
     int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) const {
         const bool few = (d.nodes + 15) / 16 <= numCUs;
         int best = 4; long bestCost = -1;
@@ -755,7 +763,8 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {   // slab kernel (default); falls back to the tile kernel when the slab does not fit
             const int nw = slab_waves((m + 15) / 16, g.kp / 4, 0, 0);
-            hipLaunchKernelGGL((k_gemm_slab<T, EPI>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_slab<T, EPI, true>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
+            else hipLaunchKernelGGL((k_gemm_slab<T, EPI, false>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, SB);
             return;
         }
 #endif
@@ -771,7 +780,8 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
-            hipLaunchKernelGGL(k_gemm_prep_m2<T>, dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_prep_m2<T, true>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
+            else hipLaunchKernelGGL((k_gemm_prep_m2<T, false>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
             return;
         }
 #endif
@@ -787,6 +797,29 @@ struct Ctx : CtxBase {
         return false;
 #endif
     }
+    // slabs per workgroup of k_gemm_vlv_wide (0: use k_gemm_vlv): 3 when every CU gets many slabs (more than four per CU: the
+    // shared operators' stream from L2, re-read per slab, is then what the launch waits for; fp32 wide network, 21 slabs per CU:
+    // 1 047 -> 780 us), and only if the workgroup's LDS (ct slab buffers; > 64 KB needs the function attribute, set once) is
+    // granted.  With two or three slabs per CU (493-scenario tree) the plain kernel is as fast or faster (30.0 vs 31.2 us).
+    int wideCt = -1;
+    int wide_ct(int nSlabs, size_t ldsPerSlab) {
+        if (wideCt >= 0) return wideCt;
+        wideCt = 0;
+        int want = nSlabs > 4 * numCUs ? 3 : 0;
+        if (const char *e = std::getenv("RAPIDNET_VLV_WIDE")) want = std::min(3, std::max(0, std::atoi(e)));   // tuning runs; 0 / 1: off
+        for (; want >= 2; want--) {
+            const size_t bytes = ldsPerSlab * want;
+            if (bytes > 160 * 1024) continue;
+            const void *fn = want == 2 ? (const void *)k_gemm_vlv_wide<T, 2> : (const void *)k_gemm_vlv_wide<T, 3>;
+            if (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) { wideCt = want; break; }
+            (void)hipGetLastError();
+        }
+        return wideCt;
+    }
+    static int wide_waves() {
+        static const int nw = [] { const char *e = std::getenv("RAPIDNET_VLV_WIDE_WAVES"); const int v = e ? std::atoi(e) : 8; return std::min(RN_WIDE_THREADS / 64, std::max(4, v)); }();
+        return nw;
+    }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
     void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
@@ -798,8 +831,17 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nSlabs = (d.nodes + 15) / 16;
+            // more slabs than CUs: one workgroup per CU with CT slabs each, every A fragment used CT times (k_gemm_vlv_wide)
+            const int ct = wide_ct(nSlabs, lds);
+            if (ct >= 2 && foldRoot != 2) {
+                const int grid = (nSlabs + ct - 1) / ct, threads = 64 * wide_waves();
+                if (ct == 2) hipLaunchKernelGGL((k_gemm_vlv_wide<T, 2>), dim3(grid), dim3(threads), lds * 2, stream, gV, gL, SB, SV, a, foldRoot);
+                else hipLaunchKernelGGL((k_gemm_vlv_wide<T, 3>), dim3(grid), dim3(threads), lds * 3, stream, gV, gL, SB, SV, a, foldRoot);
+                return;
+            }
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            hipLaunchKernelGGL(k_gemm_vlv<T>, dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
             return;
         }
 #endif

@@ -1,0 +1,40 @@
+"""The shared-operator products v = m1 - RT [s; kappa] / (2p) and [L v; B L v] have three forms: k_gemm_vlv with the
+software-pipelined MFMA loop (at most one slab workgroup per CU, and fp32), k_gemm_vlv with the lean loop (more slabs than
+CUs) and k_gemm_vlv_wide (2 or 3 slabs per workgroup, every operator fragment used for all of them: many slabs per CU).
+Which one a context takes is decided by the tree's size; every output element is the same chain of MFMAs over k in all of
+them, so forcing the wide kernel on a small tree must reproduce the default bit for bit.  (The lean loop and the wide kernel
+at their own sizes are covered by the full-size tests: tests/test_gpu_fullsize.py, tests/test_gpu_baseline_configs.py.)"""
+import numpy as np
+import pytest
+
+from rapidnet_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+synth.CONFIGS.setdefault("wide16", (4, 200, 360, 280, 54, 24, [4, 2, 2]))   # the wide network (nv = 306: 20 row tiles), 16 scenarios
+BUFS = (capi.BUF_X, capi.BUF_U, capi.BUF_V, capi.BUF_UPD_XI, capi.BUF_UPD_PSI, capi.BUF_PRIMAL_XI, capi.BUF_PRIMAL_PSI)
+
+
+def run(p, structured, precision, n=40):
+    s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    s.initialiseSmpcController(dh, ah)
+    s.apgReset()
+    hist = s.apgIterate(n)
+    out = {b: s.get(b) for b in BUFS}
+    kernel = s.kernelInfo()
+    s.close()
+    return hist, out, kernel
+
+
+@pytest.mark.parametrize("name,structured,precision", [("medium", False, "f64"), ("medium", True, "f64"), ("ragged", False, "f64"),
+                                                       ("barcelona31", False, "f64"), ("medium", False, "f32"), ("wide16", False, "f32")])
+@pytest.mark.parametrize("ct", [2, 3])
+def test_wide_slab_kernel_is_bitwise_the_default(monkeypatch, name, structured, precision, ct):
+    p = synth.make_problem(name)
+    monkeypatch.delenv("RAPIDNET_VLV_WIDE", raising=False)
+    h0, o0, _ = run(p, structured, precision)
+    monkeypatch.setenv("RAPIDNET_VLV_WIDE", str(ct))     # read when a context launches its first sweep
+    h1, o1, _ = run(p, structured, precision)
+    assert np.array_equal(h0, h1)
+    for b in BUFS:
+        assert np.array_equal(o0[b], o1[b]), b
