@@ -759,8 +759,11 @@ __device__ __forceinline__ void up_root_from_presummed(const SweepArgs<T> &a, in
 // root's children are dealt flat to all threads, every child's rho / kappa / q goes to global memory (what
 // up_crown_presummed_flat stores) and to LDS, and after one barrier thread t folds the children's values in ascending
 // order (up_crown_node's association).  sh: nc * (nv + 2 nx) reals.
+// slab != nullptr: the [s; kappa] columns of the nodes 0 .. 15 (the workgroup's own slab of the v product: the root and the first
+// stage-1 nodes) are also written straight into the slab buffer ([16][SB], zeroed by the caller), so that the workgroup neither
+// waits for its stores nor reads them back from global memory
 template <typename T>
-__device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int tid, int nthreads) {
+__device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int tid, int nthreads, T *slab = nullptr, int SB = 0) {
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
     const int c0n = a.tr.childStart[0], nc = a.tr.childCount[0], s1 = a.tr.stageCum[1];
     const int total = nc * per;
@@ -794,6 +797,7 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
                     a.sk[(size_t)node * per + t] = a.structured ? rho : sv;
                     a.rkq[(size_t)node * w + t] = rho;
                     sh[(size_t)c * w + t] = rho;
+                    if (slab && node < 16) slab[node * SB + t] = a.structured ? rho : sv;
                 } else {
                     const int j0 = t - nv;
                     const T kap = c0[u] + c1[u], q = c1[u] + b0[u];
@@ -802,6 +806,7 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
                     a.rkq[(size_t)node * w + nv + nx + j0] = q;
                     sh[(size_t)c * w + nv + j0] = kap + q;
                     sh[(size_t)c * w + nv + nx + j0] = q;
+                    if (slab && node < 16) slab[node * SB + nv + j0] = kap;
                 }
             }
         }
@@ -814,6 +819,7 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
         const T rho = sv + rm;
         a.sk[tid] = a.structured ? rho : sv;
         a.rkq[tid] = rho;
+        if (slab) slab[tid] = a.structured ? rho : sv;
     } else if (tid < per) {
         const int j0 = tid - nv;
         T kap = 0, q = 0;
@@ -821,6 +827,7 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
         a.sk[nv + j0] = kap;
         a.rkq[nv + j0] = kap;
         a.rkq[nv + nx + j0] = q + rb;
+        if (slab) slab[nv + j0] = kap;
     }
 }
 // one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
@@ -1298,10 +1305,11 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
 template <typename T, bool PIPE>
-__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot) {
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int crownScratch) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
     T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
+    bool slabReady = false;                      // workgroup 0, foldRoot = 2: its slab has been filled in LDS by the crown step
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     // foldRoot = 2 (sharded, crown = root + the exchange stage): the exchange stage's step is just "beta + all-reduced
@@ -1316,7 +1324,17 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
         // has swept the caches and TLBs
         // (RN_CROWN2_FALLBACK builds force the two-function path below, which otherwise only very wide crowns take)
-        if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
+        if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && crownScratch > 0 && a.tr.stageCum[2] >= 16 && (int)blockDim.x >= a.nv + a.nx) {
+            // all 16 nodes of this workgroup's slab are crown nodes: their [s; kappa] columns go straight into the slab buffer (the
+            // children's values through a scratch area BEHIND the slab buffers, sized by the host), so the launch's critical
+            // workgroup neither drains its stores nor reads its slab back from global memory
+            up_crown2_wg0<T>(a, sB + 16 * (SB + SV), threadIdx.x, blockDim.x, sB, SB);
+            {   // the crown step wrote the nv + nx live columns of all 16 rows; the padding columns are zeroed here (disjoint: no barrier)
+                const int per = a.nv + a.nx, padc = SB - per;
+                for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) sB[(i / padc) * SB + per + i % padc] = (T)0;
+            }
+            slabReady = true;
+        } else if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
             up_crown2_wg0<T>(a, sB, threadIdx.x, blockDim.x);
         } else {
             if (blockIdx.x == 0) up_root_from_presummed<T>(a, threadIdx.x, blockDim.x);
@@ -1328,7 +1346,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
             st->distX = dX; st->distS = dS;
             if (dX > a.thrX || dS > a.thrS) st->violated = 1;
         }
-        if (lo < hi || blockIdx.x == 0) __threadfence_block();   // the workgroup reads its own sk rows back below (same CU, same L1)
+        if ((lo < hi || blockIdx.x == 0) && !slabReady) __threadfence_block();   // the workgroup reads its own sk rows back below (same CU, same L1)
         __syncthreads();
     }
     RN_KT(1);
@@ -1340,7 +1358,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     RN_KT(2);
     const int node0 = blockIdx.x * 16;
     const int cnt = gV.nodes - node0 < 16 ? gV.nodes - node0 : 16;
-    slab_load<T>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane);
+    if (!slabReady) slab_load<T>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, nw, lane);
     for (int i = threadIdx.x; i < 16 * SV; i += blockDim.x) sV[i] = (T)0;
     __syncthreads();
     RN_KT(3);

@@ -811,10 +811,30 @@ struct Ctx : CtxBase {
             const size_t bytes = ldsPerSlab * want;
             if (bytes > 160 * 1024) continue;
             const void *fn = want == 2 ? (const void *)k_gemm_vlv_wide<T, 2> : (const void *)k_gemm_vlv_wide<T, 3>;
-            if (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) { wideCt = want; break; }
+            // (the attribute belongs to the function, not to this context: always the device's whole LDS)
+            if (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) { wideCt = want; break; }
             (void)hipGetLastError();
         }
         return wideCt;
+    }
+    // values of LDS scratch behind the slab buffers of k_gemm_vlv for the root's children (0: not granted / switched off)
+    int crownScratchVals = -1;
+    int crown_scratch(size_t ldsSlab) {
+        if (crownScratchVals >= 0) return crownScratchVals;
+        crownScratchVals = 0;
+        if (const char *e = std::getenv("RAPIDNET_CROWN_LDS")) { if (std::atoi(e) == 0) return 0; }   // tuning runs
+        const size_t want = (size_t)h_childCount[0] * (d.nv + 2 * d.nx), bytes = ldsSlab + want * sizeof(T);
+        if (bytes > 160 * 1024) return 0;
+        if (bytes > 64 * 1024) {
+            // the attribute belongs to the function, not to this context: always the device's whole LDS, never a smaller value later
+            if (hipFuncSetAttribute((const void *)k_gemm_vlv<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+        }
+        crownScratchVals = (int)want;
+        return crownScratchVals;
     }
     static int wide_waves() {
         static const int nw = [] { const char *e = std::getenv("RAPIDNET_VLV_WIDE_WAVES"); const int v = e ? std::atoi(e) : 8; return std::min(RN_WIDE_THREADS / 64, std::max(4, v)); }();
@@ -840,8 +860,12 @@ struct Ctx : CtxBase {
                 return;
             }
             const int nw = slab_waves((nv + 15) / 16, gV.kp / 4, (nu + nx + 15) / 16, gL.kp / 4);
-            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
-            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), lds, stream, gV, gL, SB, SV, a, foldRoot);
+            // sharded two-stage crown (foldRoot = 2): scratch for the root's children behind the slab buffers, so that workgroup 0 -- the
+            // launch's critical path -- fills its own slab in LDS instead of draining its stores and reading them back
+            const int scratch = foldRoot == 2 ? crown_scratch(lds) : 0;
+            const size_t ldsAll = lds + (size_t)scratch * sizeof(T);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
+            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
             return;
         }
 #endif
