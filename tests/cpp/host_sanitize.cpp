@@ -1,7 +1,7 @@
 // AddressSanitizer / UBSan run of the host-only parts of the C++ class surface (rapidnet_amd/csrc/host/): the null-space
 // routine (Engine::calculateMatLandMatLhat, Engine.cu:466-669) on random full-rank and rank-deficient E, checked for
 // E L = 0, L'L = I and E Lhat = -Ed.  (The JSON loaders run under the same sanitizers through `test_host loaders`.)
-// Built and run by tests/test_partition_sanitized.py; exit code 0 = clean.
+// Built and run by tests/test_host_sanitized.py; exit code 0 = clean.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

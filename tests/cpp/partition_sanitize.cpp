@@ -1,7 +1,7 @@
 // AddressSanitizer / UBSan run of the subtree partitioner (rapidnet_amd/csrc/partition.hpp: host-only code behind
 // rn_partition_create / rn_create_sharded) over random stage-contiguous trees -- uniform and per-node child counts -- for
 // every cut stage and several rank counts, with the invariants a local tree must keep.  Built and run by
-// tests/test_partition_sanitized.py (g++ -fsanitize=address,undefined); exit code 0 = clean.
+// tests/test_host_sanitized.py (g++ -fsanitize=address,undefined); exit code 0 = clean.
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
