@@ -110,7 +110,7 @@ def measure_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + probe,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=150)
             if r.returncode != 0:
                 src["why_not"] = "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, r.stderr[-300:])
                 return {}, src
