@@ -524,7 +524,14 @@ def main():
 
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
     dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats)
-    struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats if args.structured else 0) if (args.structured or (not sharded and not args.dense_only)) else None
+    struct, struct_error = None, None
+    if args.structured:
+        struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats)
+    elif not sharded and not args.dense_only:
+        try:      # the opt-in mode rides along: a failure there is reported in the line, it does not take the headline with it
+            struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=0)
+        except Exception as e:   # noqa: BLE001
+            struct_error = "%s: %s" % (type(e).__name__, e)
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
@@ -559,6 +566,8 @@ def main():
             out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",
                                                                "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
+        if struct_error:
+            out["structured_mode"] = {"error": struct_error}
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
         # the other single-GPU configurations of BASELINE.json, timed in the same run (dense per-node blocks, the same protocol:
