@@ -149,11 +149,23 @@ int rn_apg_reset(rn_ctx *ctx);
 int rn_apg_iterate(rn_ctx *ctx, int n, double *primalInfs);
 /* SmpcController::algorithmApg (SmpcController.cu:1500-1525) = rn_apg_reset + rn_apg_iterate(maxIterations) */
 int rn_algorithm_apg(rn_ctx *ctx, int maxIterations, double *primalInfs);
-/* SmpcController::controlAction(real_t*) (SmpcController.cu:1607-1625) without the leak check:
- * update state, eliminate, APG, copy u of the root node (nu reals) to the host. */
+/* SmpcController::controlAction(real_t*) (SmpcController.cu:1607-1625): update state, eliminate, APG, copy u of the root node
+ * (nu reals) to the host.  The reference's leak check around these calls (cudaMemGetInfo before and after, :1612-1623) is the
+ * caller's, with rn_device_memory_info below -- the host class SmpcController::controlAction does exactly that. */
 int rn_control_action(rn_ctx *ctx, const double *currentX, const double *prevU, const double *prevDemand,
                       const double *nominalDemand, const double *nominalPrices, int maxIterations,
                       int projectOnBounds, double *u0);
+
+/* cudaMemGetInfo of the reference's leak check (SmpcController.cu:1612, :1619, :1641, :1657): info = {free bytes of the context's
+ * device, total bytes, bytes THIS context holds, live contexts of this process}.  The device-wide figure moves with every other
+ * context and process on the device; the context's own does not. */
+int rn_device_memory_info(rn_ctx *ctx, size_t info[4]);
+/* SmpcController::allocateApgAlgorithm sizes the per-iteration storage by maxIterations once (SmpcController.cu:124-151): reserves
+ * the iteration tables and the checkpoint buffers for batches of up to maxIterations iterations, so that no later
+ * rn_apg_iterate / rn_control_action allocates device memory.  (1 022 iterations are reserved by rn_create.) */
+int rn_reserve_iterations(rn_ctx *ctx, int maxIterations);
+/* test hook for a caller's leak check: the NEXT rn_control_action allocates `bytes` of device memory that stay with the context */
+int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes);
 
 /* Extension (the reference always cold-starts, SmpcController.cu:1509): when on,
  * rn_control_action keeps the duals of the previous control step and only restarts the momentum. */
@@ -218,6 +230,10 @@ int rn_get_operator(rn_ctx *ctx, int op_id, int node, double *host, size_t n);
 int rn_profile_enable(rn_ctx *ctx, int on);
 int rn_profile_reset(rn_ctx *ctx);
 int rn_profile_read(rn_ctx *ctx, double ms[4], long launches[4]);
+/* sharded contexts: device time between hipEvents recorded on the solver's stream around every all-reduce (RCCL or an installed
+ * stand-in) since the last rn_profile_reset -- wire latency plus the wait for the slowest peer; these intervals lie INSIDE
+ * class 1 of rn_profile_read. */
+int rn_profile_read_collective(rn_ctx *ctx, double *ms, long *launches);
 /* algorithmic HBM bytes of ONE launch of the dominant kernels, as defined in DESIGN.md */
 int rn_algorithmic_bytes(const rn_ctx *ctx, double *backwardStageBytesTotal, double *dualUpdateBytes);
 /* which kernels an iteration of this context launches: info = {1 if k_dual_stage is the main pass of the fused dual update
@@ -265,8 +281,10 @@ int rn_set_exchange_mode(rn_ctx *ctx, int mode);
  * stage order) E_i = sum over ALL children c of p_c * errorDemand_c (nd reals) and P_i = sum_c p_c.  They replace the
  * children loop of calculateZeta (Utilities.cu:100-131) for those nodes: sum_c p_c uhat_c = Lhat (E_i + P_i dhat). */
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E /* parents*nd */, const double *P /* parents */, size_t nParents);
-/* per-iteration {max|res_xi|, signed entry, max|res_psi|, signed entry} for iterations [first, first+n), so that
- * ranks can combine their local arg-max into the tree-global vecPrimalInfs (SmpcController.cu:1480-1496) */
+/* per-iteration {max|res_xi|, signed entry, max|res_psi|, signed entry} over THIS RANK's nodes for iterations [first, first+n).
+ * (The history rn_apg_iterate returns is tree-global on a sharded context with a communicator: one MAX all-reduce per batch
+ * combines the ranks' parts into vecPrimalInfs, SmpcController.cu:1480-1496, :1521.  Without a communicator -- id128 == NULL,
+ * the exchange emulated by a test -- it is rank-local and these parts are what the caller combines.) */
 int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out /* 4*n */);
 /* Batch bookkeeping of rn_apg_iterate: out = {optimistic batches, exact batches, optimistic batches that were replayed
  * through the exact path because a tree-global prox distance exceeded its threshold, exact batches still to run before the
@@ -337,6 +355,17 @@ int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
 int rn_debug_local_group_create(int nranks, void **group);
 int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);
 int rn_debug_local_group_destroy(void *group);
+
+/* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
+ * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red
+ * zone on both sides; red zones and payloads of floating-point buffers start as NaN (0xFF bytes), so an out-of-bounds or
+ * uninitialised READ carries a NaN into the iterates, and an out-of-bounds WRITE changes a red zone: rn_guard_check counts the
+ * red-zone bytes that no longer hold their pattern (0 outside guard mode); rn_destroy reports them on stderr. */
+int rn_guard_check(rn_ctx *ctx, long *badBytes);
+/* process-wide tally of the checks rn_destroy makes in guard mode: out = {contexts checked so far, red-zone bytes found overwritten} */
+int rn_guard_report(long out[2]);
+/* test of the detector itself: overwrites `nbytes` (1 .. 256) right behind the payload of the context's first buffer */
+int rn_debug_guard_poke(rn_ctx *ctx, int nbytes);
 
 #ifdef __cplusplus
 }

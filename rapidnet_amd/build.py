@@ -83,6 +83,11 @@ def hip_is_stale():
     return _stale(LIB_HIP, _hip_deps())
 
 
+def hip_fingerprint():
+    """Content fingerprint of everything librapidnet_hip.so is built from (what its .srchash stamp holds)."""
+    return _fingerprint(_hip_deps())
+
+
 LIB_HOST = os.path.join(HERE, "librapidnet_host.so")
 BIN_DIR = os.path.join(HERE, "bin")
 TEST_HOST = os.path.join(BIN_DIR, "test_host")

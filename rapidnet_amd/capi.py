@@ -35,6 +35,7 @@ SYMBOLS = [
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
+    "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
 ]
 
 
@@ -81,7 +82,10 @@ def load():
         # image).  Under a launcher only local rank 0 compiles, before any GPU call; the others wait for the finished file
         # (build_hip renames it into place).  There is no CPU fallback.
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        failed = path + ".buildfailed"      # left by local rank 0 when its build fails, so that the waiting ranks abort at once
+        # left by local rank 0 when its build fails, so that the waiting ranks abort at once.  Its first line is the fingerprint of
+        # the sources that failed to build: a marker an EARLIER run left behind for other sources is ignored (the waiting ranks may
+        # look before local rank 0 has removed it)
+        failed = path + ".buildfailed"
         try:
             if local_rank == 0:
                 if os.path.exists(failed):
@@ -90,7 +94,7 @@ def load():
                     _build.build_hip()
                 except Exception as e:
                     with open(failed, "w") as f:
-                        f.write(str(e))
+                        f.write("%s\n%s" % (_build.hip_fingerprint(), e))
                     raise
             else:
                 import time
@@ -99,7 +103,12 @@ def load():
                     if not _build.hip_is_stale():
                         break
                     if os.path.exists(failed):
-                        raise RuntimeError("local rank 0 could not build librapidnet_hip.so: %s" % open(failed).read().strip())
+                        try:
+                            stamp, _, why = open(failed).read().partition("\n")
+                        except OSError:      # removed between the two calls
+                            stamp, why = "", ""
+                        if stamp.strip() == _build.hip_fingerprint():
+                            raise RuntimeError("local rank 0 could not build librapidnet_hip.so: %s" % why.strip())
                     time.sleep(0.5)
                 else:   # every rank must run the same binary: a library that is still stale after 15 minutes is an error, not a fallback
                     raise RuntimeError("librapidnet_hip.so is still older than its sources after waiting 900 s for local rank 0 to rebuild it")
@@ -181,6 +190,13 @@ def load():
     lib.rn_debug_local_group_create.argtypes = [ip, C.POINTER(vp)]
     lib.rn_debug_local_group_join.argtypes = [vp, vp, ip]
     lib.rn_debug_local_group_destroy.argtypes = [vp]
+    lib.rn_guard_check.argtypes = [vp, dp]
+    lib.rn_device_memory_info.argtypes = [vp, dp]
+    lib.rn_reserve_iterations.argtypes = [vp, ip]
+    lib.rn_debug_inject_allocation.argtypes = [vp, C.c_size_t]
+    lib.rn_guard_report.argtypes = [dp]
+    lib.rn_debug_guard_poke.argtypes = [vp, ip]
+    lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
     _LIB = lib
     return lib
 
@@ -468,6 +484,29 @@ class Solver:
         self._check(self.lib.rn_profile_read(self.h, ms.ctypes.data, n.ctypes.data))
         return ms, n
 
+    def profileReadCollective(self):
+        """(ms, count) of the all-reduces timed since the last profileReset (sharded contexts; inside class 1 of profileRead)."""
+        ms, n = C.c_double(0), C.c_long(0)
+        self._check(self.lib.rn_profile_read_collective(self.h, C.addressof(ms), C.addressof(n)))
+        return ms.value, n.value
+
+    def guardCheck(self):
+        """red-zone bytes overwritten so far (0 unless the context was created under RAPIDNET_GUARD=1)."""
+        bad = C.c_long(0)
+        self._check(self.lib.rn_guard_check(self.h, C.addressof(bad)))
+        return bad.value
+
+    def debugGuardPoke(self, nbytes):
+        self._check(self.lib.rn_debug_guard_poke(self.h, int(nbytes)))
+
+    def deviceMemoryInfo(self):
+        out = (C.c_size_t * 4)()
+        self._check(self.lib.rn_device_memory_info(self.h, C.addressof(out)))
+        return dict(zip(("free", "total", "context_bytes", "live_contexts"), (int(v) for v in out)))
+
+    def reserveIterations(self, n):
+        self._check(self.lib.rn_reserve_iterations(self.h, int(n)))
+
     def measureHbm(self, nbytes=1 << 30, reps=3):
         """(read-only GB/s, copy GB/s) of do-nothing flat streaming kernels on this device."""
         r, c = C.c_double(0), C.c_double(0)
@@ -597,6 +636,13 @@ def partition_tree(tree, rank, nranks, cut_stage=0):
                 "momE": darr(part.momE, part.nCutParents * nd).reshape(part.nCutParents, nd), "momP": darr(part.momP, part.nCutParents)}
     finally:
         lib.rn_partition_destroy(C.byref(part))
+
+
+def guard_report():
+    """(contexts checked at rn_destroy in guard mode, red-zone bytes found overwritten) of this process."""
+    out = (C.c_long * 2)()
+    load().rn_guard_report(C.addressof(out))
+    return int(out[0]), int(out[1])
 
 
 def local_group_create(nranks):

@@ -67,6 +67,8 @@ void Engine::create(int precision, int device, int rank, int nranks, const void 
     if (rc != RN_OK) throw std::runtime_error(string("rn_create_sharded: ") + rn_last_error(nullptr));
     check(rn_set_parameters(ctx, ptrMySmpcConfig->getStepSize(), ptrMySmpcConfig->getPenaltyState(), ptrMySmpcConfig->getPenaltySafety()),
           "rn_set_parameters");
+    // SmpcController::allocateApgAlgorithm (SmpcController.cu:124-151): per-iteration storage for maxIterations, allocated once
+    check(rn_reserve_iterations(ctx, (int)ptrMySmpcConfig->getMaxIterations()), "rn_reserve_iterations");
     if (!apgFlag)   // SmpcController::allocateGlobalFbeAlgorithm / allocateNamaAlgorithm / allocateLbfgsBuffer (SmpcController.cu:234-330)
         check(rn_set_algorithm(ctx, globalFbeFlag ? RN_ALG_GLOBAL_FBE : RN_ALG_NAMA, (int)ptrMySmpcConfig->getLbfgsBufferSize()), "rn_set_algorithm");
 }

@@ -57,12 +57,31 @@ void SmpcController::controllerSmpc() {
     algorithmApg();
 }
 
+// The reference's leak check (SmpcController.cu:1612-1623, :1641, :1657-1664): free device memory before and after the control
+// step; any difference prints "RUNTIME ERROR: MEMORY LEAKS" and makes controlAction return 0.  rn_device_memory_info gives the
+// device-wide figure the reference compares (cudaMemGetInfo) and the bytes this controller's context holds.  The device-wide
+// figure also moves when ANOTHER context of this process allocates (several sharded controllers on one device in one process):
+// it is compared only while this context is the process's only one; the context's own bytes are compared always.
+bool SmpcController::deviceMemoryChanged(const size_t before[4]) {
+    size_t after[4];
+    check(rn_device_memory_info(ptrMyEngine->getContext(), after), "rn_device_memory_info");
+    const bool alone = before[3] == 1 && after[3] == 1;
+    if (after[2] != before[2] || (alone && after[0] != before[0])) {
+        std::cout << "RUNTIME ERROR: MEMORY LEAKS" << std::endl;
+        return true;
+    }
+    return false;
+}
+
 uint_t SmpcController::controlAction(real_t *u) {
     if (!factorStepFlag) { ptrMyEngine->factorStep(); factorStepFlag = true; }
+    size_t before[4];
+    check(rn_device_memory_info(ptrMyEngine->getContext(), before), "rn_device_memory_info");
     const int rc = rn_control_action(ptrMyEngine->getContext(), ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(),
                                      ptrMySmpcConfig->getPrevDemand(), ptrMyForecaster->getNominalDemand(),
                                      ptrMyForecaster->getNominalPrices(), ptrMySmpcConfig->getMaxIterations(), 0, u);
     if (rc != RN_OK) { std::cerr << "controlAction: " << rn_last_error(ptrMyEngine->getContext()) << std::endl; return 0; }
+    if (deviceMemoryChanged(before)) return 0;
     return 1;   // devControlAction (lastControl) is only written by the stream overload (:1647), as in the reference
 }
 
@@ -71,6 +90,8 @@ uint_t SmpcController::controlAction(std::fstream &out) {
     if (!factorStepFlag) { ptrMyEngine->factorStep(); factorStepFlag = true; }
     const uint_t nu = ptrMySmpcConfig->getNU();
     std::vector<real_t> u(nu);
+    size_t before[4];
+    check(rn_device_memory_info(ptrMyEngine->getContext(), before), "rn_device_memory_info");
     const int rc = rn_control_action(ptrMyEngine->getContext(), ptrMySmpcConfig->getCurrentX(), ptrMySmpcConfig->getPrevU(),
                                      ptrMySmpcConfig->getPrevDemand(), ptrMyForecaster->getNominalDemand(),
                                      ptrMyForecaster->getNominalPrices(), ptrMySmpcConfig->getMaxIterations(), 1 /* projectionBox :1649 */,
@@ -80,6 +101,7 @@ uint_t SmpcController::controlAction(std::fstream &out) {
     for (uint_t i = 0; i < nu; i++) out << u[i] << ", ";
     out << "]" << std::endl;
     lastControl = u;
+    if (deviceMemoryChanged(before)) return 0;
     return 1;
 }
 

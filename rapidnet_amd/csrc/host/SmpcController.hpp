@@ -68,6 +68,7 @@ protected:
     void getVector(int bufferId, real_t *host) { ptrMyEngine->getBuffer(bufferId, host); }
     void setVector(int bufferId, const real_t *host) { ptrMyEngine->setBuffer(bufferId, host); }
     void check(int rc, const char *what);
+    bool deviceMemoryChanged(const size_t before[4]);       // the leak check of :1612-1623 (prints the reference's message)
 
     Engine *ptrMyEngine;
     Forecaster *ptrMyForecaster;

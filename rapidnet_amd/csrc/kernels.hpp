@@ -2192,16 +2192,34 @@ __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Parti
                                                                      double *hist, double *histParts, int histCap, double thrX, double thrS) {
     finalize_optimistic_body<T>(FinArgs{partials, nblocks, st, (void *)tail, hist, histParts, histCap, thrX, thrS});
 }
-// after the all-reduce: the tail holds the tree-global dist^2 of the previous iteration
-// vote != nullptr: the rank's verdict for the whole batch (1 = a threshold was exceeded somewhere) is left there for one
-// more sum all-reduce, so that every rank takes the same replay decision even if an all-reduce algorithm ever delivered
-// results that differ in the last bit between ranks (a rank replaying alone would wait for collectives nobody else issues)
+// Sharded APG, end of a batch (SmpcController::updatePrimalInfeasibity, SmpcController.cu:1480-1496, records ONE tree-global value
+// per iteration in vecPrimalInfs, :1521): the ranks' history entries are made tree-global by one MAX all-reduce per BATCH, which
+// also carries the ranks' verdicts.  pack: out[0] = this rank's verdict (tail != nullptr: the all-reduced dist^2 of the batch's
+// last iteration is checked first against the thresholds), out[1 + 4 i ...] = (v_xi, -v_xi, v_psi, -v_psi) of iteration first + i,
+// v = the signed entry at the rank's arg-max |.|: the maxima over the ranks give the largest magnitude of either sign, hence the
+// entry at the tree-global arg-max (equal magnitudes of opposite sign on two ranks: the positive one).
 template <typename T>
-__global__ void k_check_dist(T *tail, IterState *st, double thrX, double thrS, T *vote) {
-    const double dX = sqrt((double)tail[0]), dS = sqrt((double)tail[1]);
-    st->distX = dX; st->distS = dS;
-    if (dX > thrX || dS > thrS) st->violated = 1;
-    if (vote) *vote = st->violated ? (T)1 : (T)0;
+__global__ void __launch_bounds__(ELT_THREADS) k_batch_close_pack(const T *tail, IterState *st, double thrX, double thrS, const double *histParts,
+                                                                  int first, int n, double *out) {
+    if (threadIdx.x == 0) {
+        if (tail) {
+            const double dX = sqrt((double)tail[0]), dS = sqrt((double)tail[1]);
+            st->distX = dX; st->distS = dS;
+            if (dX > thrX || dS > thrS) st->violated = 1;
+            out[0] = st->violated ? 1.0 : 0.0;
+        } else out[0] = 0.0;
+    }
+    for (int i = threadIdx.x; i < n; i += ELT_THREADS) {
+        const double vx = histParts[4 * (size_t)(first + i) + 1], vp = histParts[4 * (size_t)(first + i) + 3];
+        out[1 + 4 * i] = vx; out[2 + 4 * i] = -vx; out[3 + 4 * i] = vp; out[4 + 4 * i] = -vp;
+    }
+}
+__global__ void __launch_bounds__(ELT_THREADS) k_batch_close_unpack(const double *in, double *hist, int first, int n) {
+    for (int i = threadIdx.x; i < n; i += ELT_THREADS) {
+        const double gx = in[1 + 4 * i] >= in[2 + 4 * i] ? in[1 + 4 * i] : -in[2 + 4 * i];
+        const double gp = in[3 + 4 * i] >= in[4 + 4 * i] ? in[3 + 4 * i] : -in[4 + 4 * i];
+        hist[first + i] = gx > gp ? gx : gp;
+    }
 }
 
 // multi-GPU variant of k_decide: fold the local partials to (d2x, d2s), all-reduce those two numbers, then decide

@@ -35,15 +35,23 @@ inline int build_partition(const rn_dims *d, const rn_tree *t, const double *err
     if (cut <= 0) cut = default_cut_stage(d, t);
     if (cut < 1 || cut >= N) { err = "rn_partition_create: the cut stage must lie in [1, N-1] (a horizon of 1 cannot be sharded)"; return RN_E_ARG; }
     const int *cum = t->nodesPerStageCumul;
-    if (cum[0] != 0 || cum[N] != nodes) { err = "rn_partition_create: nodesPerStageCumul inconsistent with nodes"; return RN_E_ARG; }
+    if (nodes < 1 || cum[0] != 0 || cum[N] != nodes) { err = "rn_partition_create: nodesPerStageCumul inconsistent with nodes"; return RN_E_ARG; }
+    // the whole tree is validated BEFORE anything is indexed through it (this is a public entry point: a malformed `ancestor` or
+    // `stages` must end in RN_E_ARG, not in an out-of-bounds access): stage boundaries ascending, nodes numbered stage by stage,
+    // node 0 the only root, every other node's ancestor a node of the previous stage
+    for (int k = 0; k < N; k++)
+        if (cum[k + 1] <= cum[k]) { err = "rn_partition_create: nodesPerStageCumul must be strictly ascending (every stage has a node)"; return RN_E_ARG; }
+    if (cum[1] != 1 || t->ancestor[0] != 0 || t->stages[0] != 0) { err = "rn_partition_create: node 0 must be the only root"; return RN_E_ARG; }
+    for (int k = 1; k < N; k++)
+        for (int i = cum[k]; i < cum[k + 1]; i++) {
+            if (t->stages[i] != k) { err = "rn_partition_create: nodes are not numbered stage by stage"; return RN_E_ARG; }
+            const int par = t->ancestor[i] - 1;
+            if (par < cum[k - 1] || par >= cum[k]) { err = "rn_partition_create: ancestor must be a node of the previous stage"; return RN_E_ARG; }
+        }
     // owner of every node: -1 = replicated crown node; subtree roots by position, descendants inherit (parents come first)
     std::vector<int> owner(nodes, -1);
     for (int i = cum[cut]; i < cum[cut + 1]; i++) owner[i] = (i - cum[cut]) % nranks;
-    for (int i = cum[cut + 1]; i < nodes; i++) {
-        const int par = t->ancestor[i] - 1;
-        if (par < cum[cut] || par >= i) { err = "rn_partition_create: ancestor must be a node of the previous stage"; return RN_E_ARG; }
-        owner[i] = owner[par];
-    }
+    for (int i = cum[cut + 1]; i < nodes; i++) owner[i] = owner[t->ancestor[i] - 1];
     PartitionData *p = new PartitionData();
     std::vector<int> newId(nodes, -1);
     for (int i = 0; i < nodes; i++)

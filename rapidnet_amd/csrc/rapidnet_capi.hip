@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rapidnet.h"
@@ -102,6 +104,8 @@ struct NcclApi {
 };
 static NcclApi g_nccl;
 struct UniqueId128 { char b[128]; };
+static std::atomic<long> g_guardContexts{0}, g_guardBadBytes{0};   // guard mode: contexts checked when they were destroyed / red-zone bytes found overwritten
+static std::atomic<long> g_liveContexts{0};   // contexts of this process (rn_device_memory_info: a device-wide figure is only the caller's own while this is 1)
 
 struct CtxBase {
     std::string err;
@@ -170,6 +174,12 @@ struct CtxBase {
     virtual void set_global_nodes(const int *, int, int) = 0;
     virtual int device_ordinal() const = 0;
     virtual int join_local_group(struct LocalGroup *, int) = 0;
+    virtual int guard_check(long *) = 0;
+    virtual int memory_info(size_t *) = 0;
+    virtual int reserve_iterations(int) = 0;
+    virtual int profile_read_collective(double *, long *) = 0;
+    virtual int inject_allocation(size_t) = 0;
+    virtual int guard_poke(int) = 0;
 };
 
 // ---- in-process stand-in for the communicator (rn_debug_local_group_*): `n` contexts of one process, one host thread each ----
@@ -317,6 +327,7 @@ struct Ctx : CtxBase {
     IterState *d_state = nullptr;
     Partial *d_partials = nullptr, *d_partials2 = nullptr;   // main pass / fix-up pass
     double *d_lam = nullptr, *d_hist = nullptr, *d_histParts = nullptr, *d_dist2 = nullptr;
+    double *d_histGlob = nullptr;   // sharded: payload of the per-batch MAX all-reduce (verdict + the batch's history entries)
     int lamCap = 0, histCap = 0;
     int h_it = 0;
     double theta0 = 1, theta1 = 1;
@@ -333,8 +344,8 @@ struct Ctx : CtxBase {
     struct EvPair { int cls; hipEvent_t a, b; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> freeEvents;
-    double prof_ms[4] = {0, 0, 0, 0};
-    long prof_n[4] = {0, 0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0};   // classes 0-3 as in rn_profile_read; 4 = the collectives (rn_profile_read_collective)
+    long prof_n[5] = {0, 0, 0, 0, 0};
     // multi-GPU
     void *comm = nullptr;
     int rank = 0, nranks = 1, cutStage = -1;
@@ -347,19 +358,28 @@ struct Ctx : CtxBase {
     // sum all-reduce, in place, on the solver's stream: the library's RCCL communicator, or the installed stand-in
     int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */) {
         if (arHook) {
+            hipEvent_t ev = prof_begin(4);
             const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, op, (void *)stream);
+            prof_end(ev);
             RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + ": the installed all-reduce callback failed (" + std::to_string(rc) + ")");
             return RN_OK;
         }
         RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
+        hipEvent_t ev = prof_begin(4);
         const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
+        prof_end(ev);
         RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
     }
 
     ~Ctx() override {
+        g_liveContexts--;
         if (comm && g_nccl.CommDestroy) g_nccl.CommDestroy(comm);
         (void)hipSetDevice(device);
+        if (guardMode && stream) {   // guard mode: a context never goes away with an overwritten red zone unnoticed
+            long bad = 0;
+            if (guard_check(&bad) == RN_OK) { g_guardContexts++; g_guardBadBytes += bad; if (bad) fprintf(stderr, "librapidnet_hip: %s\n", err.c_str()); }
+        }
         if (localMember) { if (localMember->recv) (void)hipFree(localMember->recv); delete localMember; }
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -368,11 +388,75 @@ struct Ctx : CtxBase {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
+    // ---- device allocations ---------------------------------------------------------------------------------
+    // Every buffer of the context comes from here.  RAPIDNET_GUARD=1 (read when the context is created) is the library's
+    // stand-in for a GPU address sanitizer, which this pool does not offer: every buffer gets a red zone of GUARD_BYTES on both
+    // sides, and red zones AND payload of floating-point buffers start out as 0xFF bytes -- a NaN in fp64 and in fp32 -- so a
+    // kernel that reads outside its buffer, or reads what nobody has written, carries a NaN into the iterates (the parity
+    // tests then fail); integer tables get zero red zones (an index read from one stays in range).  A kernel that WRITES
+    // outside its buffer changes a red zone: rn_guard_check / rn_destroy compare them with the pattern.
+    static constexpr size_t GUARD_BYTES = 128 * 1024;
+    struct GuardRec { void *base; size_t bytes; unsigned char pat; };
+    std::vector<GuardRec> guards;
+    bool guardMode = false;
+    size_t allocatedBytes = 0;   // payload bytes of all live allocations of this context (rn_device_memory_info)
     template <typename U> int dalloc(U **p, size_t n) {
         void *q = nullptr;
-        RN_HIP(hipMalloc(&q, (n ? n : 1) * sizeof(U)));
+        const size_t bytes = (n ? n : 1) * sizeof(U);
+        if (!guardMode) {
+            RN_HIP(hipMalloc(&q, bytes));
+            allocs.push_back(q);
+            allocatedBytes += bytes;
+            *p = (U *)q;
+            return RN_OK;
+        }
+        const size_t padded = (bytes + 255) / 256 * 256;
+        RN_HIP(hipMalloc(&q, padded + 2 * GUARD_BYTES));
         allocs.push_back(q);
-        *p = (U *)q;
+        allocatedBytes += bytes;
+        const unsigned char pat = std::is_floating_point<U>::value || std::is_class<U>::value ? 0xFF : 0x00;
+        RN_HIP(hipMemset(q, pat, padded + 2 * GUARD_BYTES));
+        guards.push_back(GuardRec{q, bytes, pat});
+        *p = (U *)((char *)q + GUARD_BYTES);
+        return RN_OK;
+    }
+    // number of red-zone bytes that no longer hold their pattern (0 outside guard mode)
+    int guard_check(long *bad) override {
+        RN_CHECK(bad, RN_E_ARG, "rn_guard_check: null output");
+        *bad = 0;
+        if (!guardMode) return RN_OK;
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned char> h(GUARD_BYTES + 256);
+        for (const GuardRec &g : guards) {
+            const size_t padded = (g.bytes + 255) / 256 * 256;
+            RN_HIP(hipMemcpy(h.data(), g.base, GUARD_BYTES, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < GUARD_BYTES; i++) if (h[i] != g.pat) (*bad)++;
+            // the back red zone starts right behind the payload (the round-up to 256 bytes belongs to it)
+            const size_t back = GUARD_BYTES + (padded - g.bytes);
+            RN_HIP(hipMemcpy(h.data(), (char *)g.base + GUARD_BYTES + g.bytes, back, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < back; i++) if (h[i] != g.pat) (*bad)++;
+        }
+        if (*bad) err = "rn_guard_check: " + std::to_string(*bad) + " red-zone bytes were overwritten (a kernel wrote outside its buffer)";
+        return RN_OK;
+    }
+    // test of the detector: `n` bytes right behind the payload of the context's first buffer are overwritten
+    int guard_poke(int n) override {
+        RN_CHECK(guardMode && !guards.empty(), RN_E_STATE, "rn_debug_guard_poke: the context was not created under RAPIDNET_GUARD=1");
+        RN_CHECK(n >= 1 && n <= 256, RN_E_ARG, "rn_debug_guard_poke: 1 .. 256 bytes");
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipStreamSynchronize(stream));
+        RN_HIP(hipMemset((char *)guards[0].base + GUARD_BYTES + guards[0].bytes, 0xA5, (size_t)n));
+        return RN_OK;
+    }
+    // free / total bytes of the device and the bytes this context holds: what cudaMemGetInfo reports in the reference's leak check
+    // (SmpcController.cu:1612, :1619) plus a figure that other contexts on the same device cannot disturb
+    int memory_info(size_t *out) override {
+        RN_CHECK(out, RN_E_ARG, "rn_device_memory_info: null output");
+        RN_HIP(hipSetDevice(device));
+        size_t fr = 0, tot = 0;
+        RN_HIP(hipMemGetInfo(&fr, &tot));
+        out[0] = fr; out[1] = tot; out[2] = allocatedBytes; out[3] = (size_t)g_liveContexts.load();
         return RN_OK;
     }
     int upload(T *dst, const double *src, size_t n) {
@@ -427,6 +511,8 @@ struct Ctx : CtxBase {
     // ---- construction --------------------------------------------------------------------------------
     int init(const rn_dims *dims, const rn_tree *tr, int dev) {
         d = *dims; device = dev;
+        g_liveContexts++;
+        { const char *e = std::getenv("RAPIDNET_GUARD"); guardMode = e && std::atoi(e) != 0; }
         RN_CHECK(d.nx > 0 && d.nu > 0 && d.nv > 0 && d.nd > 0 && d.N > 0 && d.K > 0 && d.nodes > 0, RN_E_ARG, "rn_create: non-positive dimension");
         RN_CHECK(d.nv <= d.nu, RN_E_ARG, "rn_create: nv must not exceed nu");
         ny = 2 * d.nx + d.nu;
@@ -633,7 +719,7 @@ struct Ctx : CtxBase {
         a.momE = (cutStage > 0 && moments_set) ? d_momE : nullptr; a.momP = d_momP; a.cutStage = cutStage;
         const size_t sh1 = (size_t)(((d.nd + 3) & ~3) + ((std::max(d.nx, d.nu) + 3) & ~3) + AFF_THREADS) * sizeof(T);
         const size_t sh2 = (size_t)(2 * ((d.nu + 3) & ~3) + ((std::max(d.nv, d.nu) + 3) & ~3) + ((d.nv + 3) & ~3) + ((d.nd + 3) & ~3) + AFF_THREADS) * sizeof(T);
-        const hipEvent_t *e0 = prof_begin(3);
+        hipEvent_t e0 = prof_begin(3);
         hipLaunchKernelGGL(k_affine_demand<T>, dim3(d.nodes), dim3(AFF_THREADS), sh1, stream, a);
         hipLaunchKernelGGL(k_affine_beta<T>, dim3(d.nodes), dim3(AFF_THREADS), sh2, stream, a);
         prof_end(e0);
@@ -652,14 +738,18 @@ struct Ctx : CtxBase {
         if (!freeEvents.empty()) { hipEvent_t e = freeEvents.back(); freeEvents.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
-    const hipEvent_t *prof_begin(int cls) {
+    // returns the closing event of the interval (a handle: intervals nest -- the collectives sit inside class 1 -- and `pending`
+    // may grow in between), nullptr while profiling is off
+    int profOpen = 0;
+    hipEvent_t prof_begin(int cls) {
         if (!prof) return nullptr;
-        if (pending.size() >= 60000) (void)prof_flush();
+        if (pending.size() >= 60000 && profOpen == 0) (void)prof_flush();
         pending.push_back(EvPair{cls, get_event(), get_event()});
         (void)hipEventRecord(pending.back().a, stream);
-        return &pending.back().b;
+        profOpen++;
+        return pending.back().b;
     }
-    void prof_end(const hipEvent_t *e) { if (e) (void)hipEventRecord(*e, stream); }
+    void prof_end(hipEvent_t e) { if (e) { (void)hipEventRecord(e, stream); profOpen--; } }
     int prof_flush() {
         if (pending.empty()) return RN_OK;
         RN_HIP(hipStreamSynchronize(stream));
@@ -669,13 +759,23 @@ struct Ctx : CtxBase {
             freeEvents.push_back(p.a); freeEvents.push_back(p.b);
         }
         pending.clear();
+        profOpen = 0;
         return RN_OK;
     }
     int profile_enable(int on) override { if (!on) { int rc = prof_flush(); prof = 0; return rc; } prof = on; return RN_OK; }
-    int profile_reset() override { int rc = prof_flush(); for (int i = 0; i < 4; i++) { prof_ms[i] = 0; prof_n[i] = 0; } return rc; }
+    int profile_reset() override { int rc = prof_flush(); for (int i = 0; i < 5; i++) { prof_ms[i] = 0; prof_n[i] = 0; } return rc; }
     int profile_read(double *ms, long *n) override {
         int rc = prof_flush();
         for (int i = 0; i < 4; i++) { ms[i] = prof_ms[i]; n[i] = prof_n[i]; }
+        return rc;
+    }
+    // time between hipEvents recorded on the solver's stream around every all-reduce (RCCL or the installed stand-in) while
+    // profiling is on: from the end of the kernel in front of the collective to the end of the collective, i.e. wire latency
+    // AND the wait for the slowest peer.  The launches of class 1 (recursion + shared products) contain these intervals.
+    int profile_read_collective(double *ms, long *n) override {
+        RN_CHECK(ms && n, RN_E_ARG, "rn_profile_read_collective: null output");
+        int rc = prof_flush();
+        *ms = prof_ms[4]; *n = prof_n[4];
         return rc;
     }
     int algorithmic_bytes(double *bwd, double *dual) const override {
@@ -912,7 +1012,7 @@ struct Ctx : CtxBase {
             hipLaunchKernelGGL(k_bw0<T>, dim3(1), dim3(128), 0, stream, d_B, nx, nu, d_prevU, d_prevUhat, d_bw0);
             aux_dirty = false;
         }
-        const hipEvent_t *e0 = nullptr, *e1 = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         if (phase != 2) {
             e0 = prof_begin(0);
             if (structured) {
@@ -1082,6 +1182,7 @@ struct Ctx : CtxBase {
             if (int rc = dalloc(&nl, cap)) return rc;
             if (int rc = dalloc(&nh, cap)) return rc;
             if (int rc = dalloc(&np, (size_t)4 * cap)) return rc;
+            if (int rc = dalloc(&d_histGlob, (size_t)4 * cap + 1)) return rc;
             RN_HIP(hipStreamSynchronize(stream));
             if (d_hist && histCap) {
                 RN_HIP(hipMemcpy(nh, d_hist, histCap * sizeof(double), hipMemcpyDeviceToDevice));
@@ -1105,6 +1206,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
+        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
         return ensure_tables(0);
     }
@@ -1147,9 +1249,9 @@ struct Ctx : CtxBase {
             // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
             // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
             lazyIn = lazy && k > 0;
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; carryTail = false; pendingFin = false; return rc; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; carryTail = false; pendingFin = false; return fail_batch(rc); }
             DualArgs<T> a = dual_args();
-            const hipEvent_t *e2 = prof_begin(2);
+            hipEvent_t e2 = prof_begin(2);
             const bool storesW = !lazy || k == n - 1;
             launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
             prof_end(e2);
@@ -1157,7 +1259,7 @@ struct Ctx : CtxBase {
             // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
             // batch gets a launch of its own
             if (k == n - 1) {
-                const hipEvent_t *e3 = prof_begin(3);
+                hipEvent_t e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, d_cut + tail,
                                    d_hist, d_histParts, histCap, -1.0, -1.0);
                 prof_end(e3);
@@ -1168,18 +1270,19 @@ struct Ctx : CtxBase {
         }
         carryTail = false;
         if (n > 0) {   // the last iteration's distances: one 2-element all-reduce per BATCH
-            if (int rc = all_reduce(d_cut + tail, 2, sizeof(T) == 8, "ncclAllReduce(dist tail)")) return rc;
-            // the ranks agree on the verdict (sum of the per-rank flags): one more 1-element all-reduce per BATCH
-            hipLaunchKernelGGL(k_check_dist<T>, dim3(1), dim3(1), 0, stream, d_cut + tail, d_state, penX / stepSize, penXs / stepSize, d_cut + tail);
-            if (int rc = all_reduce(d_cut + tail, 1, sizeof(T) == 8, "ncclAllReduce(verdict)")) return rc;
+            if (int rc = all_reduce(d_cut + tail, 2, sizeof(T) == 8, "ncclAllReduce(dist tail)")) return fail_batch(rc);
+            // one more all-reduce per BATCH (MAX): the ranks agree on the verdict (every rank takes the same replay decision even if
+            // an all-reduce algorithm ever delivered sums that differ in the last bit between ranks) and the batch's history
+            // entries become tree-global (vecPrimalInfs, SmpcController.cu:1521)
+            if (int rc = globalize_history(first, n, d_cut + tail)) return fail_batch(rc);
         }
         RN_HIP(hipGetLastError());
         int violated = 0;
         if (n > 0) {
-            T votes = 0;
-            RN_HIP(hipMemcpyAsync(&votes, d_cut + tail, sizeof(T), hipMemcpyDeviceToHost, stream));
+            double votes = 0;
+            RN_HIP(hipMemcpyAsync(&votes, d_histGlob, sizeof(double), hipMemcpyDeviceToHost, stream));
             RN_HIP(hipStreamSynchronize(stream));
-            violated = votes > (T)0 ? 1 : 0;
+            violated = votes > 0 ? 1 : 0;
         } else RN_HIP(hipStreamSynchronize(stream));
         if (violated) {   // replay the batch exactly
             fallbacks++;
@@ -1224,15 +1327,15 @@ struct Ctx : CtxBase {
             // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
             // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
             lazyIn = lazy && k > 0;
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; pendingFin = false; return rc; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; pendingFin = false; return fail_batch(rc); }
             DualArgs<T> a = dual_args();
-            const hipEvent_t *e2 = prof_begin(2);
+            hipEvent_t e2 = prof_begin(2);
             const bool storesW = !lazy || k == n - 1;
             launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
             prof_end(e2);
             lazyIn = false;
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
-                const hipEvent_t *e3 = prof_begin(3);
+                hipEvent_t e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, (T *)nullptr,
                                    d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize);
                 prof_end(e3);
@@ -1263,6 +1366,18 @@ struct Ctx : CtxBase {
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
+    // SmpcController::allocateApgAlgorithm sizes its per-iteration storage by maxIterations once (SmpcController.cu:124-151):
+    // the iteration tables (lambda_k, vecPrimalInfs and its parts) and the optimistic paths' checkpoint buffers for `n` iterations
+    // are allocated here, so that no control step allocates device memory (the reference's leak check, :1612-1623, would flag it)
+    size_t injectBytes = 0;
+    int inject_allocation(size_t bytes) override { injectBytes = bytes; return RN_OK; }
+    int reserve_iterations(int n) override {
+        RN_CHECK(n >= 0, RN_E_ARG, "rn_reserve_iterations: negative iteration count");
+        RN_HIP(hipSetDevice(device));
+        for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
+        if (n + 2 > lamCap) return ensure_tables(n);
+        return RN_OK;
+    }
     int set_exchange_mode(int mode) override {
         RN_CHECK(mode >= 0 && mode <= 2, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic, 2 optimistic without the stored accelerated dual");
         optimistic = mode; optHold = 0;
@@ -1271,6 +1386,7 @@ struct Ctx : CtxBase {
     int apg_iterate(int n, double *primalInfs) override {
         RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_apg_iterate before the factor step / affine terms");
         RN_CHECK(n >= 0, RN_E_ARG, "rn_apg_iterate: negative iteration count");
+        RN_CHECK(!poisoned, RN_E_STATE, "rn_apg_iterate: an earlier batch failed half-way; call rn_apg_reset first");
         RN_HIP(hipSetDevice(device));
         // optimistic batches (prox as a pure projection, verified afterwards); after a replay the next RN_OPT_BACKOFF batches
         // go straight through the exact path (every rank sees the same verdicts, so sharded ranks stay in step)
@@ -1289,16 +1405,16 @@ struct Ctx : CtxBase {
                 acc_ready = true;
             }
             const bool last = (k == n - 1);
-            if (int rc = launch_sweep(0, nullptr, last)) return rc;
+            if (int rc = launch_sweep(0, nullptr, last)) return fail_batch(rc);
             DualArgs<T> a = dual_args();
-            const hipEvent_t *e2 = prof_begin(2);
+            hipEvent_t e2 = prof_begin(2);
             const bool exactSharded = has_comm() && cutStage > 0;   // its fix-up pass and k_finalize fold eltBlocks partials: flat kernel
             launch_dual_main(a, last, exactSharded);
             prof_end(e2);
-            const hipEvent_t *e3 = prof_begin(3);
+            hipEvent_t e3 = prof_begin(3);
             if (exactSharded) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
                 hipLaunchKernelGGL(k_reduce_dist, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
-                if (int rc = all_reduce(d_dist2, 2, true, "ncclAllReduce(dist)")) return rc;
+                if (int rc = all_reduce(d_dist2, 2, true, "ncclAllReduce(dist)")) return fail_batch(rc);
                 hipLaunchKernelGGL(k_decide_from, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
@@ -1318,11 +1434,34 @@ struct Ctx : CtxBase {
             h_it++;
         }
         RN_HIP(hipGetLastError());
+        // sharded: the batch's history entries become tree-global (one MAX all-reduce per batch)
+        if (has_comm() && cutStage > 0 && n > 0) { if (int rc = globalize_history(first, n, nullptr)) return fail_batch(rc); }
         if (primalInfs && n > 0) {
             RN_HIP(hipStreamSynchronize(stream));
             RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         }
         return RN_OK;
+    }
+    // Sharded contexts, once per batch: vecPrimalInfs[first .. first + n) of this rank (arg-max over its own nodes) -> the
+    // tree-global values, on every rank (SmpcController.cu:1480-1496, :1521); element 0 of the payload carries the ranks'
+    // verdict on the optimistic batch (tail = the all-reduced dist^2 of its last iteration; nullptr: no verdict).
+    int globalize_history(int first, int n, T *tail) {
+        hipLaunchKernelGGL(k_batch_close_pack<T>, dim3(1), dim3(ELT_THREADS), 0, stream, (const T *)tail, d_state, penX / stepSize, penXs / stepSize,
+                           (const double *)d_histParts, first, n, d_histGlob);
+        if (int rc = all_reduce(d_histGlob, (size_t)4 * n + 1, true, "ncclAllReduce(verdict + primal infeasibilities)", 2 /* ncclMax */)) return rc;
+        hipLaunchKernelGGL(k_batch_close_unpack, dim3(1), dim3(ELT_THREADS), 0, stream, (const double *)d_histGlob, d_hist, first, n);
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
+    // A batch that fails half-way (a launch or a collective returned an error after some of its iterations were enqueued) leaves
+    // the rotating iterate buffers, the device-side iteration counter and the host's view of them out of step: the context
+    // refuses further iterations until rn_apg_reset / rn_fbe_reset (or rn_control_action, which resets) instead of continuing
+    // from an inconsistent accelerated dual.
+    bool poisoned = false;
+    int fail_batch(int rc) {
+        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false;
+        err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
+        return rc;
     }
     // which kernels a batch of this context launches (bench.py names them in its JSON line instead of assuming)
     int kernel_info(int *out) override {
@@ -1353,9 +1492,14 @@ struct Ctx : CtxBase {
     int control_action(const double *x0, const double *up, const double *dp, const double *dhat, const double *ahat, int maxIt,
                        int project, double *u0) override {
         RN_CHECK(u0, RN_E_ARG, "rn_control_action: null output");
+        if (injectBytes) {   // rn_debug_inject_allocation: a deliberate leak inside this control step (test of the callers' leak check)
+            char *leak = nullptr;
+            if (int rc = dalloc(&leak, injectBytes)) return rc;
+            injectBytes = 0;
+        }
         if (int rc = update_state_control(x0, up, dp)) return rc;
         if (int rc = eliminate(dhat, ahat)) return rc;
-        if (warmStart && h_it > 0) { if (int rc = apg_restart_keep_duals()) return rc; }   // y, y+ kept; theta = {1,1}
+        if (warmStart && h_it > 0 && !poisoned) { if (int rc = apg_restart_keep_duals()) return rc; }   // y, y+ kept; theta = {1,1}
         else if (int rc = apg_reset()) return rc;
         if (int rc = apg_iterate(maxIt, nullptr)) return rc;
         T *src = d_u;
@@ -1930,6 +2074,13 @@ int rn_debug_local_group_create(int nranks, void **group) {
 }
 int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank) { RN_GUARD(ctx); return ctx->impl->join_local_group(static_cast<rn::LocalGroup *>(group), rank); }
 int rn_debug_local_group_destroy(void *group) { if (!group) return RN_E_ARG; delete static_cast<rn::LocalGroup *>(group); return RN_OK; }
+int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes) { RN_GUARD(ctx); return ctx->impl->inject_allocation(bytes); }
+int rn_debug_guard_poke(rn_ctx *ctx, int nbytes) { RN_GUARD(ctx); return ctx->impl->guard_poke(nbytes); }
+int rn_guard_report(long out[2]) { if (!out) return RN_E_ARG; out[0] = rn::g_guardContexts.load(); out[1] = rn::g_guardBadBytes.load(); return RN_OK; }
+int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
+int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
+int rn_reserve_iterations(rn_ctx *ctx, int maxIterations) { RN_GUARD(ctx); return ctx->impl->reserve_iterations(maxIterations); }
+int rn_profile_read_collective(rn_ctx *ctx, double *ms, long *launches) { RN_GUARD(ctx); return ctx->impl->profile_read_collective(ms, launches); }
 
 }  // extern "C"
 

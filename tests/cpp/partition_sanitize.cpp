@@ -110,6 +110,35 @@ int main() {
                     for (int g = 0; g < T.d.nodes; g++) CHECK(seen[g] == (T.stages[g] >= (cut <= 0 ? rn::default_cut_stage(&T.d, &T.t) : cut) ? 1 : 0));
             }
     }
-    std::printf("partitions built %ld, refused %ld\n", parts, refused);
-    return parts > 1000 ? 0 : 3;
+    // malformed trees through the public entry point: every one must be refused with a message, none may be indexed through
+    // (the sanitizers watch): ancestors beyond the tree, forward-pointing, in the wrong stage, negative; stages out of order;
+    // an empty stage; a second root
+    long malformed = 0;
+    for (int trial = 0; trial < 200; trial++) {
+        const int N = 3 + rng() % 4;
+        Tree T = make_tree(rng, N, 3, trial % 2 == 1, 2, 3);
+        if (T.d.nodes < 4) continue;
+        const int victim = 1 + (int)(rng() % (T.d.nodes - 1)), kind = trial % 8;
+        const int k = T.stages[victim];
+        switch (kind) {
+            case 0: T.anc[victim] = T.d.nodes + 1 + (int)(rng() % 1000); break;          // beyond the tree
+            case 1: T.anc[victim] = victim + 1; break;                                   // itself
+            case 2: T.anc[victim] = T.d.nodes; break;                                    // forward-pointing (last node)
+            case 3: T.anc[victim] = -5; break;                                           // negative
+            case 4: T.anc[victim] = 0; break;                                            // a second root
+            case 5: T.stages[victim] = k + 1; break;                                     // not numbered stage by stage
+            case 6: T.cum[k + 1] = T.cum[k]; break;                                      // an empty stage
+            default: if (k >= 2) T.anc[victim] = T.cum[k - 2] + 1; else T.anc[victim] = T.d.nodes + 7; break;   // two stages up
+        }
+        for (int cut = 0; cut < N; cut++)
+            for (int W : {1, 2, 3}) {
+                rn_partition P;
+                std::string err;
+                const int rc = rn::build_partition(&T.d, &T.t, T.errD.data(), T.errP.data(), W - 1, W, cut, &P, err);
+                CHECK(rc == RN_E_ARG && !err.empty());
+                malformed++;
+            }
+    }
+    std::printf("partitions built %ld, refused %ld, malformed trees refused %ld\n", parts, refused, malformed);
+    return parts > 1000 && malformed > 1000 ? 0 : 3;
 }

@@ -313,6 +313,22 @@ static void testClosedLoop(const string &dir) {
     }
     CHECK(ctl.controlAction(u.data()) == 1);
     for (real_t v : u) CHECK(std::isfinite(v));
+    // the reference's leak check (SmpcController.cu:1612-1623): a control step that leaves device memory behind returns 0 (and
+    // prints the reference's message); the clean steps before and after it return 1
+    {
+        size_t m0[4], m1[4];
+        CHECK(rn_device_memory_info(ctl.getEngine()->getContext(), m0) == RN_OK && m0[1] > 0 && m0[2] > 0 && m0[3] == 1);
+        CHECK(rn_debug_inject_allocation(ctl.getEngine()->getContext(), (size_t)8 << 20) == RN_OK);
+        CHECK(ctl.controlAction(u.data()) == 0);
+        CHECK(rn_device_memory_info(ctl.getEngine()->getContext(), m1) == RN_OK && m1[2] == m0[2] + ((size_t)8 << 20));
+        CHECK(ctl.controlAction(u.data()) == 1);
+        CHECK(rn_debug_inject_allocation(ctl.getEngine()->getContext(), (size_t)8 << 20) == RN_OK);
+        std::fstream out2((dir + "/controlOutput2.tmp").c_str(), std::fstream::out);
+        CHECK(ctl.controlAction(out2) == 0);
+        CHECK(ctl.controlAction(out2) == 1);
+        out2.close();
+        std::remove((dir + "/controlOutput2.tmp").c_str());
+    }
     // KPIs of the two simulated steps (main.cu:66-69)
     const real_t eco = ctl.getEconomicKpi(2), smooth = ctl.getSmoothKpi(2), safe = ctl.getSafetyKpi(2), net = ctl.getNetworkKpi(2);
     CHECK(std::isfinite(eco) && eco > 0);
@@ -477,6 +493,7 @@ public:
     ShardedController(const string &cfg, int rank, int world) : SmpcController(cfg, rank, world, nullptr) {}
     explicit ShardedController(const string &cfg) : SmpcController(cfg) {}
     using SmpcController::getVector;
+    using SmpcController::algorithmApg;
 };
 static void testSharded(const string &dir, int world) {
     const string cfgPath = dir + "/controllerConfig.json";
@@ -486,6 +503,11 @@ static void testSharded(const string &dir, int world) {
     const uint_t nx = ref.getSmpcConfiguration()->getNX(), nu = ref.getSmpcConfiguration()->getNU();
     const uint_t nodes = ref.getScenarioTree()->getNumNodes();
     std::vector<real_t> uRef(nu);
+    // SmpcController::algorithmApg records the tree-global vecPrimalInfs (SmpcController.cu:1521): a sharded controller's must be
+    // the unsharded controller's on every rank
+    const uint_t maxIt = ref.getSmpcConfiguration()->getMaxIterations();
+    CHECK(ref.algorithmApg() == 1);
+    const std::vector<real_t> infRef(ref.getPrimalInfeasibility(), ref.getPrimalInfeasibility() + maxIt);
     CHECK(ref.controlAction(uRef.data()) == 1);
     void *group = nullptr;
     CHECK(rn_debug_local_group_create(world, &group) == RN_OK);
@@ -503,11 +525,20 @@ static void testSharded(const string &dir, int world) {
             try {
                 rk[r]->getForecaster()->predictDemand(0); rk[r]->getForecaster()->predictPrices(0);
                 rk[r]->initialiseSmpcController();
-                ok[r] = (int)rk[r]->controlAction(u0[r].data());
+                ok[r] = (int)rk[r]->algorithmApg();
+                ok[r] = ok[r] && (int)rk[r]->controlAction(u0[r].data());
             } catch (const std::exception &e) { std::cerr << "rank " << r << ": " << e.what() << "\n"; ok[r] = 0; }
         });
     for (auto &t : th) t.join();
     for (int r = 0; r < world; r++) CHECK(ok[r] == 1);
+    {
+        real_t scale = 0;
+        for (real_t v : infRef) scale = std::max(scale, std::fabs(v));
+        for (int r = 0; r < world; r++) {
+            CHECK(closeAbs(rk[r]->getPrimalInfeasibility(), infRef.data(), maxIt, 1e-9 * scale, "vecPrimalInfs (tree-global on every rank)"));
+            CHECK(std::memcmp(rk[r]->getPrimalInfeasibility(), rk[0]->getPrimalInfeasibility(), maxIt * sizeof(real_t)) == 0);
+        }
+    }
     // the root's control is replicated: identical bits on every rank, and the unsharded controller's value
     real_t un = 0;
     for (uint_t i = 0; i < nu; i++) un = std::max(un, std::fabs(uRef[i]));
@@ -580,8 +611,8 @@ static void testSharded(const string &dir, int world) {
     for (uint_t i = 0; i < nodes; i++) CHECK(owners[i] == (i < crown ? world : 1));   // crown replicated, every other node owned once
     long cnt[4];
     CHECK(rn_get_counters(rk[0]->getEngine()->getContext(), cnt) == RN_OK);
-    // (three control steps were run: three optimistic batches, or -- once a threshold has tripped -- one replayed batch and the
-    //  back-off's exact batches after it)
+    // (one algorithmApg and three control steps were run: four optimistic batches, or -- once a threshold has tripped -- one
+    //  replayed batch and the back-off's exact batches after it)
     std::cout << "sharded: " << world << " ranks, cut stage " << info[2] << ", " << info[3] << " cut parents, crown " << crown << " nodes, batches optimistic/exact/replayed "
               << cnt[0] << "/" << cnt[1] << "/" << cnt[2] << "\n";
     for (int r = 0; r < world; r++) {

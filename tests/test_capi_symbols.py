@@ -36,3 +36,37 @@ def test_create_fails_loudly_without_gpu_or_with_bad_input():
     if not torch.cuda.is_available():
         with pytest.raises(capi.RapidNetError):
             capi.Solver(p["network"], p["tree"], p["config"])
+
+
+def test_build_failed_marker_of_other_sources_is_ignored(monkeypatch):
+    """Ranks other than local rank 0 wait for its build and abort at once when it leaves a failure marker -- but only a marker
+    written for the sources they are waiting for: one an earlier run left behind (other sources) must not fail the launch."""
+    import pytest
+
+    from rapidnet_amd import build
+
+    capi.load()
+    marker = build.LIB_HIP + ".buildfailed"
+    calls = [0]
+
+    def stale_twice():
+        calls[0] += 1
+        return calls[0] < 3
+
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(build, "hip_is_stale", stale_twice)
+    try:
+        open(marker, "w").write("0" * 64 + "\nan error of an earlier run")
+        monkeypatch.setattr(capi, "_LIB", None)
+        assert capi.load() is not None and calls[0] == 3          # waited through the stale marker
+        calls[0] = 0
+        open(marker, "w").write(build.hip_fingerprint() + "\nhipcc: error: boom")
+        monkeypatch.setattr(capi, "_LIB", None)
+        with pytest.raises(RuntimeError, match="boom"):
+            capi.load()
+    finally:
+        if os.path.exists(marker):
+            os.remove(marker)
+        monkeypatch.setattr(capi, "_LIB", None)
+    monkeypatch.undo()
+    capi.load()

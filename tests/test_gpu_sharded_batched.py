@@ -89,17 +89,22 @@ def test_batched_sharded_solve_matches_oracle(name, world, cut, structured, kw, 
         def solve(s):
             s.initialiseSmpcController(dh, ah)
             s.apgReset()
-            s.apgIterate(20, history=False)         # two batches: checkpoint, tails and theta carry over
-            s.apgIterate(4, history=False)
-            return s.counters()
+            h1 = s.apgIterate(20)                   # two batches: checkpoint, tails and theta carry over
+            h2 = s.apgIterate(4)
+            return s.counters(), np.concatenate([h1, h2])
 
-        counters = rk.run(solve)
+        res = rk.run(solve)
+        counters = [r[0] for r in res]
         assert all(c == counters[0] for c in counters), counters          # the ranks took the same path through every batch
         assert (counters[0]["replayed"] >= 1) == trips, counters
+        # vecPrimalInfs (SmpcController.cu:1480-1496, :1521) is tree-global on EVERY rank: one MAX all-reduce per batch
+        for _, hist in res:
+            assert np.array_equal(hist, res[0][1])
+            assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
         d = dims_of(rk.shards[0])
         for bid, nm, dm in VECS:
             assert relmax(rk.gathered(bid, d[dm]), o.get(nm)) < REL_TOL, nm
-        # tree-global primal infeasibility from the ranks' arg-max parts (rn_get_history_parts)
+        # ... and the same values follow from the ranks' arg-max parts (rn_get_history_parts stays rank-local)
         parts = np.stack([s.historyParts(0, 24) for s in rk.shards])      # [rank, it, (absXi, valXi, absPsi, valPsi)]
         ix, ip = parts[:, :, 0].argmax(0), parts[:, :, 2].argmax(0)
         vx, vp = parts[ix, np.arange(24), 1], parts[ip, np.arange(24), 3]

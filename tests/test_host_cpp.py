@@ -77,5 +77,5 @@ def test_sharded_controllers_cpp(tmp_path, name, world, kw, replayed):
     synth.write_problem(synth.make_problem(name, max_iterations=40, **kw), str(tmp_path))
     out = _run("sharded", str(tmp_path), world)
     assert "sharded: %d ranks" % world in out and "all checks passed" in out
-    # three control steps: all optimistic, or one replayed batch followed by the back-off's exact batches
-    assert ("optimistic/exact/replayed %s" % ("1/2/1" if replayed else "3/0/0")) in out, out
+    # one algorithmApg + three control steps: all optimistic, or one replayed batch followed by the back-off's exact batches
+    assert ("optimistic/exact/replayed %s" % ("1/3/1" if replayed else "4/0/0")) in out, out
