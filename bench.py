@@ -171,6 +171,45 @@ def spawn_ranks(args):
     return rc if rc != 0 else 1
 
 
+class AgreedFailure(RuntimeError):
+    """N > 1: a set-up step failed on some rank and ALL ranks know (they raise this together, so a caller may catch it on every
+    rank and go on -- used for the secondary configs; for the headline the job ends instead)."""
+
+
+class Watchdog:
+    """N > 1 only: a rank that makes no progress for `limit` seconds (a peer died inside a collective, ncclCommInitRank never
+    returned ...) prints what it was doing and leaves with a non-zero code, so that the launcher tears the job down instead of
+    the run hanging until somebody's lease ends.  beat(what) is called at every phase boundary; the library calls in between
+    release the GIL, so this thread keeps running while the main thread is stuck in one."""
+
+    def __init__(self, rank, limit):
+        import threading
+
+        self.rank, self.limit, self.what, self.t = rank, limit, "start", time.time()
+        self.stop = threading.Event()
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, what, limit=None):
+        self.what, self.t = what, time.time()
+        if limit is not None:
+            self.limit = limit
+
+    def _run(self):
+        while not self.stop.wait(1.0):
+            if time.time() - self.t > self.limit:
+                print("bench.py rank %d: no progress for %.0f s in phase '%s' -- giving up (exit code 4)" % (self.rank, self.limit, self.what), file=sys.stderr, flush=True)
+                os._exit(4)
+
+
+def _fault(point, rank):
+    """Test hook ($RAPIDNET_BENCH_FAULT = '<point>:<rank>'): the named rank leaves abruptly at the named point, as a rank whose
+    GPU or library call failed would (tests/test_gpu_bench_contract.py checks that its peers exit within seconds)."""
+    spec = os.environ.get("RAPIDNET_BENCH_FAULT", "")
+    if spec and spec.split(":")[0] == point and int(spec.split(":")[1]) == rank:
+        print("bench.py rank %d: injected fault at '%s'" % (rank, point), file=sys.stderr, flush=True)
+        os._exit(17)
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -281,9 +320,26 @@ def main():
         if "MASTER_ADDR" not in os.environ:   # --force-shard without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: loopback (the box's hostname may not resolve)
-        dist.init_process_group("gloo", init_method="env://")
+        import datetime
+
+        # (a peer that dies closes its sockets: gloo raises in the survivors at once; the long timeout only covers ranks that wait
+        #  at the final barrier while rank 0 times the CPU baseline)
+        dist.init_process_group("gloo", init_method="env://", timeout=datetime.timedelta(seconds=1800))
     else:
         device, oversubscribed = local_rank, False
+    wd = Watchdog(rank, 600.0) if world > 1 else None
+
+    def beat(what, limit=None):
+        if wd is not None:
+            wd.beat(what, limit)
+
+    def die(msg):
+        """N > 1: leave at once with a non-zero code and without finalisers (a context whose peers are gone must not be torn down
+        collectively) -- every rank reaches this through the same agreed verdict, or the launcher ends the others"""
+        print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(1)
+
     from rapidnet_amd import capi, synth
 
     precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
@@ -300,8 +356,8 @@ def main():
         if world == 1:
             debug_part = capi.partition_tree(problem["tree"], 0, max(args.emulate_world, 1), cut_stage)
             tree = debug_part["tree"]
-    uid, uid_error = None, ""
-    if sharded:
+    def fresh_uid():
+        """(ncclUniqueId, error): rank 0's, over gloo.  Every context creates a communicator of its own, so every run_mode asks again."""
         box = [None, ""]
         if rank == 0 and args.exchange == "rccl":
             try:
@@ -309,7 +365,20 @@ def main():
             except Exception as e:   # every rank must learn about it, or the others wait in the communicator set-up
                 box[1] = "rn_comm_unique_id: %s" % e
         dist.broadcast_object_list(box, src=0)
-        uid, uid_error = box
+        return box[0], box[1]
+
+    def agree(ok, err, what):
+        """(everybody succeeded, first error): a MIN all-reduce over gloo -- every rank takes the same branch afterwards"""
+        import torch
+
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return True, None
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        return False, next(("rank %d: %s" % (i, e) for i, e in enumerate(errs) if e), "a peer rank failed in " + what)
+
     fallback_reason = [None]
     comm_ranks = [None]
     rccl_library = None
@@ -319,53 +388,72 @@ def main():
         except Exception as e:
             rccl_library = "unavailable: %s" % e
 
-    def run_mode(structured, steps, warmup, profile_steps, new_uid=None, repeats=0, problem=problem, tree=tree, precision=precision, workload=args.workload,
-                 control_step=True):
+    def run_mode(structured, steps, warmup, profile_steps, repeats=0, problem=problem, tree=tree, precision=precision, workload=args.workload,
+                 control_step=True, cut_stage=cut_stage, fatal=True):
         if sharded:
             import torch
-        def make(uid_bytes):
+        def make_local():
             if not sharded:
                 return capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
             if world == 1:    # debug modes: rank 0's shard (or the whole tree) through the sharded code path with a one-rank communicator
                 s_ = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
-                s_.commInit(0, 1, uid_bytes)
+                s_.commInit(0, 1, None)
                 s_.setCutStage(cut_stage, (debug_part["momE"], debug_part["momP"]))
                 return s_
-            # the real thing: partition + communicator + cut stage + children moments in ONE call of the C-ABI
+            # the real thing: partition + cut stage + children moments in ONE call of the C-ABI -- WITHOUT a communicator yet
             return capi.Solver(problem["network"], problem["tree"], problem["config"], precision=precision, device=device, structured=structured,
-                               rank=rank, nranks=world, cut_stage=cut_stage, unique_id=uid_bytes)
+                               rank=rank, nranks=world, cut_stage=cut_stage, unique_id=None)
 
         dh, ah = synth.forecast_at(problem["forecast"], 0)
         s = None
         if sharded:
-            # the library's RCCL communicator; if any rank cannot create it, ALL ranks fall back to the step-wise exchange
-            ok, err = 1, ""
-            if args.exchange == "torch":
-                ok, err = 0, "--exchange torch"
-            elif new_uid is None:
-                ok, err = 0, uid_error or "no unique id"
-            else:
-                try:
-                    s = make(new_uid)
-                except capi.RapidNetError as e:
-                    ok, err = 0, str(e)
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                errs = [None] * world
-                dist.all_gather_object(errs, err)
-                fallback_reason[0] = next((e for e in errs if e), "a peer rank could not create the communicator")
-                if oversubscribed and not args.allow_oversubscribe:
-                    if s is not None:
-                        s.close()
-                    sys.exit("bench.py --gpus %d on a box with fewer GPUs: RCCL refused the communicator (%s); one rank per GPU is required "
-                             "(--allow-oversubscribe rehearses the launcher path over gloo)" % (world, fallback_reason[0]))
+            # Two agreed steps, so that nobody ever waits inside ncclCommInitRank (blocking, no timeout) for a peer that has
+            # already failed: (1) every rank creates its shard context WITHOUT a communicator and the ranks agree over gloo that
+            # all of them succeeded -- otherwise everybody leaves with a non-zero code; (2) only then rn_comm_init, under the
+            # watchdog, and a second agreement on its outcome.
+            beat("rn_create_sharded (%s)" % workload)
+            ok, err = True, ""
+            try:
+                s = make_local()
+            except Exception as e:   # noqa: BLE001 -- reported by every rank, then the job ends
+                ok, err = False, "%s: %s" % (type(e).__name__, e)
+            all_ok, why = agree(ok, err, "rn_create_sharded")
+            if not all_ok:
                 if s is not None:
                     s.close()
-                s = make(None)
+                if not fatal:
+                    raise AgreedFailure("a rank could not create its shard context (%s)" % why)
+                die("a rank could not create its shard context, nobody starts the communicator set-up (%s)" % why)
+            _fault("before_comm_init", rank)
+            new_uid, uid_error = fresh_uid()
+            ok, err = True, ""
+            if args.exchange == "torch":
+                ok, err = False, "--exchange torch"
+            elif new_uid is None:
+                ok, err = False, uid_error or "no unique id"
+            else:
+                beat("rn_comm_init / ncclCommInitRank (%s)" % workload, 180.0)
+                try:
+                    s.commInit(rank if world > 1 else 0, world, new_uid)
+                except capi.RapidNetError as e:
+                    ok, err = False, str(e)
+                beat("communicator ready", 600.0)
+            all_ok, why = agree(ok, err, "rn_comm_init")
+            if not all_ok:
+                fallback_reason[0] = why
+                if not (args.exchange == "torch" or (oversubscribed and args.allow_oversubscribe)):
+                    if not fatal:
+                        s.close()
+                        raise AgreedFailure("RCCL could not create the communicator (%s)" % why)
+                    die("RCCL could not create the communicator (%s); one rank per GPU is required (--allow-oversubscribe rehearses the "
+                        "launcher path over gloo on a box with fewer GPUs)" % why)
+                if ok and args.exchange != "torch":   # a communicator its peers do not have is of no use: start over without one
+                    s.close()
+                    s = make_local()
             comm_ranks[0] = s.shardInfo()["comm_ranks"]
         else:
-            s = make(None)
+            s = make_local()
+        beat("factor step + affine terms (%s)" % workload)
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
         theta = [1.0, 1.0]
@@ -412,12 +500,24 @@ def main():
             while time.perf_counter() - t_ramp < 0.08:
                 iterate(20)
                 s.synchronize()
+        beat("warm-up (%s)" % workload)
         iterate(warmup)
         barrier()
+        beat("timed region (%s)" % workload)
         t0 = time.perf_counter()
         iterate(steps)
+        s.synchronize()
+        dt_own = time.perf_counter() - t0      # this rank's own time: enqueue + its GPU work incl. the waits inside the collectives
         barrier()
         dt = time.perf_counter() - t0
+        per_rank = None
+        if dist is not None and world > 1:     # who was slow, and how uneven the shards are
+            rows = [None] * world
+            dist.all_gather_object(rows, (int(s.nodes), 1e3 * dt_own / steps))
+            per_rank = {"local_nodes": [r[0] for r in rows], "local_nodes_min": min(r[0] for r in rows), "local_nodes_max": max(r[0] for r in rows),
+                        "ms_per_step_own": [r[1] for r in rows], "ms_per_step_own_min": min(r[1] for r in rows), "ms_per_step_own_max": max(r[1] for r in rows),
+                        "note": "own = K steps enqueued and synchronised on the rank's stream, before the closing barrier; the collectives inside make the ranks wait for each other, "
+                                "so the spread shows launch / clock skew, not the shards' work -- see kernel_classes for that"}
 
         def max_over_ranks(v):
             if dist is None:
@@ -432,6 +532,7 @@ def main():
         # the contract's timed region is the one above; `repeats` further regions of the same K steps give its spread
         rep = []
         for _ in range(max(0, repeats)):
+            beat("repeat regions (%s)" % workload)
             barrier()
             t0 = time.perf_counter()
             iterate(steps)
@@ -453,6 +554,7 @@ def main():
         # per-launch hipEvent pass on the solver's own stream
         roofline, classes = None, {}
         if profile_steps > 0:
+            beat("per-launch hipEvent pass (%s)" % workload)
             s.apgReset()
             s.apgIterate(5, history=False)
             s.profileEnable(1)
@@ -469,6 +571,12 @@ def main():
             names = ("stream_gemv" if not structured else "struct_prep+gemm_m2", "recursion+shared_gemms", "dual_update", "bookkeeping")
             for i, nm in enumerate(names):
                 classes[nm] = {"ms_total": float(ms[i]), "launches": int(n[i]), "avg_us": float(1e3 * ms[i] / max(n[i], 1))}
+            if sharded:   # the all-reduces, bracketed by hipEvents of their own on the solver's stream (they lie INSIDE recursion+shared_gemms)
+                cms, cn = s.profileReadCollective()
+                classes["collective"] = {"ms_total": float(cms), "launches": int(cn), "avg_us": float(1e3 * cms / max(cn, 1)),
+                                         "per_step_us": float(1e3 * cms / max(profile_steps, 1)),
+                                         "note": "hipEvents around every all-reduce (cut payload once per iteration; dist tail and verdict + history once per batch): "
+                                                 "wire latency plus the wait for the slowest peer; contained in recursion+shared_gemms"}
             kinfo = s.kernelInfo()
             dual_kernel = "k_dual_stage" if kinfo["dual_stage"] else "k_dual_fused"
             dual_s = 1e-3 * ms[2] / max(n[2], 1)
@@ -516,20 +624,20 @@ def main():
                     roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
                     dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
-        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
+        res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
                "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}
         s.close()
         return res
 
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
-    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats)
+    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
     struct, struct_error = None, None
     if args.structured:
-        struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=args.repeats)
+        struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
     elif not sharded and not args.dense_only:
         try:      # the opt-in mode rides along: a failure there is reported in the line, it does not take the headline with it
-            struct = run_mode(True, args.steps, args.warmup, args.profile_steps, uid, repeats=0)
+            struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=0)
         except Exception as e:   # noqa: BLE001
             struct_error = "%s: %s" % (type(e).__name__, e)
     head = struct if args.structured else dense
@@ -542,6 +650,15 @@ def main():
     s = _S()
     s.nx, s.nu, s.nv, s.nd, s.N = nx, nu, nv, nd, N
 
+    # The other configurations of BASELINE.json, timed in the same run with the same protocol (W warm-up steps, K timed steps, the
+    # per-launch hipEvent pass), each with its own roofline object and CPU leg.  One GPU: barcelona31 (fp64) and wide4096 (fp32).
+    # N > 1: configs[4] -- the wide network, fp32, sharded over the N GPUs like the headline tree (every rank runs it: collectives).
+    others = []
+    if not args.structured and args.workload == "barcelona493" and not args.traffic_probe:
+        others = [w for w in args.other_configs.split(",") if w and w != args.workload]
+        if sharded:
+            others = [w for w in others if w == "wide4096"] if world > 1 else []
+    out = None
     if rank == 0:
         out = {
             "metric": "apg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
@@ -568,30 +685,46 @@ def main():
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if struct_error:
             out["structured_mode"] = {"error": struct_error}
-        if not args.no_cpu_baseline and not sharded:
+        if head.get("per_rank"):
+            out["per_rank"] = head["per_rank"]
+        if others and sharded:   # should a secondary config take the job down, the headline is on record
+            print("bench.py: headline so far: %s" % json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "config")}), file=sys.stderr, flush=True)
+    entries = []
+    for w in others:
+        prec_w = "f32" if w.startswith("wide") else "f64"
+        entry = {"workload": w, "dtype": prec_w}
+        try:
+            beat("problem data (%s)" % w)
+            pw = synth.make_problem(w)
+            cut_w = capi.default_cut_stage(pw["tree"]) if sharded else -1
+            r = run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=min(args.repeats, 4), problem=pw, tree=pw["tree"],
+                         precision=prec_w, workload=w, control_step=False, cut_stage=cut_w, fatal=False)
+            nxw, nuw, nvw, ndw, Nw = r["dims"]
+            entry.update({"config": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (w, nxw, nuw, nvw, ndw, Nw, int(pw["tree"]["K"][0]), int(pw["tree"]["nodes"][0])),
+                          "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"], "steps": args.steps, "warmup": args.warmup,
+                          "timing_spread": r["spread"], "roofline": r["roofline"], "kernel_classes": r["kernel_classes"]})
+            if sharded:
+                entry.update({"n_gpus": world, "local_nodes": int(r["nodes"]), "per_rank": r["per_rank"],
+                              "parallelism": "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_w if not fallback_reason[0]
+                              else "subtree sharding below stage %d, FALLBACK exchange through torch.distributed (%s)" % (cut_w, fallback_reason[0])})
+            if rank == 0 and not args.no_cpu_baseline:
+                beat("CPU baseline (%s)" % w, 1200.0)
+                entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
+            del pw
+        except AgreedFailure as e:   # every rank raised it together: reported, the run goes on
+            entry["error"] = "AgreedFailure: %s" % e
+        except Exception as e:   # a config that does not fit this device / host is reported, not fatal for the headline
+            if world > 1:        # ... unless other ranks are inside collectives this rank will never join
+                die("secondary config %s failed on this rank only (%s: %s)" % (w, type(e).__name__, e))
+            entry["error"] = "%s: %s" % (type(e).__name__, e)
+        entries.append(entry)
+    if rank == 0:
+        if entries:
+            out["configs"] = entries
+        if not args.no_cpu_baseline and not args.traffic_probe and (not sharded or world > 1):
+            # rank 0 only, after every timed region (the other ranks wait at the closing barrier)
+            beat("CPU baseline (%s)" % args.workload, 1200.0)
             out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
-        # the other single-GPU configurations of BASELINE.json, timed in the same run (dense per-node blocks, the same protocol:
-        # W warm-up steps, K timed steps, the per-launch hipEvent pass); each with its own roofline object and CPU leg
-        others = [w for w in args.other_configs.split(",") if w and w != args.workload] if (not sharded and not args.structured and args.workload == "barcelona493") else []
-        if others:
-            out["configs"] = []
-        for w in others:
-            prec_w = "f32" if w.startswith("wide") else "f64"
-            entry = {"workload": w, "dtype": prec_w}
-            try:
-                pw = synth.make_problem(w)
-                r = run_mode(False, args.steps, args.warmup, args.profile_steps, None, repeats=min(args.repeats, 4), problem=pw, tree=pw["tree"],
-                             precision=prec_w, workload=w, control_step=False)
-                nxw, nuw, nvw, ndw, Nw = r["dims"]
-                entry.update({"config": "%s: nx=%d nu=%d nv=%d nd=%d N=%d K=%d nodes=%d" % (w, nxw, nuw, nvw, ndw, Nw, int(pw["tree"]["K"][0]), int(pw["tree"]["nodes"][0])),
-                              "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"], "steps": args.steps, "warmup": args.warmup,
-                              "timing_spread": r["spread"], "roofline": r["roofline"], "kernel_classes": r["kernel_classes"]})
-                if not args.no_cpu_baseline:
-                    entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
-                del pw
-            except Exception as e:   # a config that does not fit this device / host is reported, not fatal for the headline
-                entry["error"] = "%s: %s" % (type(e).__name__, e)
-            out["configs"].append(entry)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -602,4 +735,23 @@ def main():
 
 
 if __name__ == "__main__":
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # a rank that fails leaves AT ONCE with a non-zero code and without finalisers (its peers may be inside a collective it
+        # will never join; tearing down a communicator collectively would hang as well) -- the launcher then ends the others
+        try:
+            main()
+        except SystemExit as e:
+            code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+            if isinstance(e.code, str):
+                print(e.code, file=sys.stderr)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(code)
+        except BaseException:   # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     main()

@@ -415,7 +415,10 @@ struct Ctx : CtxBase {
         allocs.push_back(q);
         allocatedBytes += bytes;
         const unsigned char pat = std::is_floating_point<U>::value || std::is_class<U>::value ? 0xFF : 0x00;
-        RN_HIP(hipMemset(q, pat, padded + 2 * GUARD_BYTES));
+        // filled on the context's OWN stream and waited for: the stream is non-blocking (no implicit ordering with the null
+        // stream), and everything that touches the buffer afterwards -- uploads on either stream, kernels -- must come after the fill
+        RN_HIP(hipMemsetAsync(q, pat, padded + 2 * GUARD_BYTES, stream));
+        RN_HIP(hipStreamSynchronize(stream));
         guards.push_back(GuardRec{q, bytes, pat});
         *p = (U *)((char *)q + GUARD_BYTES);
         return RN_OK;

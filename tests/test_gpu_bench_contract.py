@@ -75,7 +75,8 @@ def test_gpus_2_spawns_its_own_ranks():
     device -- with a non-zero exit code and no JSON line; with --allow-oversubscribe it rehearses the whole launcher path (two
     processes, gloo rendezvous, rn_create_sharded on both, agreed fallback exchange, max-over-ranks timing) and labels the
     line as a fallback.  With two or more GPUs the plain form simply has to produce a sharded result."""
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "0", "--repeats", "1"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "0", "--repeats", "1",
+            "--cpu-iterations", "3"]
     if _devices() >= 2:
         p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -86,8 +87,8 @@ def test_gpus_2_spawns_its_own_ranks():
     assert p.returncode != 0
     assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")], "no result line for a run that could not create its communicator"
     err = p.stderr.decode()
-    assert "ncclCommInitRank failed" in err and "RCCL refused the communicator" in err, err[-2000:]
-    p = subprocess.run(base + ["--allow-oversubscribe"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert "ncclCommInitRank failed" in err and "RCCL could not create the communicator" in err, err[-2000:]
+    p = subprocess.run(base + ["--allow-oversubscribe"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1
@@ -95,3 +96,35 @@ def test_gpus_2_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "FALLBACK" in d["config"]["parallelism"] and d["rccl"]["ranks"] == 2 and d["rccl"]["ranks_seen_by_rccl"] == 0
     assert d["local_nodes"] in (5452, 5430)        # half of the 493 chains + the 18 replicated crown nodes
+    # the N > 1 line explains itself: who held how many nodes, every rank's own step time, the CPU leg, and BASELINE.json
+    # configs[4] (the wide fp32 network) sharded over the same ranks
+    pr = d["per_rank"]
+    assert sorted(pr["local_nodes"]) == [5430, 5452] and pr["local_nodes_min"] == 5430 and pr["local_nodes_max"] == 5452
+    assert len(pr["ms_per_step_own"]) == 2 and 0 < pr["ms_per_step_own_min"] <= pr["ms_per_step_own_max"] <= d["ms_per_step"] * 1.001
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "10864 nodes" in c["sample"]
+    assert [w.get("workload") for w in d["configs"]] == ["wide4096"], d.get("configs")
+    w = d["configs"][0]
+    assert "error" not in w, w
+    assert w["n_gpus"] == 2 and w["dtype"] == "f32" and w["value"] > 0 and sum(w["per_rank"]["local_nodes"]) == 86289 + 273 and w["cpu_baseline"]["value"] > 0
+
+
+def test_a_rank_that_dies_before_the_communicator_set_up_ends_the_job_within_seconds():
+    """The first real multi-GPU run must not be able to hang: every rank creates its shard context WITHOUT a communicator, the
+    ranks agree over gloo that all succeeded, and only then call rn_comm_init.  Here rank 1 leaves abruptly right before the
+    communicator set-up ($RAPIDNET_BENCH_FAULT): rank 0 must notice (its gloo collective fails, or the launcher ends it), nobody
+    may be left inside ncclCommInitRank, and the run must end with a non-zero code and no result line -- within seconds, not at
+    somebody's lease timeout."""
+    import time
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "0", "--repeats", "0",
+           "--no-cpu-baseline", "--other-configs", "", "--allow-oversubscribe"]
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, RAPIDNET_BENCH_FAULT="before_comm_init:1"))
+    elapsed = time.time() - t0
+    err = p.stderr.decode()
+    assert p.returncode != 0, err[-2000:]
+    assert "injected fault at 'before_comm_init'" in err, err[-2000:]
+    assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert "ncclCommInitRank" not in err.replace("rn_comm_init / ncclCommInitRank", ""), "a rank entered the communicator set-up although a peer had failed"
+    assert elapsed < 120, "took %.0f s" % elapsed          # set-up (problem data, two contexts) + a few seconds; no lease-long wait

@@ -446,7 +446,7 @@ def test_rounding_sensitivity_bounds_long_runs(capsys):
         e_gpu = relmax(s.get(capi.BUF_X), base[k]["x"])
         e_self = relmax(pert[k]["x"], base[k]["x"])
         rows.append((total, e_gpu, e_self))
-        assert e_gpu < max(1e-9, 200 * e_self), (total, e_gpu, e_self)
+        assert e_gpu < max(1e-9, 20 * e_self), (total, e_gpu, e_self)      # measured ratios: <= 3 at every checkpoint
     assert rows[-1][2] > 1e-10   # the sensitivity is real (otherwise tighten the bound above)
     with capsys.disabled():
         print("\n[barcelona31_infeasible, synthetic] iterations: HIP-vs-oracle rel. error in x | oracle-vs-perturbed-oracle (beta * (1 + 1e-15))")

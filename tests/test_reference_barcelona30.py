@@ -9,7 +9,8 @@ the reference's files state.  GPU: the HIP path against the committed iterates a
 itself whose beta differs by one part in 1e13 are 4e-10 apart after 200 iterations and 1e-4 after 500, whatever the step
 size (0.25 ... 1 x the held 1e-4), the bounds or the size of the tree errors -- the iterates are still far from converged
 after 500 iterations (primal infeasibility 30-70 of 1700) and the active set keeps changing.  So at 200 ... 500 iterations the
-bound is the oracle's own sensitivity (x 200), as for the infeasible synthetic data; the table is printed."""
+bound is the oracle's own sensitivity (x 20; measured ratios are at most 3), as for the infeasible synthetic data; 1e-8 is asserted
+directly up to 200 iterations; the table is printed."""
 import os
 
 import numpy as np
@@ -109,10 +110,10 @@ def test_hip_path_on_reference_held_data(capsys):
         e_gpu = max(rel(s.get(bids[n]), base[i][n]) for n in NAMES)
         e_self = max(rel(pert[i][n], base[i][n]) for n in NAMES)
         rows.append((k, e_gpu, e_self))
-        if k <= 100:
-            assert e_gpu < 1e-8, (k, e_gpu)                      # north_star's tolerance, directly
-        else:
-            assert e_gpu < max(1e-8, 200 * e_self), (k, e_gpu, e_self)
+        if k <= 200:
+            assert e_gpu < 1e-8, (k, e_gpu)                      # north_star's tolerance, directly (measured: 6.5e-11 at 200)
+        else:                                                    # measured ratios are <= 3: a factor of 20 leaves one digit, not two
+            assert e_gpu < max(1e-8, 20 * e_self), (k, e_gpu, e_self)
         if k in CHECKPOINTS and k <= 100:                            # and against the committed vectors
             for n in NAMES:
                 assert rel(s.get(bids[n])[::st], g["%s_%d" % (n, k)]) < 1e-8, (k, n)
