@@ -356,6 +356,25 @@ int rn_debug_local_group_create(int nranks, void **group);
 int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);
 int rn_debug_local_group_destroy(void *group);
 
+/* ---- one-shot exchange at the cut (opt-in transport for the per-iteration exchange) ------------------
+ * The reference has no counterpart (single GPU).  What is exchanged is exactly what solveSumChildren computes at the cut
+ * (Utilities.cu:168-201): the cut parents' children sums.  With transport 1 the kernel that produces a rank's partial sums
+ * writes them straight into an inbox on every peer (xGMI peer mappings) as self-validating {32 payload bits, 32-bit sequence
+ * tag} packets, and the crown kernel of every rank adds the n contributions in rank order (the same bits everywhere): no
+ * collective launch and no launch boundary between the chain walks and the crown.  The per-BATCH collectives (dist^2 tail,
+ * verdict + history) stay with the communicator, which therefore must exist.  Set-up, once per context:
+ *   rn_peer_inbox_create   allocates this rank's inbox (uncached device memory) and returns its 64-byte hipIpcMemHandle_t;
+ *   (the caller gathers the handles of all ranks, in rank order -- bench.py: torch.distributed / gloo)
+ *   rn_peer_inbox_connect  maps the peers' inboxes (hipIpcOpenMemHandle);
+ *   rn_set_exchange_transport(ctx, 1)   one-shot inside rn_apg_iterate batches; 0 (default): the collective.
+ * A reader that waits longer than 2 s ($RAPIDNET_ONESHOT_TIMEOUT_MS) for a peer's packets gives up: the batch returns
+ * RN_E_COMM (never a hang).  rn_debug_peer_inbox_connect_local wires the inboxes of `nranks` contexts of ONE process (tests:
+ * same address space, no IPC handle needed), contexts in rank order. */
+int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64 /* 64 bytes out */);
+int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 bytes, rank order */, int nranks);
+int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks);
+int rn_set_exchange_transport(rn_ctx *ctx, int transport);
+
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red
  * zone on both sides; red zones and payloads of floating-point buffers start as NaN (0xFF bytes), so an out-of-bounds or

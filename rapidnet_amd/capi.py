@@ -36,6 +36,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
+    "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport",
 ]
 
 
@@ -196,6 +197,10 @@ def load():
     lib.rn_debug_inject_allocation.argtypes = [vp, C.c_size_t]
     lib.rn_guard_report.argtypes = [dp]
     lib.rn_debug_guard_poke.argtypes = [vp, ip]
+    lib.rn_peer_inbox_create.argtypes = [vp, dp]
+    lib.rn_peer_inbox_connect.argtypes = [vp, dp, ip]
+    lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
+    lib.rn_set_exchange_transport.argtypes = [vp, ip]
     lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
     _LIB = lib
     return lib
@@ -496,6 +501,22 @@ class Solver:
         self._check(self.lib.rn_guard_check(self.h, C.addressof(bad)))
         return bad.value
 
+    def peerInboxCreate(self):
+        """this rank's inbox for the one-shot exchange: returns its 64-byte IPC handle (bytes)"""
+        buf = C.create_string_buffer(64)
+        self._check(self.lib.rn_peer_inbox_create(self.h, C.cast(buf, C.c_void_p)))
+        return bytes(buf.raw)
+
+    def peerInboxConnect(self, handles):
+        """handles: the 64-byte IPC handles of all ranks, in rank order"""
+        blob = b"".join(bytes(h) for h in handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self.lib.rn_peer_inbox_connect(self.h, C.cast(buf, C.c_void_p), len(handles)))
+
+    def setExchangeTransport(self, transport):
+        """0: the cut payload is all-reduced by the communicator (default); 1: one-shot peer writes (needs connected inboxes)"""
+        self._check(self.lib.rn_set_exchange_transport(self.h, int(transport)))
+
     def debugGuardPoke(self, nbytes):
         self._check(self.lib.rn_debug_guard_poke(self.h, int(nbytes)))
 
@@ -643,6 +664,14 @@ def guard_report():
     out = (C.c_long * 2)()
     load().rn_guard_report(C.addressof(out))
     return int(out[0]), int(out[1])
+
+
+def peer_inbox_connect_local(solvers):
+    """contexts of ONE process, in rank order, each with an inbox (peerInboxCreate): wire them to each other (tests)"""
+    arr = (C.c_void_p * len(solvers))(*[s.h for s in solvers])
+    rc = load().rn_debug_peer_inbox_connect_local(arr, len(solvers))
+    if rc != 0:
+        raise RapidNetError("rn_debug_peer_inbox_connect_local failed (%d): %s" % (rc, "; ".join(load().rn_last_error(s.h).decode() for s in solvers)))
 
 
 def local_group_create(nranks):

@@ -43,7 +43,93 @@ struct IterState {         // device-resident scalars of the APG loop
     int tripped;           // soft-constraint branch taken in this iteration
     double scaleX, scaleS; // 1 - gamma/(lambda dist) for the two halves (0 when not tripped)
     double distX, distS;   // tree-global distances of this iteration
+    int commFail;          // one-shot exchange: a reader gave up waiting for a peer's packets (sticky; the host turns it into RN_E_COMM)
 };
+
+// ---- one-shot exchange at the cut (opt-in transport, rn_set_exchange_transport) -----------------------
+// Instead of an all-reduce launch between the chain walks and the crown, every rank WRITES its partial children sums straight
+// into an inbox on every peer (xGMI peer mappings; its own inbox included) and the crown workgroups READ the n contributions
+// and add them in rank order -- the same bits on every rank.  No fence, no flag: an element travels as self-validating 8-byte
+// packets {32 payload bits, 32-bit sequence tag} (a double = two packets), written with system-scope relaxed atomic stores and
+// polled with system-scope atomic loads, so no cache can hold either side back and a torn element is recognised by its tags.
+// Two buffers alternate by the parity of the sequence number: a rank can only start exchange s + 2 after it has read every
+// peer's packets of s + 1, which every peer wrote after it had finished reading s.  The reader's spin is bounded by the wall
+// clock; on time-out it raises IterState::commFail and carries on with what it has (the grid always drains).
+constexpr int PEER_MAX = 16;
+struct PeerTable {
+    unsigned long long *inbox[PEER_MAX];   // every rank's inbox as mapped into THIS process (own rank: the local allocation)
+    int nranks, rank;
+    unsigned int slots;                    // elements per source rank and buffer: cut parents x (nv + 2 nx) + 2 (the dist^2 tail)
+    unsigned long long timeoutTicks;       // bound of a reader's wait, in ticks of the 100 MHz wall clock
+};
+template <typename T> struct PeerPk;
+template <> struct PeerPk<double> { static constexpr int N = 2; };
+template <> struct PeerPk<float> { static constexpr int N = 1; };
+template <typename T>
+__device__ __forceinline__ size_t peer_word(const PeerTable &p, unsigned int seq, int src, unsigned int idx) {
+    return (((size_t)(seq & 1u) * (size_t)p.nranks + (size_t)src) * p.slots + idx) * PeerPk<T>::N;
+}
+__device__ __forceinline__ void peer_push(const PeerTable &p, unsigned int seq, unsigned int idx, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)seq << 32;
+    const unsigned long long lo = (bits & 0xffffffffull) | tag, hi = (bits >> 32) | tag;
+    const size_t wd = peer_word<double>(p, seq, p.rank, idx);
+    for (int r = 0; r < p.nranks; r++) {
+        __hip_atomic_store(p.inbox[r] + wd, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.inbox[r] + wd + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__device__ __forceinline__ void peer_push(const PeerTable &p, unsigned int seq, unsigned int idx, float v) {
+    const unsigned long long pk = (unsigned long long)__float_as_uint(v) | ((unsigned long long)seq << 32);
+    const size_t wd = peer_word<float>(p, seq, p.rank, idx);
+    for (int r = 0; r < p.nranks; r++) __hip_atomic_store(p.inbox[r] + wd, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one element of one source rank out of this rank's inbox: polls until its packets carry `seq` (false: timed out)
+__device__ __forceinline__ bool peer_poll(const unsigned long long *w, unsigned int seq, long long t0, unsigned long long limit, unsigned long long &pk) {
+    for (;;) {
+        pk = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)(pk >> 32) == seq) return true;
+        if ((unsigned long long)(wall_clock64() - t0) > limit) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+// dst[i] = sum over the ranks, in ascending rank order, of element i of exchange `seq`, for i in [i0, i1): called by a whole
+// workgroup (tid / nthreads); the caller makes the values visible to itself (fence + barrier) before it reads dst back
+template <typename T>
+__device__ __attribute__((noinline)) void peer_gather(const PeerTable *pt, unsigned int seq, T *dst, int i0, int i1, int tid, int nthreads, IterState *st) {
+    const PeerTable p = *pt;
+    const unsigned long long *in = p.inbox[p.rank];
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    for (int i = i0 + tid; i < i1; i += nthreads) {
+        T s = 0;
+        for (int r0 = 0; r0 < p.nranks; r0 += 4) {
+            unsigned long long pk[4][PeerPk<T>::N];
+            // first look at four ranks' packets at once (one round trip when everything has arrived) ...
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u < p.nranks ? r0 + u : p.nranks - 1;
+                const unsigned long long *w = in + peer_word<T>(p, seq, r, (unsigned int)i);
+#pragma unroll
+                for (int h = 0; h < PeerPk<T>::N; h++) pk[u][h] = __hip_atomic_load(w + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            // ... then wait for the ones that have not
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (r0 + u >= p.nranks) break;
+                const unsigned long long *w = in + peer_word<T>(p, seq, r0 + u, (unsigned int)i);
+#pragma unroll
+                for (int h = 0; h < PeerPk<T>::N; h++)
+                    if ((unsigned int)(pk[u][h] >> 32) != seq) ok = peer_poll(w + h, seq, t0, p.timeoutTicks, pk[u][h]) && ok;
+                T v;
+                if (PeerPk<T>::N == 2) v = (T)__longlong_as_double((long long)((pk[u][0] & 0xffffffffull) | (pk[u][PeerPk<T>::N - 1] << 32)));
+                else v = (T)__uint_as_float((unsigned int)pk[u][0]);
+                s = (r0 + u == 0) ? v : s + v;
+            }
+        }
+        dst[i] = s;
+    }
+    if (!ok) st->commFail = 1;
+}
 template <typename T>
 struct SweepArgs {
     TreeDev<T> tr;
@@ -77,6 +163,10 @@ struct SweepArgs {
     // optimistic exchange: the all-reduced payload ends with the tree-global dist^2 of the previous iteration; the first
     // crown kernel after the all-reduce checks it against the thresholds (no extra launch)
     const T *distTail; double thrX, thrS; void *iterState;
+    // one-shot exchange (nullptr: the payload is all-reduced by a collective between the launches): the kernels that produce the
+    // cut parents' local sums push them to every peer under sequence number peerSeq, the crown kernels gather and add them;
+    // peerTail: the payload's 2-element dist^2 tail travels with this exchange (the previous iteration's bookkeeping rode along)
+    const PeerTable *peer; unsigned int peerSeq; int peerTail;
     // 0: the primal iterates x, u, v are not stored by this sweep (inner iterations of a device-resident batch: only Hx feeds
     // the dual update; the last iteration of every batch and every step-wise call store them)
     int writePrimal;
@@ -473,7 +563,7 @@ constexpr int CROWN_THREADS = 1024;   // stages prefetched per round trip (the r
 // (thrX >= 0: single GPU).  Rides as one extra workgroup in k_cut_partial_sums (sharded) or k_up_chain (single GPU).
 struct FinArgs { const Partial *partials; int nblocks; IterState *st; void *tail; double *hist, *histParts; int histCap; double thrX, thrS; };
 template <typename T>
-__device__ void finalize_optimistic_body(const FinArgs &fin);
+__device__ void finalize_optimistic_body(const FinArgs &fin, const PeerTable *peer = nullptr, unsigned int peerSeq = 0, unsigned int tailIdx = 0);
 // (the walk is spelled out twice, here and in k_up_chain_cut: shared through a device function it measured 8 us slower on the
 //  493-scenario tree -- 20.1 instead of 11.8 us)
 template <typename T>
@@ -546,7 +636,7 @@ template <typename T>
 __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, T *out, int nParents, int lanesPer, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
         if (threadIdx.x >= ELT_THREADS) return;      // the bookkeeping is written for ELT_THREADS threads
-        finalize_optimistic_body<T>(fin);
+        finalize_optimistic_body<T>(fin, a.peer, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -618,6 +708,7 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
         T sum = 0;
         for (int c = 0; c < nc; c++) sum += sh[c * w + tt];
         out[(size_t)blockIdx.x * w + tt] = sum;
+        if (a.peer) peer_push(*a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)tt, sum);   // one-shot exchange: straight to every peer
     }
 }
 // Crown region (stages < c*), one node: children are summed explicitly (loads batched CHAIN_PF at a time).
@@ -841,6 +932,14 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
+    if (presummed && a.peer) {   // one-shot exchange: this node's all-reduced sums (workgroup 0: the dist^2 tail as well) come out of the inbox
+        T *cs = const_cast<T *>(a.cutSums);
+        IterState *st = reinterpret_cast<IterState *>(a.iterState);
+        peer_gather<T>(a.peer, a.peerSeq, cs, pos * w, (pos + 1) * w, threadIdx.x, CROWN_THREADS, st);
+        if (blockIdx.x == 0 && a.peerTail) { const int nP = a.tr.stageCum[stage + 1] - a.tr.stageCum[stage]; peer_gather<T>(a.peer, a.peerSeq, cs, nP * w, nP * w + 2, threadIdx.x, CROWN_THREADS, st); }
+        __threadfence_block();
+        __syncthreads();
+    }
     if (presummed && a.distTail != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         IterState *st = reinterpret_cast<IterState *>(a.iterState);
         const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
@@ -897,7 +996,7 @@ constexpr int CUT_THREADS = 256;   // = ELT_THREADS (the bookkeeping block's red
 template <typename T>
 __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a, T *out, int nParents, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
-        finalize_optimistic_body<T>(fin);
+        finalize_optimistic_body<T>(fin, a.peer, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
         return;
     }
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
@@ -913,6 +1012,7 @@ __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a
             for (int j = 0; j < CHAIN_PF; j++) if (c + j < nc) s += r[j];
         }
         out[(size_t)blockIdx.x * w + t] = s;
+        if (a.peer) peer_push(*a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)t, s);
     }
 }
 
@@ -1320,6 +1420,15 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
         const int lo = s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16;
         const int hi = e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16;
+        if (a.peer && (blockIdx.x == 0 || lo < hi)) {   // one-shot exchange: the workgroups that use the all-reduced sums take them out of the inbox
+            T *cs = const_cast<T *>(a.cutSums);
+            IterState *st = reinterpret_cast<IterState *>(a.iterState);
+            const int w = a.nv + 2 * a.nx, nP = e1 - s1;
+            if (blockIdx.x == 0) peer_gather<T>(a.peer, a.peerSeq, cs, 0, nP * w + (a.peerTail ? 2 : 0), threadIdx.x, blockDim.x, st);
+            else peer_gather<T>(a.peer, a.peerSeq, cs, (lo - s1) * w, (hi - s1) * w, threadIdx.x, blockDim.x, st);
+            __threadfence_block();
+            __syncthreads();
+        }
         // workgroup 0 does both steps in one batch of loads when the children's values fit in the (still unused) slab
         // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
         // has swept the caches and TLBs
@@ -2166,7 +2275,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials,
 // correction; this kernel folds the block partials, stores the rank-local dist^2 of THIS iteration in the tail of the
 // cut payload (it rides on the NEXT iteration's all-reduce), writes the rank-local history entry and advances `it`.
 template <typename T>
-__device__ void finalize_optimistic_body(const FinArgs &fin) {
+__device__ void finalize_optimistic_body(const FinArgs &fin, const PeerTable *peer, unsigned int peerSeq, unsigned int tailIdx) {
     const Partial *partials = fin.partials;
     const int nblocks = fin.nblocks, histCap = fin.histCap;
     IterState *st = fin.st;
@@ -2177,6 +2286,7 @@ __device__ void finalize_optimistic_body(const FinArgs &fin) {
     fold_partials(partials, nblocks, true, tx2, ts2, p);
     if (threadIdx.x == 0) {
         if (tail) { tail[0] = (T)tx2; tail[1] = (T)ts2; }
+        if (tail && peer) { peer_push(*peer, peerSeq, tailIdx, (T)tx2); peer_push(*peer, peerSeq, tailIdx + 1, (T)ts2); }   // one-shot exchange: the tail travels too
         if (fin.thrX >= 0) {   // single GPU: the distances are complete -- verify the projection-only prox right here
             const double dX = sqrt(tx2), dS = sqrt(ts2);
             st->distX = dX; st->distS = dS;

@@ -180,6 +180,11 @@ struct CtxBase {
     virtual int profile_read_collective(double *, long *) = 0;
     virtual int inject_allocation(size_t) = 0;
     virtual int guard_poke(int) = 0;
+    virtual int peer_inbox_create(void *) = 0;
+    virtual int peer_inbox_connect(const void *, int) = 0;
+    virtual int peer_inbox_connect_local(CtxBase **, int) = 0;
+    virtual unsigned long long *peer_inbox_ptr() = 0;
+    virtual int set_exchange_transport(int) = 0;
 };
 
 // ---- in-process stand-in for the communicator (rn_debug_local_group_*): `n` contexts of one process, one host thread each ----
@@ -384,6 +389,8 @@ struct Ctx : CtxBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         for (auto e : freeEvents) (void)hipEventDestroy(e);
+        for (void *p : ipcOpened) (void)hipIpcCloseMemHandle(p);
+        if (d_inbox) (void)hipFree(d_inbox);
         for (void *p : allocs) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1007,6 +1014,13 @@ struct Ctx : CtxBase {
             a.x = d_xdir; a.u = d_udir; a.hx = d_hxDir;
         }
         RN_CHECK(phase == 0 || a.cutSums, RN_E_STATE, "rn_debug_sweep_phase needs rn_set_cut_stage and nranks > 1");
+        // one-shot exchange (inside rn_apg_iterate batches only): the launch that produces the cut parents' local sums pushes them
+        // to every peer, the crown launch gathers them -- no collective in between
+        const bool oneShot = transport == 1 && peerReady && inBatch && phase == 0 && a.cutSums != nullptr && hessianInput == nullptr;
+        if (oneShot) {
+            if (++peerSeq == 0) ++peerSeq;      // 0 is the "never written" tag
+            a.peer = d_peer; a.peerSeq = peerSeq; a.peerTail = (pendingFin && carryTail) ? 1 : 0;
+        }
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
         auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
         // (1) all per-node mat-vecs of the backward sweep in one streaming launch
@@ -1054,6 +1068,7 @@ struct Ctx : CtxBase {
                 pendingFin = false;
             }
             if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
+            if (oneShot) return RN_OK;                       // the payload has gone to the peers' inboxes straight from the kernel
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
             return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
         };
@@ -1242,7 +1257,7 @@ struct Ctx : CtxBase {
         const size_t tail = cut_tail_offset();
         RN_HIP(hipMemsetAsync(d_cut + tail, 0, 2 * sizeof(T), stream));
         RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
-        carryTail = true;
+        carryTail = true; inBatch = true;
         const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
@@ -1271,7 +1286,7 @@ struct Ctx : CtxBase {
             if (storesW) { p_acc_view = p_acc; std::swap(p_acc, p_acc_other); }
             h_it++;
         }
-        carryTail = false;
+        carryTail = false; inBatch = false;
         if (n > 0) {   // the last iteration's distances: one 2-element all-reduce per BATCH
             if (int rc = all_reduce(d_cut + tail, 2, sizeof(T) == 8, "ncclAllReduce(dist tail)")) return fail_batch(rc);
             // one more all-reduce per BATCH (MAX): the ranks agree on the verdict (every rank takes the same replay decision even if
@@ -1287,6 +1302,7 @@ struct Ctx : CtxBase {
             RN_HIP(hipStreamSynchronize(stream));
             violated = votes > 0 ? 1 : 0;
         } else RN_HIP(hipStreamSynchronize(stream));
+        if (transport == 1 && peerReady) { if (int rc = check_comm_fail()) return fail_batch(rc); }
         if (violated) {   // replay the batch exactly
             fallbacks++;
             p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
@@ -1372,6 +1388,85 @@ struct Ctx : CtxBase {
     // SmpcController::allocateApgAlgorithm sizes its per-iteration storage by maxIterations once (SmpcController.cu:124-151):
     // the iteration tables (lambda_k, vecPrimalInfs and its parts) and the optimistic paths' checkpoint buffers for `n` iterations
     // are allocated here, so that no control step allocates device memory (the reference's leak check, :1612-1623, would flag it)
+    // ---- one-shot exchange at the cut (kernels.hpp, PeerTable) -----------------------------------------------------------------
+    // The inbox of this rank: 2 buffers x nranks sources x slots elements of 8-byte packets, in UNCACHED device memory (no L2 of
+    // either side may hold a packet back), exported as a hipIpcMemHandle_t; peers map it and write into it from their kernels.
+    unsigned long long *d_inbox = nullptr;
+    size_t inboxBytes = 0;
+    PeerTable h_peer{};
+    PeerTable *d_peer = nullptr;
+    std::vector<void *> ipcOpened;
+    bool peerReady = false, inBatch = false;
+    int transport = 0;            // 0: the cut payload is all-reduced by the collective; 1: one-shot peer writes (inside rn_apg_iterate batches)
+    unsigned int peerSeq = 0;     // sequence number of the last one-shot exchange (the same on every rank: they issue the same exchanges)
+    unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }
+    int peer_inbox_create(void *handle64) override {
+        RN_CHECK(handle64, RN_E_ARG, "rn_peer_inbox_create: null output");
+        RN_CHECK(cutStage > 0 && nranks >= 2 && nranks <= PEER_MAX, RN_E_STATE, "rn_peer_inbox_create: a sharded context of 2 .. 16 ranks is required");
+        RN_HIP(hipSetDevice(device));
+        if (!d_inbox) {
+            inboxBytes = (size_t)2 * nranks * peer_slots() * PeerPk<T>::N * sizeof(unsigned long long);
+            RN_HIP(hipExtMallocWithFlags((void **)&d_inbox, inboxBytes, hipDeviceMallocUncached));
+            RN_HIP(hipMemset(d_inbox, 0, inboxBytes));      // tag 0 = "never written" (sequence numbers start at 1)
+            RN_HIP(hipDeviceSynchronize());
+        }
+        hipIpcMemHandle_t h;
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "rn_peer_inbox_create hands out 64-byte handles");
+        RN_HIP(hipIpcGetMemHandle(&h, d_inbox));
+        std::memcpy(handle64, &h, sizeof h);
+        return RN_OK;
+    }
+    unsigned long long *peer_inbox_ptr() override { return d_inbox; }
+    int peer_table_install() {
+        h_peer.nranks = nranks; h_peer.rank = rank; h_peer.slots = peer_slots();
+        double ms = 2000.0;   // a reader waits at most this long for a peer's packets, then gives up with RN_E_COMM
+        if (const char *e = std::getenv("RAPIDNET_ONESHOT_TIMEOUT_MS")) { const double v = std::atof(e); if (v > 0) ms = v; }
+        h_peer.timeoutTicks = (unsigned long long)(ms * 1e5);   // 100 MHz wall clock
+        if (!d_peer) { if (int rc = dalloc(&d_peer, 1)) return rc; }
+        RN_HIP(hipMemcpy(d_peer, &h_peer, sizeof h_peer, hipMemcpyHostToDevice));
+        peerReady = true; peerSeq = 0;
+        return RN_OK;
+    }
+    int peer_inbox_connect(const void *handles, int n) override {
+        RN_CHECK(handles && n == nranks, RN_E_ARG, "rn_peer_inbox_connect: one 64-byte handle per rank expected");
+        RN_CHECK(d_inbox != nullptr, RN_E_STATE, "rn_peer_inbox_connect before rn_peer_inbox_create");
+        RN_HIP(hipSetDevice(device));
+        for (int r = 0; r < nranks; r++) {
+            if (r == rank) { h_peer.inbox[r] = d_inbox; continue; }
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, (const char *)handles + (size_t)64 * r, sizeof h);
+            void *ptr = nullptr;
+            RN_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+            ipcOpened.push_back(ptr);
+            h_peer.inbox[r] = (unsigned long long *)ptr;
+        }
+        return peer_table_install();
+    }
+    // the ranks are contexts of ONE process (tests): a peer's inbox is an ordinary device pointer of the same address space
+    int peer_inbox_connect_local(CtxBase **peers, int n) override {
+        RN_CHECK(peers && n == nranks, RN_E_ARG, "rn_debug_peer_inbox_connect_local: one context per rank expected");
+        for (int r = 0; r < nranks; r++) {
+            RN_CHECK(peers[r] && peers[r]->peer_inbox_ptr(), RN_E_STATE, "rn_debug_peer_inbox_connect_local: a rank has no inbox (rn_peer_inbox_create)");
+            h_peer.inbox[r] = peers[r]->peer_inbox_ptr();
+        }
+        RN_CHECK(h_peer.inbox[rank] == d_inbox, RN_E_ARG, "rn_debug_peer_inbox_connect_local: contexts must be given in rank order");
+        RN_HIP(hipSetDevice(device));
+        return peer_table_install();
+    }
+    int set_exchange_transport(int t) override {
+        RN_CHECK(t == 0 || t == 1, RN_E_ARG, "rn_set_exchange_transport: 0 (collective) or 1 (one-shot peer writes)");
+        RN_CHECK(t == 0 || peerReady, RN_E_STATE, "rn_set_exchange_transport: connect the peers' inboxes first (rn_peer_inbox_connect)");
+        transport = t;
+        return RN_OK;
+    }
+    // after a batch in one-shot mode: did a reader give up waiting?  (one 4-byte read-back; the stream has been synchronised)
+    int check_comm_fail() {
+        int f = 0;
+        RN_HIP(hipMemcpyAsync(&f, &d_state->commFail, sizeof(int), hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        RN_CHECK(f == 0, RN_E_COMM, "one-shot exchange: a peer's packets did not arrive within the time-out (a rank is missing or far behind)");
+        return RN_OK;
+    }
     size_t injectBytes = 0;
     int inject_allocation(size_t bytes) override { injectBytes = bytes; return RN_OK; }
     int reserve_iterations(int n) override {
@@ -1402,6 +1497,7 @@ struct Ctx : CtxBase {
         if (!inReplay && n > 0) exactBatches++;
         const int first = h_it;
         if (int rc = ensure_tables(h_it + n)) return rc;
+        inBatch = true;
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {   // re-derive w_t after manual buffer edits (SmpcController.cu:1514)
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
@@ -1436,9 +1532,11 @@ struct Ctx : CtxBase {
             std::swap(p_acc, p_acc_other);
             h_it++;
         }
+        inBatch = false;
         RN_HIP(hipGetLastError());
         // sharded: the batch's history entries become tree-global (one MAX all-reduce per batch)
         if (has_comm() && cutStage > 0 && n > 0) { if (int rc = globalize_history(first, n, nullptr)) return fail_batch(rc); }
+        if (transport == 1 && peerReady && has_comm() && cutStage > 0 && n > 0) { if (int rc = check_comm_fail()) return fail_batch(rc); }
         if (primalInfs && n > 0) {
             RN_HIP(hipStreamSynchronize(stream));
             RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1462,7 +1560,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
-        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false;
+ poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }
@@ -2080,6 +2178,16 @@ int rn_debug_local_group_destroy(void *group) { if (!group) return RN_E_ARG; del
 int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes) { RN_GUARD(ctx); return ctx->impl->inject_allocation(bytes); }
 int rn_debug_guard_poke(rn_ctx *ctx, int nbytes) { RN_GUARD(ctx); return ctx->impl->guard_poke(nbytes); }
 int rn_guard_report(long out[2]) { if (!out) return RN_E_ARG; out[0] = rn::g_guardContexts.load(); out[1] = rn::g_guardBadBytes.load(); return RN_OK; }
+int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64) { RN_GUARD(ctx); return ctx->impl->peer_inbox_create(ipcHandle64); }
+int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles, int nranks) { RN_GUARD(ctx); return ctx->impl->peer_inbox_connect(ipcHandles, nranks); }
+int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
+    if (!ctxs || nranks < 2 || nranks > rn::PEER_MAX) return RN_E_ARG;
+    std::vector<rn::CtxBase *> impls(nranks);
+    for (int r = 0; r < nranks; r++) { if (!ctxs[r] || !ctxs[r]->impl) return RN_E_ARG; impls[r] = ctxs[r]->impl; }
+    for (int r = 0; r < nranks; r++) if (int rc = impls[r]->peer_inbox_connect_local(impls.data(), nranks)) return rc;
+    return RN_OK;
+}
+int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
 int rn_reserve_iterations(rn_ctx *ctx, int maxIterations) { RN_GUARD(ctx); return ctx->impl->reserve_iterations(maxIterations); }

@@ -348,6 +348,39 @@ def make_problem(name, max_iterations=500, sim_horizon=2, penalty_x=1e6, penalty
     return make_feasible(problem) if feasible else problem
 
 
+# Version tag of the generated data.  "f1" (round 3 on): the BASELINE.json shapes (names in FEASIBLE) are made feasible by
+# construction (make_feasible: control bounds, prevU and -- for rank-deficient B L -- a few columns of Gd are re-centred); "g0": the
+# generator's original random bounds (what rounds 1-2 benchmarked under the plain names, still available as "<name>_infeasible").
+# Dimensions, B, L, W, the preconditioner, the tree and the step size are the same in both, so the kernels do the same work; the
+# iterates, the goldens and the active sets differ -- numbers of different versions are not comparable digit for digit.
+DATA_VERSION_FEASIBLE, DATA_VERSION_ORIGINAL = "f1", "g0"
+
+
+def data_tag(name):
+    """'<workload>@<data version>' of a named config, e.g. 'barcelona493@f1', 'barcelona31_infeasible@g0'."""
+    base = name[:-11] if name.endswith("_infeasible") else name
+    feasible = (base in FEASIBLE) and not name.endswith("_infeasible")
+    return "%s@%s" % (name, DATA_VERSION_FEASIBLE if feasible else DATA_VERSION_ORIGINAL)
+
+
+def fingerprint(problem):
+    """sha256 over the numbers a solve depends on (network, tree, configuration, both forecasts), as float64 bytes in a fixed
+    key order: two runs that print the same fingerprint solved the same problem."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for part, keys in (("network", ("matB", "matGd", "matE", "matEd", "vecXmin", "vecXmax", "vecXsafe", "vecUmin", "vecUmax", "costAlpha1")),
+                       ("tree", ("ancestor", "stages", "probNode", "errorDemandNode", "errorPriceNode")),
+                       ("config", ("matL", "matLhat", "costW", "matDiagPrecnd", "currentX", "prevU", "prevDemand", "stepSize", "penaltyStateX", "penaltySafetyX"))):
+        for k in keys:
+            h.update(k.encode() + b"\0")
+            h.update(np.ascontiguousarray(np.asarray(problem[part][k], dtype=np.float64)).tobytes())
+    for k in sorted(problem["forecast"]):
+        h.update(k.encode() + b"\0")
+        h.update(np.ascontiguousarray(np.asarray(problem["forecast"][k], dtype=np.float64)).tobytes())
+    return h.hexdigest()
+
+
 def forecast_at(forecast, sim_time):
     """Forecaster::predictDemand/predictPrices member-order rule (Forecaster.cu:93-119)."""
     keys = list(forecast.keys())

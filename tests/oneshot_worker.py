@@ -1,0 +1,198 @@
+"""Worker of tests/test_gpu_oneshot.py -- the one-shot exchange at the cut (rn_set_exchange_transport(ctx, 1)).
+
+  inprocess <problem> <world> <cut> [structured] [f32]
+      `world` shard contexts of ONE process, one host thread each, inboxes wired through rn_debug_peer_inbox_connect_local;
+      run in a process of its own because the ranks' streams must sit on different hardware queues (a crown kernel that
+      waits for a peer's packets must not block that peer's kernels behind it in the same queue): GPU_MAX_HW_QUEUES is set
+      by the parent.  Compared with the stand-in transport (bitwise) and with the CPU oracle.
+  ipc <problem> <cut>
+      one rank of a 2-process run under torch.distributed.run on one GPU: the inboxes travel as hipIpcMemHandle_t over
+      gloo (the path `bench.py --gpus N` takes on a multi-GPU node); the per-batch collectives go through an all-reduce
+      callback that uses gloo.  Rank 0 compares the reassembled iterates with the oracle.
+"""
+import os
+import sys
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+from oracle.oracle import Oracle  # noqa: E402
+from rapidnet_amd import capi, partition, synth  # noqa: E402
+
+VECS = ((capi.BUF_X, "x", "nx"), (capi.BUF_U, "u", "nu"), (capi.BUF_V, "v", "nv"), (capi.BUF_UPD_XI, "updXi", "2nx"), (capi.BUF_UPD_PSI, "updPsi", "nu"),
+        (capi.BUF_DUAL_XI, "dualXi", "2nx"), (capi.BUF_RES_PSI, "resPsi", "nu"))
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    assert a.shape == b.shape and np.isfinite(a).all()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def inprocess(name, world, cut, structured, precision, kw):
+    p = synth.make_problem(name, **kw)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
+    o.initialise(dh, ah)
+    ohist = o.apg(44)
+    tol = 1e-9 if precision == "f64" else 2e-4
+    results = {}
+    for transport in (0, 1):
+        group = capi.local_group_create(world)
+        shards = []
+        for r in range(world):
+            s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=world, cut_stage=cut, structured=structured, precision=precision)
+            s.joinLocalGroup(group, r)
+            shards.append(s)
+        if transport == 1:
+            for s in shards:
+                s.peerInboxCreate()
+            capi.peer_inbox_connect_local(shards)
+            for s in shards:
+                s.setExchangeTransport(1)
+        out, errs = [None] * world, []
+
+        def work(i):
+            try:
+                s = shards[i]
+                s.initialiseSmpcController(dh, ah)
+                s.apgReset()
+                h = [s.apgIterate(20), s.apgIterate(4), s.apgIterate(20)]     # optimistic, exact (short batch: no -- sharded batches are always optimistic), optimistic
+                out[i] = (np.concatenate(h), s.counters())
+            except Exception as e:   # noqa: BLE001
+                errs.append((i, e))
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        d = {"nx": shards[0].nx, "nu": shards[0].nu, "nv": shards[0].nv, "2nx": 2 * shards[0].nx}
+        nodes = shards[0].full_nodes
+        got = {nm: partition.scatter_to_global([s.get(bid) for s in shards], [s.global_nodes for s in shards], nodes, d[dm]) for bid, nm, dm in VECS}
+        results[transport] = (got, [x[0] for x in out], [x[1] for x in out])
+        for nm in got:
+            assert relmax(got[nm], o.get(nm)) < tol, (transport, nm, relmax(got[nm], o.get(nm)))
+        for h, _ in out:
+            assert np.abs(h - ohist).max() <= tol * np.abs(ohist).max(), transport
+        for s in shards:
+            s.close()
+        capi.local_group_destroy(group)
+    # the same sums in the same (rank) order: the one-shot transport reproduces the stand-in's bits
+    for nm in results[0][0]:
+        assert np.array_equal(results[0][0][nm], results[1][0][nm]), nm
+    assert all(np.array_equal(a, b) for a, b in zip(results[0][1], results[1][1]))
+    assert results[0][2] == results[1][2], (results[0][2], results[1][2])
+    print("oneshot inprocess ok: %s world %d cut %d structured %d %s, batches %s" % (name, world, cut, structured, precision, results[1][2][0]), flush=True)
+
+
+def timeout_case():
+    """a rank that never pushes: the waiting rank's batch returns RN_E_COMM after the time-out instead of hanging"""
+    import time
+
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    group = capi.local_group_create(2)
+    shards = []
+    for r in range(2):
+        s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=2)
+        s.joinLocalGroup(group, r)
+        s.peerInboxCreate()
+        shards.append(s)
+    capi.peer_inbox_connect_local(shards)
+    for s in shards:
+        s.setExchangeTransport(1)
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+    res = {}
+
+    def lonely():
+        t0 = time.time()
+        try:
+            shards[0].apgIterate(20, history=False)
+            res["err"] = None
+        except capi.RapidNetError as e:
+            res["err"] = str(e)
+        res["t"] = time.time() - t0
+
+    t = threading.Thread(target=lonely)
+    t.start()
+    t.join()
+    # rank 1 never iterates: rank 0's crown kernels time out (every one of them: bounded), and the closing collective of the batch
+    # fails in the stand-in group as well -- either way an error, not a hang
+    assert res["err"] is not None and res["t"] < 60, res
+    print("oneshot timeout ok: %.1f s, %s" % (res["t"], res["err"][:120]), flush=True)
+    os._exit(0)      # the half-finished group is not torn down
+
+
+def ipc(name, cut):
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method="env://")
+    hip = C.CDLL("libamdhip64.so")
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    s = capi.Solver(p["network"], p["tree"], p["config"], rank=rank, nranks=world, cut_stage=cut)
+
+    def all_reduce(buf, count, f64, op, stream):       # stands where ncclAllReduce would: device buffer -> host -> gloo -> device
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        host = np.empty(count, np.float64 if f64 else np.float32)
+        if hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(buf), C.c_size_t(host.nbytes), 2) != 0:
+            return 1
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 2 else dist.ReduceOp.SUM)
+        return 0 if hip.hipMemcpy(C.c_void_p(buf), C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes), 1) == 0 else 2
+
+    s.debugSetAllreduce(all_reduce)
+    handles = [None] * world
+    dist.all_gather_object(handles, s.peerInboxCreate())
+    s.peerInboxConnect(handles)
+    dist.barrier()
+    s.initialiseSmpcController(dh, ah)
+    out = {}
+    for transport in (0, 1):
+        s.setExchangeTransport(transport)
+        s.apgReset()
+        h = np.concatenate([s.apgIterate(20), s.apgIterate(20)])
+        out[transport] = (h, {nm: s.get(bid) for bid, nm, _ in VECS})
+    for nm in out[0][1]:
+        assert np.array_equal(out[0][1][nm], out[1][1][nm]), nm         # two ranks: a + b in either order -- the same bits
+    assert np.array_equal(out[0][0], out[1][0])
+    rows = [None] * world
+    dist.all_gather_object(rows, (s.global_nodes, out[1][1], out[1][0], s.counters()))
+    if rank == 0:
+        o = Oracle(p["network"], p["tree"], p["config"])
+        o.initialise(dh, ah)
+        ohist = o.apg(40)
+        d = {"nx": s.nx, "nu": s.nu, "nv": s.nv, "2nx": 2 * s.nx}
+        for bid, nm, dm in VECS:
+            full = partition.scatter_to_global([r[1][nm] for r in rows], [r[0] for r in rows], s.full_nodes, d[dm])
+            assert relmax(full, o.get(nm)) < 1e-9, nm
+        for r in rows:
+            assert np.abs(r[2] - ohist).max() <= 1e-9 * np.abs(ohist).max()
+        print("oneshot ipc ok: %s, %d ranks, cut %d, batches %s" % (name, world, cut, rows[0][3]), flush=True)
+    dist.barrier()
+    sys.stdout.flush()
+    os._exit(0)      # torch + the solver library in one process: no interpreter tear-down (see tests/test_gpu_bench_contract.py)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "inprocess":
+        kw = {"penalty_x": 20.0, "penalty_xs": 5.0} if "trip" in sys.argv[5:] else {}
+        inprocess(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), "structured" in sys.argv[5:], "f32" if "f32" in sys.argv[5:] else "f64", kw)
+    elif mode == "timeout":
+        timeout_case()
+    elif mode == "ipc":
+        ipc(sys.argv[2], int(sys.argv[3]))
+    else:
+        sys.exit("unknown mode " + mode)
