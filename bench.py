@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="do not measure the HBM traffic of the dominant kernels in this run (two short rocprofv3 --pmc child runs, "
                     "started before this process touches the GPU); roofline.traffic then falls back to profiles/traffic.json if its kernel fingerprint matches")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the child run the counters are collected on
+    ap.add_argument("--one-shot", action="store_true", help="debug/timing only, with --force-shard / --emulate-world: the one-shot exchange at the cut (the rank writes to and reads "
+                    "from its own inbox) instead of the one-rank ncclAllReduce -- what a rank executes except the wire, for both transports")
+    ap.add_argument("--no-alt-exchange", action="store_true", help="N > 1: skip the extra pass that times the one-shot exchange at the cut beside the RCCL one")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
     return ap.parse_args()
@@ -389,7 +392,7 @@ def main():
             rccl_library = "unavailable: %s" % e
 
     def run_mode(structured, steps, warmup, profile_steps, repeats=0, problem=problem, tree=tree, precision=precision, workload=args.workload,
-                 control_step=True, cut_stage=cut_stage, fatal=True):
+                 control_step=True, cut_stage=cut_stage, fatal=True, alt=False):
         if sharded:
             import torch
         def make_local():
@@ -451,6 +454,9 @@ def main():
                     s.close()
                     s = make_local()
             comm_ranks[0] = s.shardInfo()["comm_ranks"]
+            if world == 1 and args.one_shot:
+                s.peerInboxConnect([s.peerInboxCreate()])
+                s.setExchangeTransport(1)
         else:
             s = make_local()
         beat("factor step + affine terms (%s)" % workload)
@@ -623,10 +629,65 @@ def main():
                 if read_ceiling:   # read-only stream vs a read-only probe; the dual update (5 read + 2 write streams) vs the copy probe
                     roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
                     dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
+        # N > 1, last pass of the run (alt=True): the SAME context, the same protocol, with the one-shot exchange at the cut instead of
+        # the per-iteration ncclAllReduce (rn_set_exchange_transport(ctx, 1): peer-written packets, gathered by the crown kernels;
+        # the per-batch collectives stay with RCCL).  Never the headline `value`; a failure is reported, not fatal.
+        alt_res = None
+        if alt and sharded and world > 1:
+            if fallback_reason[0]:
+                alt_res = {"error": "not run: no RCCL communicator in this run (%s)" % fallback_reason[0]}
+            else:
+                beat("one-shot exchange: inbox set-up (%s)" % workload)
+                ok, err, handle = True, "", None
+                try:
+                    handle = s.peerInboxCreate()
+                except capi.RapidNetError as e:
+                    ok, err = False, str(e)
+                handles = [None] * world
+                dist.all_gather_object(handles, handle)
+                if ok and all(h is not None for h in handles):
+                    try:
+                        s.peerInboxConnect(handles)
+                    except capi.RapidNetError as e:
+                        ok, err = False, str(e)
+                elif ok:
+                    ok, err = False, "a peer could not create its inbox"
+                all_ok, why = agree(ok, err, "one-shot set-up")
+                if not all_ok:
+                    alt_res = {"error": "set-up failed: %s" % why}
+                else:
+                    ok, err, dt_alt = True, "", None
+                    try:
+                        s.setExchangeTransport(1)
+                        s.apgReset()
+                        beat("one-shot exchange: timed region (%s)" % workload)
+                        for _ in range(4):
+                            iterate(20)
+                        iterate(warmup)
+                        barrier()
+                        t0 = time.perf_counter()
+                        iterate(steps)
+                        barrier()
+                        dt_alt = time.perf_counter() - t0
+                    except capi.RapidNetError as e:      # a reader's time-out: every rank's readers are bounded, so every rank gets here
+                        ok, err = False, str(e)
+                    all_ok, why = agree(ok, err, "one-shot timed region")
+                    if all_ok:
+                        dt_alt = max_over_ranks(dt_alt)
+                        alt_res = {"kind": "one-shot exchange at the cut: peer-written {payload, tag} packets gathered by the crown kernels (rn_set_exchange_transport 1); per-batch collectives over RCCL",
+                                   "value": steps / dt_alt, "unit": "iterations/s", "ms_per_step": 1e3 * dt_alt / steps,
+                                   "same_context_rccl": {"value": steps / dt, "ms_per_step": 1e3 * dt / steps},
+                                   "speedup_vs_rccl_same_context": dt / dt_alt}
+                    else:
+                        alt_res = {"error": "timed region failed: %s" % why}
+                    try:
+                        s.setExchangeTransport(0)
+                    except capi.RapidNetError:
+                        pass
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
-               "dims": (s.nx, s.nu, s.nv, s.nd, s.N)}
+               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res}
         s.close()
         return res
 
@@ -723,6 +784,18 @@ def main():
                 die("secondary config %s failed on this rank only (%s: %s)" % (w, type(e).__name__, e))
             entry["error"] = "%s: %s" % (type(e).__name__, e)
         entries.append(entry)
+    # N > 1: the one-shot exchange timed beside the RCCL one, in a context of its own, as the LAST collective step of the run
+    alt_exchange = None
+    if sharded and world > 1 and not args.structured and not args.no_alt_exchange:
+        if rank == 0 and out is not None:
+            print("bench.py: headline so far: %s" % json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}), file=sys.stderr, flush=True)
+        try:
+            r = run_mode(False, args.steps, args.warmup, 0, repeats=0, control_step=False, fatal=False, alt=True)
+            alt_exchange = r["alt_exchange"]
+        except AgreedFailure as e:
+            alt_exchange = {"error": "AgreedFailure: %s" % e}
+        except Exception as e:   # noqa: BLE001
+            die("the one-shot exchange pass failed on this rank only (%s: %s)" % (type(e).__name__, e))
     # The replay path, timed: the feasible-by-construction workloads never trip the soft-constraint thresholds, so their batches
     # always take the optimistic path once.  Here the ORIGINAL data of the 31-scenario tree (random bounds: infeasible) with small
     # penalties -- the tree-global distances exceed gamma / lambda -- run one optimistic batch (checkpoint, 20 iterations with the
@@ -750,6 +823,8 @@ def main():
         except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
             replay = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
+        if alt_exchange is not None:
+            out["alt_exchange"] = alt_exchange
         if replay is not None:
             out["replay_path"] = replay
         if entries:

@@ -1402,7 +1402,8 @@ struct Ctx : CtxBase {
     unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }
     int peer_inbox_create(void *handle64) override {
         RN_CHECK(handle64, RN_E_ARG, "rn_peer_inbox_create: null output");
-        RN_CHECK(cutStage > 0 && nranks >= 2 && nranks <= PEER_MAX, RN_E_STATE, "rn_peer_inbox_create: a sharded context of 2 .. 16 ranks is required");
+        // (one rank: the context writes to and reads from its own inbox -- what a rank executes except the wire, for timing runs)
+        RN_CHECK(cutStage > 0 && nranks >= 1 && nranks <= PEER_MAX, RN_E_STATE, "rn_peer_inbox_create: a sharded context (cut stage set) of at most 16 ranks is required");
         RN_HIP(hipSetDevice(device));
         if (!d_inbox) {
             inboxBytes = (size_t)2 * nranks * peer_slots() * PeerPk<T>::N * sizeof(unsigned long long);

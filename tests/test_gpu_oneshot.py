@@ -20,7 +20,8 @@ WORKER = os.path.join(ROOT, "tests", "oneshot_worker.py")
 
 
 def run(args, env_extra=None, timeout=600, launcher=None):
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", RAPIDNET_ONESHOT_TIMEOUT_MS="4000", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", RAPIDNET_ONESHOT_TIMEOUT_MS="4000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     cmd = (launcher or [sys.executable]) + [WORKER] + [str(a) for a in args]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     assert p.returncode == 0, "rc %d\n%s\n%s" % (p.returncode, p.stdout.decode()[-2000:], p.stderr.decode()[-4000:])
