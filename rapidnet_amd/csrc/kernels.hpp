@@ -56,9 +56,11 @@ struct IterState {         // device-resident scalars of the APG loop
 // peer's packets of s + 1, which every peer wrote after it had finished reading s.  The reader's spin is bounded by the wall
 // clock; on time-out it raises IterState::commFail and carries on with what it has (the grid always drains).
 constexpr int PEER_MAX = 16;
-struct PeerTable {
+struct PeerTable {                         // travels BY VALUE in the kernel arguments (a table in memory would put two dependent
+                                           // round trips in front of the first packet load of the launch's critical workgroup)
     unsigned long long *inbox[PEER_MAX];   // every rank's inbox as mapped into THIS process (own rank: the local allocation)
-    int nranks, rank;
+    unsigned long long *own;               // = inbox[rank]
+    int nranks, rank;                      // nranks == 0: the one-shot exchange is off for this launch
     unsigned int slots;                    // elements per source rank and buffer: cut parents x (nv + 2 nx) + 2 (the dist^2 tail)
     unsigned long long timeoutTicks;       // bound of a reader's wait, in ticks of the 100 MHz wall clock
 };
@@ -66,64 +68,175 @@ template <typename T> struct PeerPk;
 template <> struct PeerPk<double> { static constexpr int N = 2; };
 template <> struct PeerPk<float> { static constexpr int N = 1; };
 template <typename T>
+__device__ __forceinline__ size_t peer_word(int nranks, unsigned int slots, unsigned int seq, int src, unsigned int idx) {
+    return (((size_t)(seq & 1u) * (size_t)nranks + (size_t)src) * slots + idx) * PeerPk<T>::N;
+}
+template <typename T>
 __device__ __forceinline__ size_t peer_word(const PeerTable &p, unsigned int seq, int src, unsigned int idx) {
-    return (((size_t)(seq & 1u) * (size_t)p.nranks + (size_t)src) * p.slots + idx) * PeerPk<T>::N;
+    return peer_word<T>(p.nranks, p.slots, seq, src, idx);
 }
 __device__ __forceinline__ void peer_push(const PeerTable &p, unsigned int seq, unsigned int idx, double v) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)seq << 32;
     const unsigned long long lo = (bits & 0xffffffffull) | tag, hi = (bits >> 32) | tag;
     const size_t wd = peer_word<double>(p, seq, p.rank, idx);
-    for (int r = 0; r < p.nranks; r++) {
-        __hip_atomic_store(p.inbox[r] + wd, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(p.inbox[r] + wd + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+#pragma unroll
+    for (int r = 0; r < PEER_MAX; r++)      // static indices: the table lives in the kernel-argument registers
+        if (r < p.nranks) {
+            __hip_atomic_store(p.inbox[r] + wd, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.inbox[r] + wd + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 }
 __device__ __forceinline__ void peer_push(const PeerTable &p, unsigned int seq, unsigned int idx, float v) {
     const unsigned long long pk = (unsigned long long)__float_as_uint(v) | ((unsigned long long)seq << 32);
     const size_t wd = peer_word<float>(p, seq, p.rank, idx);
-    for (int r = 0; r < p.nranks; r++) __hip_atomic_store(p.inbox[r] + wd, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// one element of one source rank out of this rank's inbox: polls until its packets carry `seq` (false: timed out)
-__device__ __forceinline__ bool peer_poll(const unsigned long long *w, unsigned int seq, long long t0, unsigned long long limit, unsigned long long &pk) {
-    for (;;) {
-        pk = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned int)(pk >> 32) == seq) return true;
-        if ((unsigned long long)(wall_clock64() - t0) > limit) return false;
-        __builtin_amdgcn_s_sleep(2);
-    }
+#pragma unroll
+    for (int r = 0; r < PEER_MAX; r++)
+        if (r < p.nranks) __hip_atomic_store(p.inbox[r] + wd, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // dst[i] = sum over the ranks, in ascending rank order, of element i of exchange `seq`, for i in [i0, i1): called by a whole
-// workgroup (tid / nthreads); the caller makes the values visible to itself (fence + barrier) before it reads dst back
+// workgroup (tid / nthreads); the caller makes the values visible to itself (fence + barrier) before it reads dst back.
+// ONE workgroup pulls the whole payload of all ranks through its CU (8 ranks x 3 793 elements x 16 B = 485 KB for the 8-way split
+// of the 17 x 29 tree), so two things decide its time.  Memory-level parallelism: a thread works in passes of PEER_PASS
+// (element, rank) pairs -- all ranks of one or several of its elements (elements are dealt to the threads interleaved: consecutive
+// lanes read consecutive 16 bytes of one rank's slice) -- and the next pass's loads are requested before the current pass is
+// looked at (two register sets).  And CODE SIZE: this code runs once per launch, cold (the streaming kernel in front has swept
+// the instruction cache's backing store too): a first version that unrolled 32 pairs with a polling loop inlined per packet was
+// 12 000 instructions and cost 10 us of instruction fetch for 1.4 us of loads (tools/probes/probe_uncached.hip).  So: one loop, two
+// passes per trip, and ONE retry block per pass -- a pass with a packet that has not arrived (or a stale first look) is re-read as a
+// whole with system-scope atomic loads until it is complete or the time is up.
+constexpr int PEER_PASS = 16;
 template <typename T>
-__device__ __attribute__((noinline)) void peer_gather(const PeerTable *pt, unsigned int seq, T *dst, int i0, int i1, int tid, int nthreads, IterState *st) {
-    const PeerTable p = *pt;
-    const unsigned long long *in = p.inbox[p.rank];
+struct PeerPass { unsigned long long pk[PEER_PASS][PeerPk<T>::N]; };
+template <typename T>
+__device__ __forceinline__ void peer_pass_load(PeerPass<T> &b, const unsigned long long *base, unsigned int ib, unsigned int i1, int R, int live,
+                                               unsigned int slotsN, unsigned int estep, unsigned int nthreads, bool atomicLoads) {
+    constexpr int N = PeerPk<T>::N;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    unsigned int off = ib * N, i = ib;
+    int r = 0;
+#pragma unroll
+    for (int q = 0; q < PEER_PASS; q++) {
+        if (q < live && i < i1) {
+            if (atomicLoads) {
+#pragma unroll
+                for (int h = 0; h < N; h++) b.pk[q][h] = __hip_atomic_load(base + off + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (N == 2) {
+                const ull2 v = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(base + off));
+                b.pk[q][0] = v[0]; b.pk[q][N - 1] = v[1];
+            } else b.pk[q][0] = __builtin_nontemporal_load(base + off);
+        }
+        if (++r == R) { r = 0; off += estep - (unsigned int)(R - 1) * slotsN; i += nthreads; } else off += slotsN;
+    }
+}
+template <typename T>
+__device__ __forceinline__ bool peer_pass_complete(const PeerPass<T> &b, unsigned int ib, unsigned int i1, int R, int live, unsigned int nthreads, unsigned int seq) {
+    constexpr int N = PeerPk<T>::N;
+    unsigned int i = ib;
+    int r = 0;
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < PEER_PASS; q++) {
+        if (q < live && i < i1) {
+#pragma unroll
+            for (int h = 0; h < N; h++) all = all && (unsigned int)(b.pk[q][h] >> 32) == seq;
+        }
+        if (++r == R) { r = 0; i += nthreads; }
+    }
+    return all;
+}
+template <typename T>
+__device__ __forceinline__ void peer_pass_sum(const PeerPass<T> &b, T *dst, unsigned int ib, unsigned int i1, int R, int live, unsigned int nthreads) {
+    constexpr int N = PeerPk<T>::N;
+    unsigned int i = ib;
+    int r = 0;
+    T s = 0;
+#pragma unroll
+    for (int q = 0; q < PEER_PASS; q++) {
+        if (q < live && i < i1) {
+            T v;
+            if (N == 2) v = (T)__hiloint2double((int)(unsigned int)b.pk[q][N - 1], (int)(unsigned int)b.pk[q][0]);
+            else v = (T)__uint_as_float((unsigned int)b.pk[q][0]);
+            s = (r == 0) ? v : s + v;
+            if (r == R - 1) dst[i] = s;
+        }
+        if (++r == R) { r = 0; i += nthreads; }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void peer_gather(const PeerTable &pt, unsigned int seq, T *dst, int i0, int i1s, int tid, int nthreadsS, IterState *st) {
+    static_assert(PEER_PASS >= PEER_MAX, "all ranks of an element are requested together");
+    constexpr int N = PeerPk<T>::N;
+    const int R = pt.nranks;
+    const unsigned int slotsN = pt.slots * N;                         // words between two ranks' slices (32-bit offsets: an inbox is < 2^31 words)
+    const unsigned long long limit = pt.timeoutTicks;
+    const unsigned long long *base = pt.own + (size_t)(seq & 1u) * (size_t)R * slotsN;
+    const long long t0 = wall_clock64();
+    const int CH = PEER_PASS / R, live = CH * R;                      // elements of a thread per pass; (element, rank) pairs per pass
+    const unsigned int nthreads = (unsigned int)nthreadsS, i1 = (unsigned int)i1s, estep = nthreads * N, step = (unsigned int)CH * nthreads;
+    bool ok = true;
+    PeerPass<T> A;
+    unsigned int ib = (unsigned int)(i0 + tid);
+    PeerPass<T> B;
+    if (ib < i1) peer_pass_load<T>(A, base, ib, i1, R, live, slotsN, estep, nthreads, false);
+    // r, the pass bounds and the offsets' increments are wave-uniform (scalar unit); a lane only adds, compares and moves
+    while (ib < i1) {
+#define RN_PEER_TRIP(cur, nxt)                                                                                                                \
+        {                                                                                                                                     \
+            if (ib + step < i1) peer_pass_load<T>(nxt, base, ib + step, i1, R, live, slotsN, estep, nthreads, false);   /* next pass on its way */ \
+            while (!peer_pass_complete<T>(cur, ib, i1, R, live, nthreads, seq)) {   /* rare: a peer is late (or the first look was stale) */   \
+                if ((unsigned long long)(wall_clock64() - t0) > limit) { ok = false; break; }                                                    \
+                __builtin_amdgcn_s_sleep(4);                                                                                                     \
+                peer_pass_load<T>(cur, base, ib, i1, R, live, slotsN, estep, nthreads, true);                                                   \
+            }                                                                                                                                 \
+            peer_pass_sum<T>(cur, dst, ib, i1, R, live, nthreads);                                                                            \
+            ib += step;                                                                                                                       \
+        }
+        RN_PEER_TRIP(A, B)
+        if (ib < i1) RN_PEER_TRIP(B, A)
+#undef RN_PEER_TRIP
+    }
+    if (!ok) st->commFail = 1;
+}
+// The small form, for callers whose threads own one element each and have no registers to spare (k_up_crown: 1 024-thread
+// workgroups, one workgroup per cut parent): four ranks of an element at a time with system-scope atomic loads (always a fresh
+// look), a packet that has not arrived is polled on the spot.  nranks / 4 round trips instead of one -- microseconds on launches
+// that are not on the Barcelona shards' critical path (those gather in k_gemm_vlv, above).
+template <typename T>
+__device__ __forceinline__ void peer_gather_small(const PeerTable &pt, unsigned int seq, T *dst, int i0, int i1, int tid, int nthreads, IterState *st) {
+    constexpr int N = PeerPk<T>::N;
+    const int R = pt.nranks;
+    const unsigned int slotsN = pt.slots * N;
+    const unsigned long long limit = pt.timeoutTicks;
+    const unsigned long long *base = pt.own + (size_t)(seq & 1u) * (size_t)R * slotsN;
     const long long t0 = wall_clock64();
     bool ok = true;
     for (int i = i0 + tid; i < i1; i += nthreads) {
         T s = 0;
-        for (int r0 = 0; r0 < p.nranks; r0 += 4) {
-            unsigned long long pk[4][PeerPk<T>::N];
-            // first look at four ranks' packets at once (one round trip when everything has arrived) ...
+        for (int r0 = 0; r0 < R; r0 += 4) {
+            unsigned long long pk[4][N];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int r = r0 + u < p.nranks ? r0 + u : p.nranks - 1;
-                const unsigned long long *w = in + peer_word<T>(p, seq, r, (unsigned int)i);
+                const int r = r0 + u < R ? r0 + u : R - 1;
+                const unsigned long long *w = base + (size_t)r * slotsN + (size_t)i * N;
 #pragma unroll
-                for (int h = 0; h < PeerPk<T>::N; h++) pk[u][h] = __hip_atomic_load(w + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int h = 0; h < N; h++) pk[u][h] = __hip_atomic_load(w + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            // ... then wait for the ones that have not
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (r0 + u >= p.nranks) break;
-                const unsigned long long *w = in + peer_word<T>(p, seq, r0 + u, (unsigned int)i);
+                if (r0 + u < R) {
+                    const unsigned long long *w = base + (size_t)(r0 + u) * slotsN + (size_t)i * N;
 #pragma unroll
-                for (int h = 0; h < PeerPk<T>::N; h++)
-                    if ((unsigned int)(pk[u][h] >> 32) != seq) ok = peer_poll(w + h, seq, t0, p.timeoutTicks, pk[u][h]) && ok;
-                T v;
-                if (PeerPk<T>::N == 2) v = (T)__longlong_as_double((long long)((pk[u][0] & 0xffffffffull) | (pk[u][PeerPk<T>::N - 1] << 32)));
-                else v = (T)__uint_as_float((unsigned int)pk[u][0]);
-                s = (r0 + u == 0) ? v : s + v;
+                    for (int h = 0; h < N; h++)
+                        while ((unsigned int)(pk[u][h] >> 32) != seq) {
+                            if ((unsigned long long)(wall_clock64() - t0) > limit) { ok = false; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                            pk[u][h] = __hip_atomic_load(w + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    T v;
+                    if (N == 2) v = (T)__hiloint2double((int)(unsigned int)pk[u][N - 1], (int)(unsigned int)pk[u][0]);
+                    else v = (T)__uint_as_float((unsigned int)pk[u][0]);
+                    s = (r0 + u == 0) ? v : s + v;
+                }
             }
         }
         dst[i] = s;
@@ -166,7 +279,7 @@ struct SweepArgs {
     // one-shot exchange (nullptr: the payload is all-reduced by a collective between the launches): the kernels that produce the
     // cut parents' local sums push them to every peer under sequence number peerSeq, the crown kernels gather and add them;
     // peerTail: the payload's 2-element dist^2 tail travels with this exchange (the previous iteration's bookkeeping rode along)
-    const PeerTable *peer; unsigned int peerSeq; int peerTail;
+    PeerTable peer; unsigned int peerSeq; int peerTail;
     // 0: the primal iterates x, u, v are not stored by this sweep (inner iterations of a device-resident batch: only Hx feeds
     // the dual update; the last iteration of every batch and every step-wise call store them)
     int writePrimal;
@@ -636,7 +749,7 @@ template <typename T>
 __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, T *out, int nParents, int lanesPer, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
         if (threadIdx.x >= ELT_THREADS) return;      // the bookkeeping is written for ELT_THREADS threads
-        finalize_optimistic_body<T>(fin, a.peer, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
+        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -708,7 +821,7 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
         T sum = 0;
         for (int c = 0; c < nc; c++) sum += sh[c * w + tt];
         out[(size_t)blockIdx.x * w + tt] = sum;
-        if (a.peer) peer_push(*a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)tt, sum);   // one-shot exchange: straight to every peer
+        if (a.peer.nranks > 0) peer_push(a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)tt, sum);   // one-shot exchange: straight to every peer
     }
 }
 // Crown region (stages < c*), one node: children are summed explicitly (loads batched CHAIN_PF at a time).
@@ -923,7 +1036,8 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
 }
 // one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
 // loads of a node are in flight at once, partial sums are folded through LDS
-template <typename T>
+// ONESHOT: the instantiation that takes the all-reduced sums out of the one-shot exchange's inbox (the other one is unchanged by it)
+template <typename T, bool ONESHOT = false>
 __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh = reinterpret_cast<T *>(smem_raw);            // parts x w
@@ -932,11 +1046,14 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
-    if (presummed && a.peer) {   // one-shot exchange: this node's all-reduced sums (workgroup 0: the dist^2 tail as well) come out of the inbox
+    if (ONESHOT && presummed && a.peer.nranks > 0) {   // one-shot exchange: this node's all-reduced sums (workgroup 0: the dist^2 tail as well) come out of the inbox
         T *cs = const_cast<T *>(a.cutSums);
         IterState *st = reinterpret_cast<IterState *>(a.iterState);
-        peer_gather<T>(a.peer, a.peerSeq, cs, pos * w, (pos + 1) * w, threadIdx.x, CROWN_THREADS, st);
-        if (blockIdx.x == 0 && a.peerTail) { const int nP = a.tr.stageCum[stage + 1] - a.tr.stageCum[stage]; peer_gather<T>(a.peer, a.peerSeq, cs, nP * w, nP * w + 2, threadIdx.x, CROWN_THREADS, st); }
+        peer_gather_small<T>(a.peer, a.peerSeq, cs, pos * w, (pos + 1) * w, threadIdx.x, CROWN_THREADS, st);
+        if (blockIdx.x == 0 && a.peerTail && threadIdx.x < 64) {   // (one wave: the 2-element dist^2 tail)
+            const int nP = a.tr.stageCum[stage + 1] - a.tr.stageCum[stage];
+            peer_gather_small<T>(a.peer, a.peerSeq, cs, nP * w, nP * w + 2, threadIdx.x, 64, st);
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -996,7 +1113,7 @@ constexpr int CUT_THREADS = 256;   // = ELT_THREADS (the bookkeeping block's red
 template <typename T>
 __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a, T *out, int nParents, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
-        finalize_optimistic_body<T>(fin, a.peer, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
+        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
         return;
     }
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
@@ -1012,7 +1129,7 @@ __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a
             for (int j = 0; j < CHAIN_PF; j++) if (c + j < nc) s += r[j];
         }
         out[(size_t)blockIdx.x * w + t] = s;
-        if (a.peer) peer_push(*a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)t, s);
+        if (a.peer.nranks > 0) peer_push(a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)t, s);
     }
 }
 
@@ -1404,8 +1521,13 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
-template <typename T, bool PIPE>
-__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int crownScratch) {
+// ONESHOT: the instantiation whose crown workgroups take the all-reduced sums out of the one-shot exchange's inbox (cutLds > 0:
+// into an LDS array of that many values behind the crown scratch -- nobody else needs them, and a round trip through global
+// memory would sit on the critical path of the launch's critical workgroup); the other instantiation is unchanged by it
+template <typename T, bool PIPE, bool ONESHOT = false>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a0, int foldRoot, int crownScratch,
+                                                                  int cutLds = 0) {
+    SweepArgs<T> a = a0;
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
     T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
@@ -1420,12 +1542,21 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
         const int lo = s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16;
         const int hi = e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16;
-        if (a.peer && (blockIdx.x == 0 || lo < hi)) {   // one-shot exchange: the workgroups that use the all-reduced sums take them out of the inbox
-            T *cs = const_cast<T *>(a.cutSums);
-            IterState *st = reinterpret_cast<IterState *>(a.iterState);
+        if (ONESHOT && a.peer.nranks > 0 && (blockIdx.x == 0 || lo < hi)) {   // one-shot exchange: the workgroups that use the all-reduced sums take them out of the inbox
             const int w = a.nv + 2 * a.nx, nP = e1 - s1;
-            if (blockIdx.x == 0) peer_gather<T>(a.peer, a.peerSeq, cs, 0, nP * w + (a.peerTail ? 2 : 0), threadIdx.x, blockDim.x, st);
-            else peer_gather<T>(a.peer, a.peerSeq, cs, (lo - s1) * w, (hi - s1) * w, threadIdx.x, blockDim.x, st);
+            T *cs = const_cast<T *>(a.cutSums);
+            if (cutLds >= nP * w + 2) {      // gathered into LDS; the crown step below reads them from there (generic pointers: flat loads)
+                cs = sB + 16 * (SB + SV) + crownScratch;
+                a.cutSums = cs;
+                if (a.distTail) {            // the dist^2 tail: gathered with the payload, or (first iteration of a batch: nobody sent one) what d_cut holds
+                    if (!a.peerTail && threadIdx.x < 2) cs[nP * w + threadIdx.x] = a0.distTail[threadIdx.x];
+                    a.distTail = cs + nP * w;
+                }
+            }
+            IterState *st = reinterpret_cast<IterState *>(a.iterState);
+            // workgroup 0: everything (the root folds all the stage's nodes) and the tail; the others: the nodes of their own slab
+            const int g0 = blockIdx.x == 0 ? 0 : (lo - s1) * w, g1 = blockIdx.x == 0 ? nP * w + (a.peerTail ? 2 : 0) : (hi - s1) * w;
+            peer_gather<T>(a.peer, a.peerSeq, cs, g0, g1, threadIdx.x, blockDim.x, st);
             __threadfence_block();
             __syncthreads();
         }

@@ -935,10 +935,12 @@ struct Ctx : CtxBase {
         if (const char *e = std::getenv("RAPIDNET_CROWN_LDS")) { if (std::atoi(e) == 0) return 0; }   // tuning runs
         const size_t want = (size_t)h_childCount[0] * (d.nv + 2 * d.nx), bytes = ldsSlab + want * sizeof(T);
         if (bytes > 160 * 1024) return 0;
-        if (bytes > 64 * 1024) {
+        {   // (always: the one-shot instantiations add the cut payload to their LDS)
             // the attribute belongs to the function, not to this context: always the device's whole LDS, never a smaller value later
             if (hipFuncSetAttribute((const void *)k_gemm_vlv<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_gemm_vlv<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 return 0;
             }
@@ -974,8 +976,17 @@ struct Ctx : CtxBase {
             // launch's critical path -- fills its own slab in LDS instead of draining its stores and reading them back
             const int scratch = foldRoot == 2 ? crown_scratch(lds) : 0;
             const size_t ldsAll = lds + (size_t)scratch * sizeof(T);
-            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
-            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
+            if (a.peer.nranks > 0 && foldRoot == 2) {   // one-shot exchange: the instantiation whose crown workgroups gather the peers' packets
+                // ... into LDS behind the crown scratch when the workgroup may have that much (crown_scratch() has raised the limit)
+                int cutVals = (int)peer_slots();
+                if (scratch == 0 || ldsAll + (size_t)cutVals * sizeof(T) > 160 * 1024) cutVals = 0;
+                const size_t ldsOne = ldsAll + (size_t)cutVals * sizeof(T);
+                if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true, true>), dim3(nSlabs), dim3(64 * nw), ldsOne, stream, gV, gL, SB, SV, a, foldRoot, scratch, cutVals);
+                else hipLaunchKernelGGL((k_gemm_vlv<T, false, true>), dim3(nSlabs), dim3(64 * nw), ldsOne, stream, gV, gL, SB, SV, a, foldRoot, scratch, cutVals);
+                return;
+            }
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch, 0);
+            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch, 0);
             return;
         }
 #endif
@@ -1019,7 +1030,7 @@ struct Ctx : CtxBase {
         const bool oneShot = transport == 1 && peerReady && inBatch && phase == 0 && a.cutSums != nullptr && hessianInput == nullptr;
         if (oneShot) {
             if (++peerSeq == 0) ++peerSeq;      // 0 is the "never written" tag
-            a.peer = d_peer; a.peerSeq = peerSeq; a.peerTail = (pendingFin && carryTail) ? 1 : 0;
+            a.peer = h_peer; a.peerSeq = peerSeq; a.peerTail = (pendingFin && carryTail) ? 1 : 0;
         }
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
         auto nk = [&](int k) { return h_stageCum[k + 1] - h_stageCum[k]; };
@@ -1087,7 +1098,8 @@ struct Ctx : CtxBase {
                     if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
                     if (foldRoot == 2) continue;                       // done by the v / Lv launch
                 }
-                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
+                if (a.peer.nranks > 0 && a.cutSums && k == cutStage - 1) hipLaunchKernelGGL((k_up_crown<T, true>), dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
+                else hipLaunchKernelGGL((k_up_crown<T, false>), dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
@@ -1393,8 +1405,7 @@ struct Ctx : CtxBase {
     // either side may hold a packet back), exported as a hipIpcMemHandle_t; peers map it and write into it from their kernels.
     unsigned long long *d_inbox = nullptr;
     size_t inboxBytes = 0;
-    PeerTable h_peer{};
-    PeerTable *d_peer = nullptr;
+    PeerTable h_peer{};   // handed to the kernels by value (SweepArgs::peer)
     std::vector<void *> ipcOpened;
     bool peerReady = false, inBatch = false;
     int transport = 0;            // 0: the cut payload is all-reduced by the collective; 1: one-shot peer writes (inside rn_apg_iterate batches)
@@ -1423,8 +1434,7 @@ struct Ctx : CtxBase {
         double ms = 2000.0;   // a reader waits at most this long for a peer's packets, then gives up with RN_E_COMM
         if (const char *e = std::getenv("RAPIDNET_ONESHOT_TIMEOUT_MS")) { const double v = std::atof(e); if (v > 0) ms = v; }
         h_peer.timeoutTicks = (unsigned long long)(ms * 1e5);   // 100 MHz wall clock
-        if (!d_peer) { if (int rc = dalloc(&d_peer, 1)) return rc; }
-        RN_HIP(hipMemcpy(d_peer, &h_peer, sizeof h_peer, hipMemcpyHostToDevice));
+        h_peer.own = h_peer.inbox[rank];
         peerReady = true; peerSeq = 0;
         return RN_OK;
     }

@@ -12,8 +12,7 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "rapidnet_amd", "librapidnet_hip_kt.so")
 from rapidnet_amd import build  # noqa: E402
 
-if not os.path.exists(LIB):
-    build.build_hip(force=True, defines=["RN_KTIMING=1"], out=LIB)
+build.build_hip(defines=["RN_KTIMING=1"], out=LIB)      # (re)built when its sources have changed
 os.environ["RAPIDNET_LIB"] = LIB
 import numpy as np  # noqa: E402
 from rapidnet_amd import capi, partition, synth  # noqa: E402
@@ -30,6 +29,9 @@ s = capi.Solver(problem["network"], tree, problem["config"], **s_args)
 if W > 0:
     s.commInit(0, 1, capi.comm_unique_id())
     s.setCutStage(cut, partition.cut_children_moments(problem["tree"], cut))
+if W > 0 and len(sys.argv) > 2 and sys.argv[2] == "oneshot":     # the one-shot exchange (the rank writes to and reads from its own inbox)
+    s.peerInboxConnect([s.peerInboxCreate()])
+    s.setExchangeTransport(1)
 s.initialiseSmpcController(dh, ah)
 s.apgReset()
 s.apgIterate(20, history=False)
