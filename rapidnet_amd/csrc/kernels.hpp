@@ -263,6 +263,9 @@ struct SweepArgs {
     int structured;   // 1: no per-node blocks; m2_i comes from a shared-operator GEMM, m1_i is folded into the v GEMM
     T *ab;            // structured: [node][nx+nu]  a_i = F_i' xi_i ; b_i = G_i' psi_i
     T *my;            // [node][2nv]  m1_i = Phi xi + Psi psi ; m2_i = D xi + Ftil psi
+    // k_stream_gemv's split last round (StreamSplit): the nodes >= splitFirst -- all in the last STREAM_SPLIT_STAGES stages of the chain
+    // region -- have a second partial [m1; m2] in my2[node - splitFirst] that their consumers add (splitFirst = nodes: none)
+    const T *my2; int splitFirst;
     T *qa;            // [node][nx]   a_i = F_i' xi_i
     T *sk;            // [node][nv+nx] s_i = beta_i + sum_children rho_c ; kappa_i
     T *rkq;           // [node][nv+2nx] rho_i, kappa_i, q_i (kept for chain tops and crown nodes)
@@ -362,6 +365,7 @@ __device__ __forceinline__ void block_gemv_shared(const T *__restrict__ M, int r
 #define RN_STREAM_MINW 2
 #endif
 constexpr int STREAM_THREADS = RN_STREAM_THREADS;
+constexpr int STREAM_SPLIT_STAGES = 3;   // the split round of k_stream_gemv lies within the last this-many stages (the host checks)
 constexpr int STREAM_NLMAX = 4;   // slots per thread and span
 
 // ------------------------------------------------------------------------------------------------------
@@ -497,19 +501,40 @@ __device__ __forceinline__ T stream_qa_elem(T sp, T d0, T y0, T d1, T y1) {   //
     const T p = d1 * y1;
     return sp * fma_rn(d0, y0, p);
 }
+// The LAST, partial round of the launch is split by COLUMNS (StreamSplit): one workgroup alone can only pull what it has in flight
+// per memory round trip (~40 GB/s: 9.3 us for a 372 KB block however empty the machine is), and the launch times on 700 ... 1 844
+// blocks show it -- every started round costs ~9 us at once, then 28 ns per further block (tools/stream_vs_nodes.sh): 5.4 rounds =
+// 5 x 14.5 us + 11 us.  So the blocks of the last round (when it is at most half full) are each dealt to TWO workgroups: the first
+// takes the spans [0, spanHalf) -- whole columns, the contiguous first part of the block -- and stores its partial [m1; m2] where
+// it always goes, the second takes the rest and stores its partial in my2[block - first]; the consumers of the last stages add the
+// two (k_up_chain / k_up_chain_cut: m2; the v product's epilogue: m1).  (A split by ROWS -- disjoint outputs, no consumer
+// change -- was measured in round 3 and was slower: it reads 400-780-byte runs of every column.  More bytes in flight per
+// workgroup do not help either: spans of 10 instead of 5 per group spill and measured 89 -> 95 us.)
+template <typename T>
+struct StreamSplit {
+    int first;        // first block of the split round (= the number of blocks: no split)
+    int spanHalf;     // spans of the first half (a whole number of groups)
+    T *my2;           // [blocks - first][2 nv] partial sums of the second halves
+};
 template <typename T, int NL>
-__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0) {
+__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0, StreamSplit<T> sp) {
     typedef typename Slot<T>::type VT;
     constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny (+ G of zero padding is not needed: guarded reads)
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
     const int tid = threadIdx.x;
-    const int node = blockIdx.x;
+    // blocks [0, first): one workgroup each; from there on two workgroups per block (first half, second half)
+    const bool split = (int)blockIdx.x >= sp.first;
+    const int node = split ? sp.first + (((int)blockIdx.x - sp.first) >> 1) : (int)blockIdx.x;
+    const bool second = split && ((((int)blockIdx.x - sp.first) & 1) != 0);
     const int nx = a.nx, nv = a.nv, ny = a.ny, LD = a.LD;
     const int SPC = LD / VPL, spanSlots = G * SPC;
     const long long blockSlots = (long long)ny * SPC;
     const VT *__restrict__ Ab = reinterpret_cast<const VT *>(a.A + (size_t)node * a.strideA);
+    // this workgroup's spans: [span0, span1) of the block's ceil(ny / G)
+    const int spansAll = (ny + G - 1) / G;
+    const int span0 = second ? sp.spanHalf : 0, span1 = (split && !second) ? sp.spanHalf : spansAll;
     int off[NL], cj[NL];
     T msk[NL];
 #pragma unroll
@@ -525,17 +550,17 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     for (int j = 0; j < NL; j++)
 #pragma unroll
         for (int e = 0; e < VPL; e++) part[j][e] = 0;
-    const int nFull = ny / G;                    // spans made of G whole columns
+    const int nFull = (ny / G < span1 ? ny / G : span1) - span0;   // spans of this workgroup made of G whole columns
     const int nGroups = nFull / D;
     VT bufA[D][NL], bufB[D][NL];
 #define RN_LOADG(buf, g_)                                                                                              \
     _Pragma("unroll") for (int d = 0; d < D; d++)                                                                      \
         _Pragma("unroll") for (int j = 0; j < NL; j++)                                                                 \
-            buf[d][j] = __builtin_nontemporal_load(Ab + (size_t)((g_) * D + d) * spanSlots + off[j]);
+            buf[d][j] = __builtin_nontemporal_load(Ab + (size_t)(span0 + (g_) * D + d) * spanSlots + off[j]);
 #define RN_USEG(buf, g_)                                                                                               \
     _Pragma("unroll") for (int d = 0; d < D; d++)                                                                      \
         _Pragma("unroll") for (int j = 0; j < NL; j++) {                                                               \
-            const T yc = sh_y[((g_) * D + d) * G + cj[j]] * msk[j];                                                    \
+            const T yc = sh_y[(span0 + (g_) * D + d) * G + cj[j]] * msk[j];                                            \
             _Pragma("unroll") for (int e = 0; e < VPL; e++) part[j][e] += buf[d][j][e] * yc;                           \
         }
     // Prologue.  A wave's loads return in order, so everything the prologue needs is requested FIRST and the first group of
@@ -564,7 +589,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
         for (int d = 0; d < D; d++)
 #pragma unroll
             for (int j = 0; j < NL; j++) {
-                const int sl = d * spanSlots + off[j];
+                const int sl = (span0 + d) * spanSlots + off[j];
                 bufA[d][j] = __builtin_nontemporal_load(Ab + (sl < lastSlot ? sl : lastSlot));
             }
     }
@@ -575,9 +600,9 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     if (has0) sh_y[tid] = extrap_elem(w0a, w0b, wLn);
     for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = extrap_elem(wA[(size_t)node * ny + c], wB[(size_t)node * ny + c], wLn);
     __syncthreads();
-    // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)
+    // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)      (a split block: written by its first half)
     if (tid < nx) qa0 = stream_qa_elem(spn, dq0, sh_y[tid], dq1, sh_y[nx + tid]);
-    for (int t = tid + STREAM_THREADS; t < nx; t += STREAM_THREADS)
+    if (!second) for (int t = tid + STREAM_THREADS; t < nx; t += STREAM_THREADS)
         a.qa[(size_t)node * nx + t] = stream_qa_elem(spn, dyRow[t], sh_y[t], dyRow[nx + t], sh_y[nx + t]);
     if (nGroups > 0) {
         int g = 0;
@@ -600,7 +625,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
 #undef RN_LOADG
 #undef RN_USEG
     // remaining whole spans and the last, partial one (ny % G columns): guarded
-    for (int s = nGroups * D; s * G < ny; s++) {
+    for (int s = span0 + nGroups * D; s < span1; s++) {
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             const int c = s * G + cj[j];
@@ -618,12 +643,13 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
 #pragma unroll
             for (int e = 0; e < VPL; e++) sh_red[(size_t)off[j] * VPL + e] = part[j][e];
         }
-    if (tid < nx) stream_out(qa0, a.qa + (size_t)node * nx + tid);
+    if (tid < nx && !second) stream_out(qa0, a.qa + (size_t)node * nx + tid);
     __syncthreads();
+    T *const myOut = second ? sp.my2 + (size_t)(node - sp.first) * 2 * nv : a.my + (size_t)node * 2 * nv;
     for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {    // slot q of a span = column q / SPC, rows (q % SPC) * VPL ...
         T s = sh_red[r];
         for (int k = 1; k < G; k++) s += sh_red[(size_t)k * LD + r];
-        stream_out(s, a.my + (size_t)node * 2 * nv + r);
+        stream_out(s, myOut + r);
     }
 }
 
@@ -693,6 +719,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
     for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
         if (t < nv) {
             T rho = 0;
+            // the second partial m2 of the chain's last stages (k_stream_gemv's split last round; zero where a node was not split)
+            T mx[STREAM_SPLIT_STAGES];
+#pragma unroll
+            for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
+                const int kk = a.N - 1 - j >= top ? a.N - 1 - j : top;
+                const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                const bool has = a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
+                mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
+            }
             for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
                 T b[CHAIN_PF], m[CHAIN_PF];
 #pragma unroll
@@ -701,6 +736,10 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
+                }
+                if (k == a.N - 1 && a.splitFirst < a.nodes) {
+#pragma unroll
+                    for (int j = 0; j < STREAM_SPLIT_STAGES && j < CHAIN_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
@@ -768,6 +807,15 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
         const size_t nodeTop = (size_t)(c0 + slot);   // the chain's top node; every stage >= c* has K nodes
         if (t < nv) {
             T rho = 0;
+            // the second partial m2 of the chain's last stages (k_stream_gemv's split last round; zero where a node was not split)
+            T mx[STREAM_SPLIT_STAGES];
+#pragma unroll
+            for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
+                const int kk = a.N - 1 - j >= top ? a.N - 1 - j : top;
+                const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                const bool has = a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
+                mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
+            }
             for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
                 T b[CHAIN_PF], m[CHAIN_PF];
 #pragma unroll
@@ -776,6 +824,10 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
+                }
+                if (k == a.N - 1 && a.splitFirst < a.nodes) {
+#pragma unroll
+                    for (int j = 0; j < STREAM_SPLIT_STAGES && j < CHAIN_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
@@ -1152,7 +1204,16 @@ struct GemmArgs {
     const T *aux; int ldaux;     // EPI_V: my (m1 at aux + i*ldaux) ; EPI_Z: e
     const T *prob;
     int nodes;
+    // EPI_V: the nodes >= auxSplit have a second partial m1 in aux2[(i - auxSplit) * ldaux] (k_stream_gemv's split last round)
+    const T *aux2; int auxSplit;
 };
+// the auxiliary operand of node i, row r (EPI_V: m1, both partials of a split node added; EPI_Z: e)
+template <typename T, int EPI>
+__device__ __forceinline__ T gemm_aux(const GemmArgs<T> &g, int i, int r) {
+    T v = g.aux[(size_t)i * g.ldaux + r];
+    if (EPI == EPI_V && g.aux2 != nullptr && i >= g.auxSplit) v += g.aux2[(size_t)(i - g.auxSplit) * g.ldaux + r];
+    return v;
+}
 // MFMA 16x16x4 wrappers.  fp64: v_mfma_f64_16x16x4_f64, C/D row = (lane>>4) + 4*reg;  fp32: v_mfma_f32_16x16x4_f32,
 // C/D row = 4*(lane>>4) + reg;  both: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15], col = lane&15.
 template <typename T> struct Mfma16;
@@ -1240,7 +1301,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm_shared(GemmArgs<T> g) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int gr = r0 + t * 16 + Mfma16<T>::row(lane, reg);
-                auxv[t][reg] = g.aux[(size_t)node * g.ldaux + (gr < g.m ? gr : g.m - 1)];
+                auxv[t][reg] = gemm_aux<T, EPI>(g, node, gr < g.m ? gr : g.m - 1);
             }
     }
 #pragma unroll
@@ -1407,7 +1468,7 @@ __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T &scale, const GemmA
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int gr = (t0 + ts * j) * 16 + Mfma16<T>::row(lane, reg);
-            auxv[j][reg] = (EPI != EPI_LV) ? g.aux[(size_t)nodeC * g.ldaux + (gr < g.m ? gr : g.m - 1)] : (T)0;
+            auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
         }
 }
 // epilogue of one pass; sOut != nullptr also keeps the results in LDS ([16][SO], the B operand of a following product)
@@ -1659,7 +1720,7 @@ __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, 
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int gr = t * 16 + Mfma16<T>::row(lane, reg);
-                auxv[c][reg] = (EPI != EPI_LV) ? g.aux[(size_t)nodeC * g.ldaux + (gr < g.m ? gr : g.m - 1)] : (T)0;
+                auxv[c][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
             }
         }
         RN_KT(EPI == EPI_V ? 7 : 11);

@@ -509,7 +509,7 @@ struct Ctx : CtxBase {
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
         a.w = p_acc;
         if (lazyIn) { a.wy1 = p_upd; a.wy0 = p_xi; a.wLn = (T)h_lam[h_it]; }   // w_t is not in memory: derived from y_t, y_{t-1}
-        a.my = d_my; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
+        a.my = d_my; a.my2 = d_my2; a.splitFirst = (splitFirst >= 0 && !structured) ? splitFirst : d.nodes; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
         a.x = d_x; a.u = d_u; a.hx = d_hx;
         a.distTail = (carryTail && a.cutSums) ? d_cut + cut_tail_offset() : nullptr;
         a.thrX = penX / stepSize; a.thrS = penXs / stepSize; a.iterState = d_state;
@@ -684,6 +684,7 @@ struct Ctx : CtxBase {
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
             if (int rc = dalloc(&d_A, (size_t)d.nodes * strideA)) return rc;
         }
+        if (int rc = stream_split_setup()) return rc;
         RN_HIP(hipMemsetAsync(d_my, 0, (size_t)d.nodes * 2 * nv * sizeof(T), stream));   // structured mode never writes m1
         ExpandArgs<T> ea{};
         ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.strideA = strideA; ea.nodes = d.nodes;
@@ -828,17 +829,53 @@ struct Ctx : CtxBase {
         *G = bestG; *NL = bestNL;
     }
     size_t stream_lds(int G) const { return (size_t)(((ny + 3) & ~3) + (size_t)G * LD) * sizeof(T); }
+    // k_stream_gemv's split last round (kernels.hpp, StreamSplit): applies when the launch is longer than one round, its last round
+    // is at most half full (two workgroups per block still fit one round), every block of that round lies in the last
+    // STREAM_SPLIT_STAGES stages of the chain region (the consumers add the second partial there) and a block has at least two
+    // groups of spans.  splitFirst = nodes: no split.
+    T *d_my2 = nullptr;
+    int splitFirst = -1, splitSpanHalf = 0;
+    int stream_split_setup() {
+        if (splitFirst >= 0) return RN_OK;
+        splitFirst = d.nodes;
+        static const int mode = [] { const char *e = std::getenv("RAPIDNET_STREAM_SPLIT"); return e ? std::atoi(e) : 1; }();   // tuning runs: 0 = off
+        int G, NL;
+        stream_shape(&G, &NL);
+        const int D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE, groups = (ny / G) / D;
+        const int r = d.nodes % numCUs, cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
+        if (!mode || structured || d.nodes <= numCUs || r == 0 || 2 * r > numCUs || groups < 2) return RN_OK;
+        if (d.N - cs < STREAM_SPLIT_STAGES || r > STREAM_SPLIT_STAGES * K) return RN_OK;     // (the cut never moves the chain region's END)
+        if (int rc = dalloc(&d_my2, (size_t)r * 2 * d.nv)) return rc;
+        splitFirst = d.nodes - r;
+        splitSpanHalf = (groups + 1) / 2 * D;       // whole groups; the first half gets the odd one (the second also walks the ragged last span)
+        return RN_OK;
+    }
+    bool ensure_stream_lds() {   // > 64 KB of dynamic LDS needs the function attribute (once)
+        static const bool ok = [] {
+            bool all = true;
+            for (const void *fn : {(const void *)k_stream_gemv<T, 1>, (const void *)k_stream_gemv<T, 2>, (const void *)k_stream_gemv<T, 3>, (const void *)k_stream_gemv<T, 4>})
+                all = all && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            return all;
+        }();
+        return ok;
+    }
     int launch_stream(const SweepArgs<T> &a) {
         int G, NL;
         stream_shape(&G, &NL);
         RN_CHECK(NL <= STREAM_NLMAX, RN_E_ARG, "k_stream_gemv: more than 4096 values per operator column are not supported (2*nv too large)");
-        const size_t lds = stream_lds(G);
+        size_t lds = stream_lds(G);
+        {   // tuning runs: RAPIDNET_STREAM_ONE_PER_CU=1 asks for more than half of the CU's LDS, so that only one workgroup fits a CU
+            static const int one = [] { const char *e = std::getenv("RAPIDNET_STREAM_ONE_PER_CU"); return e ? std::atoi(e) : 0; }();
+            if (one && lds < 81 * 1024 && ensure_stream_lds()) lds = 81 * 1024;
+        }
         const int node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
+        const StreamSplit<T> sp{a.splitFirst, splitSpanHalf, d_my2};
+        const int grid = d.nodes + (d.nodes - a.splitFirst);      // two workgroups for every block of the split round
         switch (NL) {
-            case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
-            case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
-            case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
-            default: hipLaunchKernelGGL((k_stream_gemv<T, 4>), dim3(d.nodes), dim3(STREAM_THREADS), lds, stream, a, G, node0); break;
+            case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+            case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+            case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+            default: hipLaunchKernelGGL((k_stream_gemv<T, 4>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
         }
         return RN_OK;
     }
@@ -868,6 +905,7 @@ struct Ctx : CtxBase {
     template <int EPI>
     void launch_gemm(const T *Mp, int m, int k, const T *in, int ldin, T *out, int ldout, const T *aux, int ldaux) {
         GemmArgs<T> g{Mp, m, k, pad16(m), pad4(k), in, ldin, out, ldout, aux, ldaux, d_prob, d.nodes};
+        if (EPI == EPI_V && !structured && splitFirst >= 0 && splitFirst < d.nodes) { g.aux2 = d_my2; g.auxSplit = splitFirst; }   // k_stream_gemv's split last round
 #if RN_GEMM_SLAB
         const int SB = slab_stride(g.kp);
         const size_t lds = (size_t)16 * SB * sizeof(T);
@@ -956,7 +994,7 @@ struct Ctx : CtxBase {
     void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
-        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes};
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), d_v, nv, d_lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
