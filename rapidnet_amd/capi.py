@@ -36,7 +36,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport",
 ]
 
 
@@ -197,6 +197,7 @@ def load():
     lib.rn_debug_inject_allocation.argtypes = [vp, C.c_size_t]
     lib.rn_guard_report.argtypes = [dp]
     lib.rn_debug_guard_poke.argtypes = [vp, ip]
+    lib.rn_fbe_counters.argtypes = [vp, dp]
     lib.rn_peer_inbox_create.argtypes = [vp, dp]
     lib.rn_peer_inbox_connect.argtypes = [vp, dp, ip]
     lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
@@ -426,6 +427,12 @@ class Solver:
         t = C.c_double(0)
         self._check(self.lib.rn_line_search_ame_lbfgs_update(self.h, float(valueAmeY), C.byref(t)))
         return t.value
+
+    def fbeCounters(self):
+        """dict(searches, batches, sequential): how the line searches of the FBE / NAMA loops ran"""
+        out = np.zeros(3, dtype=np.int64)
+        self._check(self.lib.rn_fbe_counters(self.h, out.ctypes.data))
+        return dict(zip(("searches", "batches", "sequential"), (int(v) for v in out)))
 
     def lbfgsState(self, col=None, mem=None, H=None, rho=None):
         """get (no arguments) or set lbfgsBufferCol / Memory / Hessian / Rho; returns (col, mem, H, rho[size+1])."""

@@ -466,5 +466,225 @@ __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The line search, all candidates at once (SmpcController::computeLineSearchLbfgsUpdate / ...AmeLbfgsUpdate, SmpcController.cu:1272-1300,
+// 1381-1409).  The reference tries tau = 1, then moves on by -1/2, -1/4, ... while the FBE value does NOT exceed the reference value:
+// every trial is a cumulative update x += tau_k xdir, u += tau_k udir, w += tau_k dir, Hx += tau_k HxDir, a prox + residual pass and
+// computeValueFbe -- per trial 8 launches and two blocking read-backs here before (4-5 trials per iteration on the feasible
+// workloads: 0.7 of 3.0 ms).  The trials' states depend on nothing but the increments, so LS_K of them are evaluated by two passes
+// WITHOUT touching the state -- each candidate's state spelled as the sequential trial would have produced it (the same chain of
+// fused multiply-adds, k_trial_step's), each candidate's reductions accumulated in the element order of the sequential kernels --
+// one fold, one read-back; the host walks the reference's accept / stop logic over the values, applies the accepted number of
+// steps in one pass (k_trial_multi) and runs the ordinary prox + residual pass on the final state.  A candidate whose prox
+// distances trip the soft-constraint branch (never with the shipped penalties) sends the whole search down the sequential path.
+constexpr int LS_K = 6;          // candidates per evaluation batch (11 trials at most: two batches)
+constexpr int LS_EVAL = 4;       // partials per candidate of k_ls_eval: <w, res>, <res, res>, dist^2 box half, dist^2 safety half
+constexpr int LS_SCAL = 6;       // scalars per candidate after the fold: the four above, quad, lin
+template <typename T>
+struct LsTaus { T tau[LS_K]; int n; };
+template <typename T>
+__device__ __forceinline__ T trial_elem(T v, T tau, T d) { return v + tau * d; }      // k_trial_step's update of one element
+// the applied steps of a finished search, in ONE pass over the four index ranges (what `n` k_trial_step launches would leave)
+template <typename T>
+__global__ void k_trial_multi(TrialArgs<T> g, LsTaus<T> ts) {
+    const long long total = g.nX + g.nU + 2 * g.nY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        T *dst; const T *dir; long long k;
+        if (i < g.nY) { dst = g.w; dir = g.dir; k = i; }
+        else if (i < 2 * g.nY) { dst = g.hx; dir = g.hxdir; k = i - g.nY; }
+        else if (i < 2 * g.nY + g.nX) { dst = g.x; dir = g.xdir; k = i - 2 * g.nY; }
+        else { dst = g.u; dir = g.udir; k = i - 2 * g.nY - g.nX; }
+        T v = dst[k];
+        const T dd = dir[k];
+#pragma unroll
+        for (int c = 0; c < LS_K; c++) if (c < ts.n) v = trial_elem(v, ts.tau[c], dd);
+        dst[k] = v;
+    }
+}
+// prox + residual of every candidate, reduced: partials[block][candidate][LS_EVAL] (walks the range exactly as k_prox_res does)
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_ls_eval(DualArgs<T> a, const T *dir, const T *hxdir, LsTaus<T> ts, double *partials) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    __shared__ double sh[ELT_THREADS / 64][LS_K * LS_EVAL];
+    double acc[LS_K][LS_EVAL];
+#pragma unroll
+    for (int c = 0; c < LS_K; c++)
+#pragma unroll
+        for (int j = 0; j < LS_EVAL; j++) acc[c][j] = 0;
+    const int nx = a.nx, ny = a.ny;
+    const long long nvec = a.n / VN;
+    const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
+    int c0 = (int)((gid * VN) % ny);
+    const int cstep = (int)((stride * VN) % ny);
+    auto one = [&](T hx, T w, T lo, T hi, T dh, T dw, int col, bool counted) {
+#pragma unroll
+        for (int c = 0; c < LS_K; c++) {
+            if (c < ts.n) {
+                w = trial_elem(w, ts.tau[c], dw);
+                hx = trial_elem(hx, ts.tau[c], dh);
+                const T t = hx + a.invLambda * w;
+                const T z = t < lo ? lo : (t > hi ? hi : t);
+                const T r = hx - z;
+                if (counted) {
+                    const double diff = (double)(t - z);
+                    acc[c][0] += (double)w * (double)r;
+                    acc[c][1] += (double)r * (double)r;
+                    if (col < nx) acc[c][2] += diff * diff; else if (col < 2 * nx) acc[c][3] += diff * diff;
+                }
+            }
+        }
+    };
+    for (long long i = gid; i < nvec; i += stride) {
+        const VT hx = reinterpret_cast<const VT *>(a.hx)[i], w = reinterpret_cast<const VT *>(a.w)[i];
+        const VT lo = reinterpret_cast<const VT *>(a.lo)[i], hi = reinterpret_cast<const VT *>(a.hi)[i];
+        const VT dh = reinterpret_cast<const VT *>(hxdir)[i], dw = reinterpret_cast<const VT *>(dir)[i];
+        int c = c0;
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+            one(hx[e], w[e], lo[e], hi[e], dh[e], dw[e], c, a.countCrown || i * VN + e >= a.crownElems);
+            if (++c == ny) c = 0;
+        }
+        c0 += cstep; if (c0 >= ny) c0 -= ny;
+    }
+    for (long long i = nvec * VN + gid; i < a.n; i += stride)
+        one(a.hx[i], a.w[i], a.lo[i], a.hi[i], hxdir[i], dir[i], (int)(i % ny), a.countCrown || i >= a.crownElems);
+    // block fold: wave shuffle -> LDS -> one partial per block, candidate and quantity (dots_block_reduce's order)
+#pragma unroll
+    for (int c = 0; c < LS_K; c++)
+#pragma unroll
+        for (int j = 0; j < LS_EVAL; j++) {
+            double v = acc[c][j];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][c * LS_EVAL + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < LS_K * LS_EVAL) {
+        double s = 0;
+        for (int k = 0; k < ELT_THREADS / 64; k++) s += sh[k][threadIdx.x];
+        partials[(size_t)blockIdx.x * (LS_K * LS_EVAL) + threadIdx.x] = s;
+    }
+}
+// the two primal terms of computeValueFbe for every candidate: k_value_terms with the candidates' u spelled out.  A workgroup takes
+// LS_TILE nodes at a time; their du of all candidates sit in LDS ([candidate][nu][LS_TILE]) and thread t accumulates row t of W du
+// for all of them, so W is streamed from L2 once per tile, not once per tile and candidate.  partials[block][candidate][2]
+constexpr int LS_TILE = 8;
+constexpr int LS_RPW = LS_TILE / (VALUE_THREADS / 64);
+template <typename T>
+__global__ void __launch_bounds__(VALUE_THREADS) k_ls_value(const T *u, const T *udir, const T *prevU, const int *parent, const T *prob, const T *W, const T *alpha,
+                                                           int nu, int nodes, LsTaus<T> ts, double *partials, int firstNode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fbe_smem[];
+    T *du = reinterpret_cast<T *>(fbe_smem);            // [LS_K][nu][LS_TILE]
+    __shared__ double sq[VALUE_THREADS / 64][LS_K], sl[VALUE_THREADS / 64][LS_K];
+    double quad[LS_K], lin[LS_K];
+#pragma unroll
+    for (int c = 0; c < LS_K; c++) { quad[c] = 0; lin[c] = 0; }
+    const size_t cstride = (size_t)nu * LS_TILE;
+    const int tiles = (nodes + LS_TILE - 1) / LS_TILE;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int n0 = tile * LS_TILE;
+        const int cnt = nodes - n0 < LS_TILE ? nodes - n0 : LS_TILE;
+        {
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            int nodeOf[LS_RPW], par[LS_RPW];
+            T pb[LS_RPW];
+#pragma unroll
+            for (int r = 0; r < LS_RPW; r++) {
+                const int n = wave * LS_RPW + r;
+                nodeOf[r] = (n < cnt && n0 + n >= firstNode) ? n0 + n : -1;
+                const int nc = n < cnt ? n0 + n : n0;
+                par[r] = parent[nc]; pb[r] = prob[nc];
+            }
+            for (int t = lane; t < nu; t += 64) {
+                T un[LS_RPW], up[LS_RPW], dn[LS_RPW], dp[LS_RPW], al[LS_RPW];
+#pragma unroll
+                for (int r = 0; r < LS_RPW; r++) {
+                    const int nc = nodeOf[r] >= 0 ? nodeOf[r] : n0;
+                    un[r] = u[(size_t)nc * nu + t]; dn[r] = udir[(size_t)nc * nu + t];
+                    up[r] = par[r] < 0 ? prevU[t] : u[(size_t)par[r] * nu + t];
+                    dp[r] = par[r] < 0 ? (T)0 : udir[(size_t)par[r] * nu + t];
+                    al[r] = alpha[(size_t)nc * nu + t];
+                }
+#pragma unroll
+                for (int c = 0; c < LS_K; c++) {
+                    if (c < ts.n) {
+#pragma unroll
+                        for (int r = 0; r < LS_RPW; r++) {
+                            un[r] = trial_elem(un[r], ts.tau[c], dn[r]);
+                            if (par[r] >= 0) up[r] = trial_elem(up[r], ts.tau[c], dp[r]);     // the root's predecessor is prevU: not part of the iterate
+                            const bool live = nodeOf[r] >= 0;
+                            du[c * cstride + (size_t)t * LS_TILE + wave * LS_RPW + r] = live ? un[r] - up[r] : (T)0;
+                            if (live) lin[c] += (double)(pb[r] * un[r]) * (double)al[r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nu; t += VALUE_THREADS) {
+            T wd[LS_K][LS_TILE];
+#pragma unroll
+            for (int c = 0; c < LS_K; c++)
+#pragma unroll
+                for (int n = 0; n < LS_TILE; n++) wd[c][n] = 0;
+            for (int j0 = 0; j0 < nu; j0 += VALUE_JB) {      // the summation order over j is k_value_terms's
+                T wv[VALUE_JB];
+#pragma unroll
+                for (int jj = 0; jj < VALUE_JB; jj++) wv[jj] = W[t + (size_t)(j0 + jj < nu ? j0 + jj : nu - 1) * nu];
+#pragma unroll
+                for (int jj = 0; jj < VALUE_JB; jj++) {
+                    if (j0 + jj < nu) {
+#pragma unroll
+                        for (int c = 0; c < LS_K; c++) {
+                            if (c < ts.n) {
+                                const T *dj = du + c * cstride + (size_t)(j0 + jj) * LS_TILE;
+#pragma unroll
+                                for (int n = 0; n < LS_TILE; n++) wd[c][n] += wv[jj] * dj[n];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < LS_K; c++)
+                if (c < ts.n) {
+#pragma unroll
+                    for (int n = 0; n < LS_TILE; n++)
+                        if (n < cnt) quad[c] += (double)(prob[n0 + n] * du[c * cstride + (size_t)t * LS_TILE + n]) * (double)wd[c][n];
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < LS_K; c++) {
+        double q = quad[c], l = lin[c];
+        for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); l += __shfl_down(l, off); }
+        if ((threadIdx.x & 63) == 0) { sq[threadIdx.x >> 6][c] = q; sl[threadIdx.x >> 6][c] = l; }
+    }
+    __syncthreads();
+    if (threadIdx.x < LS_K) {
+        double a = 0, b = 0;
+        for (int k = 0; k < VALUE_THREADS / 64; k++) { a += sq[k][threadIdx.x]; b += sl[k][threadIdx.x]; }
+        partials[((size_t)blockIdx.x * LS_K + threadIdx.x) * 2 + 0] = a;
+        partials[((size_t)blockIdx.x * LS_K + threadIdx.x) * 2 + 1] = b;
+    }
+}
+// the fold of both partial arrays: workgroup j folds one (candidate, quantity) column in k_dots_finish's order
+// out[candidate][LS_SCAL] = {<w, res>, <res, res>, dist^2 box, dist^2 safety, quad, lin}
+__global__ void __launch_bounds__(ELT_THREADS) k_ls_finish(const double *evalPartials, int nbEval, const double *valPartials, int nbVal, double *out) {
+    __shared__ double sh[ELT_THREADS];
+    const int c = blockIdx.x / LS_SCAL, q = blockIdx.x % LS_SCAL;
+    double s = 0;
+    if (q < LS_EVAL) { for (int b = threadIdx.x; b < nbEval; b += ELT_THREADS) s += evalPartials[(size_t)b * (LS_K * LS_EVAL) + c * LS_EVAL + q]; }
+    else { for (int b = threadIdx.x; b < nbVal; b += ELT_THREADS) s += valPartials[((size_t)b * LS_K + c) * 2 + (q - LS_EVAL)]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = ELT_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c * LS_SCAL + q] = sh[0];
+}
+
 }  // namespace rn
 #endif

@@ -516,7 +516,10 @@ struct StreamSplit {
     int spanHalf;     // spans of the first half (a whole number of groups)
     T *my2;           // [blocks - first][2 nv] partial sums of the second halves
 };
-template <typename T, int NL>
+// SPLIT = false is the kernel as it always was (span0 = 0, every block one workgroup): the instantiation the unsplit launches run --
+// the whole 493-scenario tree among them, where the split gains nothing and the second code path would cost (same-box A/B against
+// the round-3 kernel: 605 instead of 590 us with one shared instantiation, whose register allocation let two workgroups share a CU)
+template <typename T, int NL, bool SPLIT>
 __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0, StreamSplit<T> sp) {
     typedef typename Slot<T>::type VT;
     constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
     const int tid = threadIdx.x;
     // blocks [0, first): one workgroup each; from there on two workgroups per block (first half, second half)
-    const bool split = (int)blockIdx.x >= sp.first;
+    const bool split = SPLIT && (int)blockIdx.x >= sp.first;
     const int node = split ? sp.first + (((int)blockIdx.x - sp.first) >> 1) : (int)blockIdx.x;
     const bool second = split && ((((int)blockIdx.x - sp.first) & 1) != 0);
     const int nx = a.nx, nv = a.nv, ny = a.ny, LD = a.LD;
@@ -534,7 +537,7 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     const VT *__restrict__ Ab = reinterpret_cast<const VT *>(a.A + (size_t)node * a.strideA);
     // this workgroup's spans: [span0, span1) of the block's ceil(ny / G)
     const int spansAll = (ny + G - 1) / G;
-    const int span0 = second ? sp.spanHalf : 0, span1 = (split && !second) ? sp.spanHalf : spansAll;
+    const int span0 = SPLIT ? (second ? sp.spanHalf : 0) : 0, span1 = (split && !second) ? sp.spanHalf : spansAll;
     int off[NL], cj[NL];
     T msk[NL];
 #pragma unroll
@@ -705,7 +708,8 @@ template <typename T>
 __device__ void finalize_optimistic_body(const FinArgs &fin, const PeerTable *peer = nullptr, unsigned int peerSeq = 0, unsigned int tailIdx = 0);
 // (the walk is spelled out twice, here and in k_up_chain_cut: shared through a device function it measured 8 us slower on the
 //  493-scenario tree -- 20.1 instead of 11.8 us)
-template <typename T>
+// SPLIT: the instantiation that adds the second partial m2 of k_stream_gemv's split last round (the other one is the walk as it always was)
+template <typename T, bool SPLIT = false>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
     if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
     const int s = blockIdx.x;                      // chain = position within the stage
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
             for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
                 const int kk = a.N - 1 - j >= top ? a.N - 1 - j : top;
                 const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                const bool has = a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
+                const bool has = SPLIT && a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
                 mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
             }
             for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
@@ -737,7 +741,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
                 }
-                if (k == a.N - 1 && a.splitFirst < a.nodes) {
+                if (SPLIT && k == a.N - 1) {
 #pragma unroll
                     for (int j = 0; j < STREAM_SPLIT_STAGES && j < CHAIN_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }
@@ -784,7 +788,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
 // 62 x 223 values back) disappears.  Children are added in ascending order, as k_cut_partial_sums does.  One more workgroup
 // (blockIdx = nParents, when fin.partials != nullptr) does the bookkeeping of the previous iteration's dual update.
 constexpr int UPCUT_THREADS = 1024;
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, T *out, int nParents, int lanesPer, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
         if (threadIdx.x >= ELT_THREADS) return;      // the bookkeeping is written for ELT_THREADS threads
@@ -813,7 +817,7 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
             for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
                 const int kk = a.N - 1 - j >= top ? a.N - 1 - j : top;
                 const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                const bool has = a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
+                const bool has = SPLIT && a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
                 mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
             }
             for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
@@ -825,7 +829,7 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
                     b[j] = beta[node * nv + t];
                     m[j] = my[node * 2 * nv + nv + t];
                 }
-                if (k == a.N - 1 && a.splitFirst < a.nodes) {
+                if (SPLIT && k == a.N - 1) {
 #pragma unroll
                     for (int j = 0; j < STREAM_SPLIT_STAGES && j < CHAIN_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }

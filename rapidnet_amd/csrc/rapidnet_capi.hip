@@ -185,6 +185,7 @@ struct CtxBase {
     virtual int peer_inbox_connect_local(CtxBase **, int) = 0;
     virtual unsigned long long *peer_inbox_ptr() = 0;
     virtual int set_exchange_transport(int) = 0;
+    virtual int fbe_counters(long *) = 0;
 };
 
 // ---- in-process stand-in for the communicator (rn_debug_local_group_*): `n` contexts of one process, one host thread each ----
@@ -835,6 +836,7 @@ struct Ctx : CtxBase {
     // groups of spans.  splitFirst = nodes: no split.
     T *d_my2 = nullptr;
     int splitFirst = -1, splitSpanHalf = 0;
+    bool streamTwoPerCU = false;
     int stream_split_setup() {
         if (splitFirst >= 0) return RN_OK;
         splitFirst = d.nodes;
@@ -843,7 +845,15 @@ struct Ctx : CtxBase {
         stream_shape(&G, &NL);
         const int D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE, groups = (ny / G) / D;
         const int r = d.nodes % numCUs, cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
-        if (!mode || structured || d.nodes <= numCUs || r == 0 || 2 * r > numCUs || groups < 2) return RN_OK;
+        // which instantiation the launches run: the one with the split's second code path allocates fewer registers (122 instead of
+        // 150), so two workgroups share a CU -- start-up and drain of the launch overlap better, the steady state is slower in fp64 and
+        // FASTER in fp32 (half-size blocks: the per-workgroup prologue and epilogue weigh double there).  Same-box A/B, one | two per
+        // CU, ms per iteration: fp64 whole tree (42 rounds) 0.6733 | 0.6854, 1/2 shard 0.3712 | 0.3736, 1/4 shard (10.7 rounds)
+        // 0.2101 | 0.2119, 1/8 shard (5.4 rounds) 0.1352 | 0.1318; fp32 whole tree 0.3838 | 0.3752 (the streaming kernel 313 -> 303 us
+        // = 0.84 of the HBM peak).  So: fp32 always, fp64 for launches of fewer than 8 rounds.
+        streamTwoPerCU = sizeof(T) == 4 || d.nodes < 8 * numCUs;
+        if (const char *e = std::getenv("RAPIDNET_STREAM_KERNEL")) streamTwoPerCU = std::atoi(e) != 0;   // tuning runs
+        if (!mode || !streamTwoPerCU || structured || d.nodes <= numCUs || r == 0 || 2 * r > numCUs || groups < 2) return RN_OK;
         if (d.N - cs < STREAM_SPLIT_STAGES || r > STREAM_SPLIT_STAGES * K) return RN_OK;     // (the cut never moves the chain region's END)
         if (int rc = dalloc(&d_my2, (size_t)r * 2 * d.nv)) return rc;
         splitFirst = d.nodes - r;
@@ -853,7 +863,8 @@ struct Ctx : CtxBase {
     bool ensure_stream_lds() {   // > 64 KB of dynamic LDS needs the function attribute (once)
         static const bool ok = [] {
             bool all = true;
-            for (const void *fn : {(const void *)k_stream_gemv<T, 1>, (const void *)k_stream_gemv<T, 2>, (const void *)k_stream_gemv<T, 3>, (const void *)k_stream_gemv<T, 4>})
+            for (const void *fn : {(const void *)k_stream_gemv<T, 1, false>, (const void *)k_stream_gemv<T, 2, false>, (const void *)k_stream_gemv<T, 3, false>, (const void *)k_stream_gemv<T, 4, false>,
+                                   (const void *)k_stream_gemv<T, 1, true>, (const void *)k_stream_gemv<T, 2, true>, (const void *)k_stream_gemv<T, 3, true>, (const void *)k_stream_gemv<T, 4, true>})
                 all = all && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             return all;
         }();
@@ -871,11 +882,20 @@ struct Ctx : CtxBase {
         const int node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
         const StreamSplit<T> sp{a.splitFirst, splitSpanHalf, d_my2};
         const int grid = d.nodes + (d.nodes - a.splitFirst);      // two workgroups for every block of the split round
-        switch (NL) {
-            case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-            case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-            case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-            default: hipLaunchKernelGGL((k_stream_gemv<T, 4>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+        if (streamTwoPerCU) {
+            switch (NL) {
+                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+            }
+        } else {
+            switch (NL) {
+                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+            }
         }
         return RN_OK;
     }
@@ -1096,14 +1116,16 @@ struct Ctx : CtxBase {
             FinArgs fin{};
             if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             const size_t ldsCut = (size_t)(UPCUT_THREADS / lanesPer) * (nv + 2 * nx) * sizeof(T);
-            hipLaunchKernelGGL(k_up_chain_cut<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+            if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+            else hipLaunchKernelGGL((k_up_chain_cut<T, false>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
             pendingFin = false;
         } else if (phase != 2) {
             // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
             FinArgs fin{};
             const bool ride = pendingFin && !a.cutSums;
             if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
-            hipLaunchKernelGGL(k_up_chain<T>, dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+            if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain<T, true>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+            else hipLaunchKernelGGL((k_up_chain<T, false>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
         }
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
         const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
@@ -2237,6 +2259,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
     return RN_OK;
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
+int rn_fbe_counters(rn_ctx *ctx, long out[3]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
 int rn_reserve_iterations(rn_ctx *ctx, int maxIterations) { RN_GUARD(ctx); return ctx->impl->reserve_iterations(maxIterations); }

@@ -196,6 +196,9 @@ def test_loop_matches_oracle(name, structured, alg):
     assert relmax(hs, ho) < 1e-7   # a signed arg-max entry: ties between equal |entries| may resolve to either sign
     compare_fbe(s, o, alg, 1e-8, "%s %s after %d iterations" % (alg, name, iters))
     assert s.lbfgsState()[:2] == o.lbfgs_state()[:2]
+    # the line searches evaluated their trials in batches of candidates (two passes + one read-back per batch), none trial by trial
+    c = s.fbeCounters()
+    assert c["searches"] >= 1 and c["sequential"] == 0 and c["searches"] <= c["batches"] <= 2 * c["searches"], c
 
 
 @pytest.mark.parametrize("alg", ALGS)
@@ -248,6 +251,7 @@ def test_soft_constraint_branch_value(alg):
     assert np.array_equal(ts, to)
     assert relmax(vs, vo) < REL_TOL
     compare_fbe(s, o, alg, 1e-8, "soft branch")
+    assert s.fbeCounters()["sequential"] >= 1      # a candidate's prox tripped the branch: those searches ran trial by trial
 
 
 def test_fbe_api_errors():

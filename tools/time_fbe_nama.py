@@ -30,7 +30,7 @@ for structured in (False, True):
             run(3)
             t = time.perf_counter(); h, v, tau = run(iters); dt = time.perf_counter() - t
             trials = [1 + {1.0: 0}.get(x, 0) for x in tau]
-            extra = {"tau": [float(x) for x in tau[:12]], "value_first_last": [float(v[0]), float(v[-1])]}
+            extra = {"tau": [float(x) for x in tau[:12]], "value_first_last": [float(v[0]), float(v[-1])], "line_searches": s.fbeCounters()}
         print(json.dumps({"workload": name, "structured": structured, "algorithm": alg, "iterations": iters,
                           "ms_per_iteration": 1e3 * dt / iters, "primal_inf_first_last": [float(h[0]), float(h[-1])], **extra}))
         s.close()
