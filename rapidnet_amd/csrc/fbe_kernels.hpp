@@ -477,7 +477,8 @@ __global__ void __launch_bounds__(VALUE_THREADS) k_value_terms(const T *u, const
 // one fold, one read-back; the host walks the reference's accept / stop logic over the values, applies the accepted number of
 // steps in one pass (k_trial_multi) and runs the ordinary prox + residual pass on the final state.  A candidate whose prox
 // distances trip the soft-constraint branch (never with the shipped penalties) sends the whole search down the sequential path.
-constexpr int LS_K = 6;          // candidates per evaluation batch (11 trials at most: two batches)
+constexpr int LS_K = 6;          // candidates per evaluation batch at most (11 trials in all)
+constexpr int LS_FIRST = 4;      // candidates of a search's first batch
 constexpr int LS_EVAL = 4;       // partials per candidate of k_ls_eval: <w, res>, <res, res>, dist^2 box half, dist^2 safety half
 constexpr int LS_SCAL = 6;       // scalars per candidate after the fold: the four above, quad, lin
 template <typename T>

@@ -198,7 +198,7 @@ def test_loop_matches_oracle(name, structured, alg):
     assert s.lbfgsState()[:2] == o.lbfgs_state()[:2]
     # the line searches evaluated their trials in batches of candidates (two passes + one read-back per batch), none trial by trial
     c = s.fbeCounters()
-    assert c["searches"] >= 1 and c["sequential"] == 0 and c["searches"] <= c["batches"] <= 2 * c["searches"], c
+    assert c["searches"] >= 1 and c["sequential"] == 0 and c["searches"] <= c["batches"] <= 3 * c["searches"], c
 
 
 @pytest.mark.parametrize("alg", ALGS)
