@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the child run the counters are collected on
     ap.add_argument("--one-shot", action="store_true", help="debug/timing only, with --force-shard / --emulate-world: the one-shot exchange at the cut (the rank writes to and reads "
                     "from its own inbox) instead of the one-rank ncclAllReduce -- what a rank executes except the wire, for both transports")
+    ap.add_argument("--alt-exchange-only", action="store_true", help=argparse.SUPPRESS)   # the job of its own that times the one-shot exchange (started by rank 0)
     ap.add_argument("--no-alt-exchange", action="store_true", help="N > 1: skip the extra pass that times the one-shot exchange at the cut beside the RCCL one")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
@@ -211,6 +212,39 @@ def _fault(point, rank):
     if spec and spec.split(":")[0] == point and int(spec.split(":")[1]) == rank:
         print("bench.py rank %d: injected fault at '%s'" % (rank, point), file=sys.stderr, flush=True)
         os._exit(17)
+
+
+def run_alt_exchange_job(args, world):
+    """N > 1: the one-shot exchange at the cut is timed by a JOB OF ITS OWN -- `world` fresh ranks under a child
+    `torch.distributed.run`, started by rank 0 after this job's contexts are gone -- so that nothing it does (it writes into peers'
+    memory from kernels; no multi-GPU node was available to rehearse that) can take this job's result with it: an error, a crash or
+    a time-out of the child is reported in the line as `alt_exchange.error`."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                                                            "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "RAPIDNET_BENCH_FAULT"))}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--alt-exchange-only"]
+    if args.precision:
+        cmd += ["--precision", args.precision]
+    if args.allow_oversubscribe:
+        cmd.append("--allow-oversubscribe")
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "the one-shot exchange job did not finish within 420 s (killed)"}
+    except Exception as e:   # noqa: BLE001
+        return {"error": "the one-shot exchange job could not be started: %s: %s" % (type(e).__name__, e)}
+    for ln in p.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and '"alt_exchange"' in t:
+            try:
+                return json.loads(t)["alt_exchange"]
+            except ValueError:
+                break
+    return {"error": "the one-shot exchange job ended with code %d and no result: %s" % (p.returncode, p.stderr[-600:].replace("\n", " | "))}
 
 
 def _cpu_model():
@@ -691,6 +725,19 @@ def main():
         s.close()
         return res
 
+    if args.alt_exchange_only:      # the job run_alt_exchange_job starts: RCCL timed region, then the one-shot one, in the same context
+        res = {"error": "not run"}
+        try:
+            res = run_mode(False, args.steps, args.warmup, 0, repeats=0, control_step=False, fatal=False, alt=True)["alt_exchange"]
+        except AgreedFailure as e:
+            res = {"error": "AgreedFailure: %s" % e}
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps({"alt_exchange": res}), flush=True)
+            os.dup2(2, 1)
+        dist.barrier()
+        return
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
     dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
     struct, struct_error = None, None
@@ -784,18 +831,16 @@ def main():
                 die("secondary config %s failed on this rank only (%s: %s)" % (w, type(e).__name__, e))
             entry["error"] = "%s: %s" % (type(e).__name__, e)
         entries.append(entry)
-    # N > 1: the one-shot exchange timed beside the RCCL one, in a context of its own, as the LAST collective step of the run
+    # N > 1: the one-shot exchange timed beside the RCCL one -- by a job of its own (run_alt_exchange_job), after this job's contexts
+    # are gone; the other ranks wait at the barrier behind it
     alt_exchange = None
-    if sharded and world > 1 and not args.structured and not args.no_alt_exchange:
-        if rank == 0 and out is not None:
-            print("bench.py: headline so far: %s" % json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}), file=sys.stderr, flush=True)
-        try:
-            r = run_mode(False, args.steps, args.warmup, 0, repeats=0, control_step=False, fatal=False, alt=True)
-            alt_exchange = r["alt_exchange"]
-        except AgreedFailure as e:
-            alt_exchange = {"error": "AgreedFailure: %s" % e}
-        except Exception as e:   # noqa: BLE001
-            die("the one-shot exchange pass failed on this rank only (%s: %s)" % (type(e).__name__, e))
+    if sharded and world > 1 and not args.structured and not args.no_alt_exchange and not args.alt_exchange_only:
+        dist.barrier()
+        if rank == 0:
+            beat("one-shot exchange: a job of its own", 900.0)
+            alt_exchange = run_alt_exchange_job(args, world)
+        dist.barrier()
+        beat("after the one-shot exchange job", 600.0)
     # The replay path, timed: the feasible-by-construction workloads never trip the soft-constraint thresholds, so their batches
     # always take the optimistic path once.  Here the ORIGINAL data of the 31-scenario tree (random bounds: infeasible) with small
     # penalties -- the tree-global distances exceed gamma / lambda -- run one optimistic batch (checkpoint, 20 iterations with the
