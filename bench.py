@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the child run the counters are collected on
     ap.add_argument("--one-shot", action="store_true", help="debug/timing only, with --force-shard / --emulate-world: the one-shot exchange at the cut (the rank writes to and reads "
                     "from its own inbox) instead of the one-rank ncclAllReduce -- what a rank executes except the wire, for both transports")
-    ap.add_argument("--alt-exchange-only", action="store_true", help=argparse.SUPPRESS)   # the job of its own that times the one-shot exchange (started by rank 0)
+    ap.add_argument("--alt-exchange-only", action="store_true", help=argparse.SUPPRESS)   # the second worker of a rank: times the one-shot exchange (see supervise)
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)              # N > 1: the process that does a rank's GPU work (started by the rank's supervisor)
     ap.add_argument("--no-alt-exchange", action="store_true", help="N > 1: skip the extra pass that times the one-shot exchange at the cut beside the RCCL one")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
@@ -214,37 +215,91 @@ def _fault(point, rank):
         os._exit(17)
 
 
-def run_alt_exchange_job(args, world):
-    """N > 1: the one-shot exchange at the cut is timed by a JOB OF ITS OWN -- `world` fresh ranks under a child
-    `torch.distributed.run`, started by rank 0 after this job's contexts are gone -- so that nothing it does (it writes into peers'
-    memory from kernels; no multi-GPU node was available to rehearse that) can take this job's result with it: an error, a crash or
-    a time-out of the child is reported in the line as `alt_exchange.error`."""
+def supervise(args):
+    """N > 1: what the launcher starts for a rank is this SUPERVISOR, which never touches the GPU.  It runs the rank's work as child
+    processes, one after the other, so that at no time more than one process per rank holds the device:
+      1. the worker (`--worker`): everything the JSON line reports, RCCL exchange; rank 0's worker prints the line;
+      2. unless --no-alt-exchange: a second worker (`--worker --alt-exchange-only`) that times the one-shot exchange at the cut.
+         It writes into peers' memory from kernels and no multi-GPU node was available to rehearse that, so nothing it does can
+         take the headline with it: an error, a crash or a time-out (420 s, the child is killed by its PID) ends up in the line
+         as `alt_exchange.error`.
+    A worker that fails in step 1 ends this process with its code at once (the launcher then ends the other ranks); a supervisor
+    that is ended (SIGTERM from the launcher) takes its worker with it."""
+    import ctypes
+    import signal
     import subprocess
 
-    env = {k: v for k, v in os.environ.items()
-           if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
-                                                            "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "RAPIDNET_BENCH_FAULT"))}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--alt-exchange-only"]
-    if args.precision:
-        cmd += ["--precision", args.precision]
-    if args.allow_oversubscribe:
-        cmd.append("--allow-oversubscribe")
-    try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
-    except subprocess.TimeoutExpired:
-        return {"error": "the one-shot exchange job did not finish within 420 s (killed)"}
-    except Exception as e:   # noqa: BLE001
-        return {"error": "the one-shot exchange job could not be started: %s: %s" % (type(e).__name__, e)}
-    for ln in p.stdout.splitlines():
-        t = ln.strip()
-        if t.startswith("{") and '"alt_exchange"' in t:
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    child = [None]
+
+    def _die_with_parent():                      # the worker gets SIGKILL if this process disappears without a word
+        try:
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)
+        except Exception:   # noqa: BLE001
+            pass
+
+    def _on_term(signum, _frame):
+        if child[0] is not None and child[0].poll() is None:
+            child[0].kill()
+        os._exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, _on_term)
+    signal.signal(signal.SIGINT, _on_term)
+    base = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"]
+
+    def run_worker(cmd, env, key, limit):
+        """(exit code or None after a time-out, the last stdout line that is a JSON object holding `key`)"""
+        child[0] = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, preexec_fn=_die_with_parent)
+        import threading
+
+        found = [None]
+
+        def pump():
+            for ln in child[0].stdout:            # everything but the result goes to stderr
+                t = ln.strip()
+                if t.startswith("{") and key in t:
+                    found[0] = t
+                elif t:
+                    print(t, file=sys.stderr, flush=True)
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        try:
+            rc = child[0].wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            child[0].kill()
+            child[0].wait()
+            rc = None
+        th.join(10.0)
+        return rc, found[0]
+
+    rc, line = run_worker(base, dict(os.environ), '"metric"', None)
+    if rc != 0:
+        print("bench.py rank %d: the worker ended with code %s" % (rank, rc), file=sys.stderr, flush=True)
+        os._exit(rc if rc and rc > 0 else 1)
+    alt = None
+    if not (args.structured or args.no_alt_exchange or args.alt_exchange_only or args.traffic_probe):
+        env = {k: v for k, v in os.environ.items() if k != "RAPIDNET_BENCH_FAULT"}
+        env["RAPIDNET_BENCH_STORE_PREFIX"] = "alt_exchange"      # the launcher's store is shared with step 1: keys of its own
+        rc2, aline = run_worker(base + ["--alt-exchange-only"], env, '"alt_exchange"', 420.0)
+        if aline is not None:
             try:
-                return json.loads(t)["alt_exchange"]
+                alt = json.loads(aline)["alt_exchange"]
             except ValueError:
-                break
-    return {"error": "the one-shot exchange job ended with code %d and no result: %s" % (p.returncode, p.stderr[-600:].replace("\n", " | "))}
+                alt = None
+        if alt is None:
+            alt = {"error": "the one-shot exchange job did not finish within 420 s (killed)" if rc2 is None
+                   else "the one-shot exchange job ended with code %d and no result (see stderr)" % rc2}
+    if rank == 0:
+        if line is None:
+            print("bench.py: rank 0's worker ended without a result line", file=sys.stderr, flush=True)
+            os._exit(1)
+        if alt is not None:
+            out = json.loads(line)
+            out["alt_exchange"] = alt
+            line = json.dumps(out)
+        print(line, flush=True)
+    os._exit(0)
 
 
 def _cpu_model():
@@ -361,7 +416,14 @@ def main():
 
         # (a peer that dies closes its sockets: gloo raises in the survivors at once; the long timeout only covers ranks that wait
         #  at the final barrier while rank 0 times the CPU baseline)
-        dist.init_process_group("gloo", init_method="env://", timeout=datetime.timedelta(seconds=1800))
+        prefix = os.environ.get("RAPIDNET_BENCH_STORE_PREFIX")
+        if prefix and world > 1:
+            # a rank's second worker (supervise, step 2): the launcher's store still holds the first worker's rendezvous keys
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0 and not agent, datetime.timedelta(seconds=300))
+            dist.init_process_group("gloo", store=dist.PrefixStore(prefix, store), rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+        else:
+            dist.init_process_group("gloo", init_method="env://", timeout=datetime.timedelta(seconds=1800))
     else:
         device, oversubscribed = local_rank, False
     wd = Watchdog(rank, 600.0) if world > 1 else None
@@ -725,7 +787,7 @@ def main():
         s.close()
         return res
 
-    if args.alt_exchange_only:      # the job run_alt_exchange_job starts: RCCL timed region, then the one-shot one, in the same context
+    if args.alt_exchange_only:      # the second worker of a rank (supervise): RCCL timed region, then the one-shot one, in the same context
         res = {"error": "not run"}
         try:
             res = run_mode(False, args.steps, args.warmup, 0, repeats=0, control_step=False, fatal=False, alt=True)["alt_exchange"]
@@ -831,16 +893,6 @@ def main():
                 die("secondary config %s failed on this rank only (%s: %s)" % (w, type(e).__name__, e))
             entry["error"] = "%s: %s" % (type(e).__name__, e)
         entries.append(entry)
-    # N > 1: the one-shot exchange timed beside the RCCL one -- by a job of its own (run_alt_exchange_job), after this job's contexts
-    # are gone; the other ranks wait at the barrier behind it
-    alt_exchange = None
-    if sharded and world > 1 and not args.structured and not args.no_alt_exchange and not args.alt_exchange_only:
-        dist.barrier()
-        if rank == 0:
-            beat("one-shot exchange: a job of its own", 900.0)
-            alt_exchange = run_alt_exchange_job(args, world)
-        dist.barrier()
-        beat("after the one-shot exchange job", 600.0)
     # The replay path, timed: the feasible-by-construction workloads never trip the soft-constraint thresholds, so their batches
     # always take the optimistic path once.  Here the ORIGINAL data of the 31-scenario tree (random bounds: infeasible) with small
     # penalties -- the tree-global distances exceed gamma / lambda -- run one optimistic batch (checkpoint, 20 iterations with the
@@ -871,8 +923,6 @@ def main():
         except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
             replay = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
-        if alt_exchange is not None:
-            out["alt_exchange"] = alt_exchange
         if replay is not None:
             out["replay_path"] = replay
         if entries:
@@ -892,6 +942,8 @@ def main():
 
 if __name__ == "__main__":
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if "--worker" not in sys.argv[1:]:
+            supervise(parse())     # never returns
         # a rank that fails leaves AT ONCE with a non-zero code and without finalisers (its peers may be inside a collective it
         # will never join; tearing down a communicator collectively would hang as well) -- the launcher then ends the others
         try:
