@@ -208,8 +208,9 @@ int rn_line_search_ame_lbfgs_update(rn_ctx *ctx, double valueAmeY, double *tau);
 /* How the line searches ran (both loops evaluate the trials tau = 1, 1/2, 1/4 ... of SmpcController.cu:1272-1300 in batches of six
  * candidates -- two passes and one read-back per batch instead of eight launches and two read-backs per trial; identical tau):
  * out = {line searches, candidate batches evaluated, searches that ran trial by trial (a candidate's prox tripped the
- * soft-constraint branch, or the batch kernel's LDS tile does not fit)} */
-int rn_fbe_counters(rn_ctx *ctx, long out[3]);
+ * soft-constraint branch, or the batch kernel's LDS tile does not fit), NAMA iterations whose two Hessian oracles (:1331, :1341-1345)
+ * shared one pass over the operator blocks} */
+int rn_fbe_counters(rn_ctx *ctx, long out[4]);
 /* lbfgsBufferCol / lbfgsBufferMemory / lbfgsBufferHessian and lbfgsBufferRho (lbfgsBufferSize + 1 entries, the
  * reference addresses entries 1..lbfgsBufferSize; rho may be NULL): get (set = 0) or set (set = 1) */
 int rn_lbfgs_state(rn_ctx *ctx, int set, int *col, int *mem, double *H, double *rho);

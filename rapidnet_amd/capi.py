@@ -429,10 +429,11 @@ class Solver:
         return t.value
 
     def fbeCounters(self):
-        """dict(searches, batches, sequential): how the line searches of the FBE / NAMA loops ran"""
-        out = np.zeros(3, dtype=np.int64)
+        """dict(searches, batches, sequential, sweep_pairs): how the line searches of the FBE / NAMA loops ran, and how many NAMA
+        iterations ran their two Hessian sweeps in one pass over the operator blocks"""
+        out = np.zeros(4, dtype=np.int64)
         self._check(self.lib.rn_fbe_counters(self.h, out.ctypes.data))
-        return dict(zip(("searches", "batches", "sequential"), (int(v) for v in out)))
+        return dict(zip(("searches", "batches", "sequential", "sweep_pairs"), (int(v) for v in out)))
 
     def lbfgsState(self, col=None, mem=None, H=None, rho=None):
         """get (no arguments) or set lbfgsBufferCol / Memory / Hessian / Rho; returns (col, mem, H, rho[size+1])."""

@@ -687,5 +687,14 @@ __global__ void __launch_bounds__(ELT_THREADS) k_ls_finish(const double *evalPar
     if (threadIdx.x == 0) out[c * LS_SCAL + q] = sh[0];
 }
 
+// updatePrimalInfeasibity inside the loops: fold k_absmax's partials (first-index ties, as the host fold of rn_update_primal_infeasibility)
+// into out[0..4) = (v_xi, -v_xi, v_psi, -v_psi): the form a MAX all-reduce over the ranks can combine (largest magnitude and its sign)
+__global__ void __launch_bounds__(ELT_THREADS) k_inf_fold(const Partial *partials, int nblocks, double *out) {
+    double tx2 = 0, ts2 = 0;
+    Partial p;
+    fold_partials(partials, nblocks, true, tx2, ts2, p);
+    if (threadIdx.x == 0) { out[0] = p.valXi; out[1] = -p.valXi; out[2] = p.valPsi; out[3] = -p.valPsi; }
+}
+
 }  // namespace rn
 #endif

@@ -519,13 +519,22 @@ struct StreamSplit {
 // SPLIT = false is the kernel as it always was (span0 = 0, every block one workgroup): the instantiation the unsplit launches run --
 // the whole 493-scenario tree among them, where the split gains nothing and the second code path would cost (same-box A/B against
 // the round-3 kernel: 605 instead of 590 us with one shared instantiation, whose register allocation let two workgroups share a CU)
-template <typename T, int NL, bool SPLIT>
-__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0, StreamSplit<T> sp) {
+// NR = 2: TWO right-hand sides in one pass over the blocks (the quasi-Newton loops' pairs of independent Hessian sweeps: the launch is
+// bound by the blocks' bytes, so the second product rides for free): the second vector r2.w, its results in r2.my / r2.qa.  Each
+// right-hand side's sums are formed exactly as the one-vector kernel forms them (same order over the columns): bitwise the results
+// of two launches.  Unsplit launches with w in memory only.
+template <typename T>
+struct StreamRhs2 { const T *w; T *my; T *qa; };
+template <typename T, int NL, bool SPLIT, int NR = 1>
+__global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0, StreamSplit<T> sp, StreamRhs2<T> r2) {
+    static_assert(NR == 1 || !SPLIT, "two right-hand sides: unsplit launches only");
     typedef typename Slot<T>::type VT;
     constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny (+ G of zero padding is not needed: guarded reads)
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
+    T *sh_y2 = sh_red + (size_t)G * a.LD;               // NR = 2: the same pair again for the second right-hand side
+    T *sh_red2 = sh_y2 + ((a.ny + 3) & ~3);
     const int tid = threadIdx.x;
     // blocks [0, first): one workgroup each; from there on two workgroups per block (first half, second half)
     const bool split = SPLIT && (int)blockIdx.x >= sp.first;
@@ -548,11 +557,11 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
         cj[j] = off[j] / SPC;
         msk[j] = ok ? (T)1 : (T)0;
     }
-    T part[NL][VPL];
+    T part[NL][VPL], part2[NR == 2 ? NL : 1][VPL];
 #pragma unroll
     for (int j = 0; j < NL; j++)
 #pragma unroll
-        for (int e = 0; e < VPL; e++) part[j][e] = 0;
+        for (int e = 0; e < VPL; e++) { part[j][e] = 0; if (NR == 2) part2[j][e] = 0; }
     const int nFull = (ny / G < span1 ? ny / G : span1) - span0;   // spans of this workgroup made of G whole columns
     const int nGroups = nFull / D;
     VT bufA[D][NL], bufB[D][NL];
@@ -565,6 +574,10 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
         _Pragma("unroll") for (int j = 0; j < NL; j++) {                                                               \
             const T yc = sh_y[(span0 + (g_) * D + d) * G + cj[j]] * msk[j];                                            \
             _Pragma("unroll") for (int e = 0; e < VPL; e++) part[j][e] += buf[d][j][e] * yc;                           \
+            if (NR == 2) {                                                                                             \
+                const T yc2 = sh_y2[(span0 + (g_) * D + d) * G + cj[j]] * msk[j];                                      \
+                _Pragma("unroll") for (int e = 0; e < VPL; e++) part2[j][e] += buf[d][j][e] * yc2;                     \
+            }                                                                                                          \
         }
     // Prologue.  A wave's loads return in order, so everything the prologue needs is requested FIRST and the first group of
     // A_i (which does not depend on y) right behind it: the prologue's arithmetic then runs while that group streams in, and
@@ -585,6 +598,8 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     const T *wA = a.wy1 ? a.wy1 : a.w, *wB = a.wy1 ? a.wy0 : a.w;
     const T wLn = a.wy1 ? a.wLn : (T)0;
     const T w0a = wA[i0], w0b = wB[i0];
+    T w20 = 0;
+    if (NR == 2) w20 = r2.w[i0];
     asm volatile("" ::: "memory");   // keep the request order: the compiler otherwise hoists the group's loads above the small ones
     {
         const int lastSlot = (int)blockSlots - 1;
@@ -599,14 +614,23 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     asm volatile("" ::: "memory");
     // a_i is STORED AT THE END of the kernel: stores count in the same in-order counter as the loads, so a store issued
     // here has to be acknowledged before the wave may consume any group of A_i requested after it
-    T qa0 = 0;
+    T qa0 = 0, qa02 = 0;
     if (has0) sh_y[tid] = extrap_elem(w0a, w0b, wLn);
     for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y[c] = extrap_elem(wA[(size_t)node * ny + c], wB[(size_t)node * ny + c], wLn);
+    if (NR == 2) {
+        if (has0) sh_y2[tid] = w20;
+        for (int c = tid + STREAM_THREADS; c < ny; c += STREAM_THREADS) sh_y2[c] = r2.w[(size_t)node * ny + c];
+    }
     __syncthreads();
     // a_i = F_i' xi_i = sqrt(p_i) (d_x o xi_box + d_xs o xi_safe)      (a split block: written by its first half)
     if (tid < nx) qa0 = stream_qa_elem(spn, dq0, sh_y[tid], dq1, sh_y[nx + tid]);
     if (!second) for (int t = tid + STREAM_THREADS; t < nx; t += STREAM_THREADS)
         a.qa[(size_t)node * nx + t] = stream_qa_elem(spn, dyRow[t], sh_y[t], dyRow[nx + t], sh_y[nx + t]);
+    if (NR == 2) {
+        if (tid < nx) qa02 = stream_qa_elem(spn, dq0, sh_y2[tid], dq1, sh_y2[nx + tid]);
+        for (int t = tid + STREAM_THREADS; t < nx; t += STREAM_THREADS)
+            r2.qa[(size_t)node * nx + t] = stream_qa_elem(spn, dyRow[t], sh_y2[t], dyRow[nx + t], sh_y2[nx + t]);
+    }
     if (nGroups > 0) {
         int g = 0;
         // steady state has no branch inside, so the compiler's vmcnt waits are exact: while group g is consumed, group
@@ -638,21 +662,35 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
             const T yc = live ? sh_y[c] : (T)0;
 #pragma unroll
             for (int e = 0; e < VPL; e++) part[j][e] += v[e] * yc;
+            if (NR == 2) {
+                const T yc2 = live ? sh_y2[c] : (T)0;
+#pragma unroll
+                for (int e = 0; e < VPL; e++) part2[j][e] += v[e] * yc2;
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < NL; j++)
         if (msk[j] != (T)0) {
 #pragma unroll
-            for (int e = 0; e < VPL; e++) sh_red[(size_t)off[j] * VPL + e] = part[j][e];
+            for (int e = 0; e < VPL; e++) { sh_red[(size_t)off[j] * VPL + e] = part[j][e]; if (NR == 2) sh_red2[(size_t)off[j] * VPL + e] = part2[j][e]; }
         }
     if (tid < nx && !second) stream_out(qa0, a.qa + (size_t)node * nx + tid);
+    if (NR == 2 && tid < nx) stream_out(qa02, r2.qa + (size_t)node * nx + tid);
     __syncthreads();
     T *const myOut = second ? sp.my2 + (size_t)(node - sp.first) * 2 * nv : a.my + (size_t)node * 2 * nv;
     for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {    // slot q of a span = column q / SPC, rows (q % SPC) * VPL ...
         T s = sh_red[r];
         for (int k = 1; k < G; k++) s += sh_red[(size_t)k * LD + r];
         stream_out(s, myOut + r);
+    }
+    if (NR == 2) {
+        T *const myOut2 = r2.my + (size_t)node * 2 * nv;
+        for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {
+            T s = sh_red2[r];
+            for (int k = 1; k < G; k++) s += sh_red2[(size_t)k * LD + r];
+            stream_out(s, myOut2 + r);
+        }
     }
 }
 

@@ -870,7 +870,8 @@ struct Ctx : CtxBase {
         }();
         return ok;
     }
-    int launch_stream(const SweepArgs<T> &a) {
+    // second != nullptr: two right-hand sides in one pass (k_stream_gemv NR = 2; see stream_pair_ok)
+    int launch_stream(const SweepArgs<T> &a, const StreamRhs2<T> *second = nullptr) {
         int G, NL;
         stream_shape(&G, &NL);
         RN_CHECK(NL <= STREAM_NLMAX, RN_E_ARG, "k_stream_gemv: more than 4096 values per operator column are not supported (2*nv too large)");
@@ -882,22 +883,37 @@ struct Ctx : CtxBase {
         const int node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
         const StreamSplit<T> sp{a.splitFirst, splitSpanHalf, d_my2};
         const int grid = d.nodes + (d.nodes - a.splitFirst);      // two workgroups for every block of the split round
-        if (streamTwoPerCU) {
+        const StreamRhs2<T> none{nullptr, nullptr, nullptr};
+        if (second) {
+            RN_CHECK(a.splitFirst >= d.nodes && a.wy1 == nullptr && 2 * lds <= 64 * 1024, RN_E_STATE, "k_stream_gemv with two right-hand sides: unsplit launches with w in memory only");
             switch (NL) {
-                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
+                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
+                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
+                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
+            }
+        } else if (streamTwoPerCU) {
+            switch (NL) {
+                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, true>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
             }
         } else {
             switch (NL) {
-                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
-                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp); break;
+                case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                case 3: hipLaunchKernelGGL((k_stream_gemv<T, 3, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
+                default: hipLaunchKernelGGL((k_stream_gemv<T, 4, false>), dim3(grid), dim3(STREAM_THREADS), lds, stream, a, G, node0, sp, none); break;
             }
         }
         return RN_OK;
+    }
+    // two right-hand sides in one streaming pass are possible for: dense per-node blocks, no split last round, both LDS sets in 64 KB
+    bool stream_pair_ok() const {
+        int G, NL;
+        stream_shape(&G, &NL);
+        return !structured && !(splitFirst >= 0 && splitFirst < d.nodes) && 2 * stream_lds(G) <= 64 * 1024;
     }
     static int slab_stride(int kp) { return (kp + 59) / 64 * 64 + 4; }   // >= kp, = 4 (mod 64): conflict-free MFMA B reads
     // waves per slab workgroup.  Many slabs (more workgroups than CUs): the count in {4, 6, 8} that wastes the least SIMD
@@ -1014,7 +1030,7 @@ struct Ctx : CtxBase {
     void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
-        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, d_my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), d_v, nv, d_lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
@@ -1048,7 +1064,7 @@ struct Ctx : CtxBase {
             return;
         }
 #endif
-        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, d_my, 2 * nv);
+        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, a.my, 2 * nv);
         launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
     // crown handling of the forward sweep: 0 = crown launches of their own; 1 = every chain workgroup walks its crown path and
@@ -1073,7 +1089,11 @@ struct Ctx : CtxBase {
     // hessianInput != nullptr: SmpcController::computeHessianOracalGlobalFbe (SmpcController.cu:884-1055) -- the same
     // sweep evaluated at `hessianInput` with sigma = 0 and every affine term zero, writing xdir / udir / H * dir
     // primalOut = false (inner iterations of a batch): x, u and v are not stored, only Hx (what the dual update reads)
-    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true) {
+    // hessianInput2 (with hessianInput; stream_pair_ok()): TWO Hessian sweeps whose inputs do not depend on each other's results share
+    // ONE pass over the operator blocks (k_stream_gemv NR = 2); the vector recursions and shared-operator products then run once per
+    // right-hand side.  The first sweep's results go to the pair buffers (d_xdirB, d_udirB, d_hxDirB), the second's where a Hessian
+    // sweep always leaves them (d_xdir, d_udir, d_hxDir).  Bitwise the results of two launch_sweep calls.
+    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true, const T *hessianInput2 = nullptr) {
         SweepArgs<T> a = sweep_args();
         a.writePrimal = primalOut ? 1 : 0;
         if (hessianInput) {
@@ -1081,6 +1101,11 @@ struct Ctx : CtxBase {
             a.beta = d_zero; a.uhat = d_zero; a.e = d_zero; a.eb = d_zero; a.bw0 = d_zero;
             a.curX = d_zero; a.prevU = d_zero; a.prevUhat = d_zero;
             a.x = d_xdir; a.u = d_udir; a.hx = d_hxDir;
+        }
+        const bool pair = hessianInput2 != nullptr;
+        if (pair) {
+            RN_CHECK(hessianInput && phase == 0 && d_myB && stream_pair_ok(), RN_E_STATE, "launch_sweep: a pair of sweeps needs two Hessian inputs, the pair buffers and an unsplit dense launch");
+            a.x = d_xdirB; a.u = d_udirB; a.hx = d_hxDirB;
         }
         RN_CHECK(phase == 0 || a.cutSums, RN_E_STATE, "rn_debug_sweep_phase needs rn_set_cut_stage and nranks > 1");
         // one-shot exchange (inside rn_apg_iterate batches only): the launch that produces the cut parents' local sums pushes them
@@ -1103,9 +1128,13 @@ struct Ctx : CtxBase {
             e0 = prof_begin(0);
             if (structured) {
                 launch_prep_m2(a);
-            } else if (int rc = launch_stream(a)) return rc;
+            } else {
+                const StreamRhs2<T> r2{hessianInput2, d_myB, d_qaB};
+                if (int rc = launch_stream(a, pair ? &r2 : nullptr)) return rc;
+            }
             prof_end(e0);
         }
+        auto helpers = [&](SweepArgs<T> &a) -> int {
         e1 = prof_begin(1);
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
         // sharded, cut right above the chains, few local chains per cut parent: one launch does the chain walks AND the cut
@@ -1177,6 +1206,15 @@ struct Ctx : CtxBase {
         hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K + (foldCrown == 2 ? h_stageCum[cs] : 0)), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         prof_end(e1);
         RN_HIP(hipGetLastError());
+        return RN_OK;
+        };
+        if (int rc = helpers(a)) return rc;
+        if (pair) {
+            SweepArgs<T> b = a;
+            b.w = hessianInput2; b.my = d_myB; b.qa = d_qaB;
+            b.x = d_xdir; b.u = d_udir; b.hx = d_hxDir;
+            if (int rc = helpers(b)) return rc;
+        }
         return RN_OK;
     }
     // launch shape of k_dual_stage: one tile of ELT_THREADS * trips 16-byte vectors per workgroup, tiles never cross a stage
@@ -2259,7 +2297,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
     return RN_OK;
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
-int rn_fbe_counters(rn_ctx *ctx, long out[3]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
+int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
 int rn_reserve_iterations(rn_ctx *ctx, int maxIterations) { RN_GUARD(ctx); return ctx->impl->reserve_iterations(maxIterations); }

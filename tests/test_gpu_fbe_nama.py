@@ -201,6 +201,29 @@ def test_loop_matches_oracle(name, structured, alg):
     assert c["searches"] >= 1 and c["sequential"] == 0 and c["searches"] <= c["batches"] <= 3 * c["searches"], c
 
 
+@pytest.mark.parametrize("name,precision", [("medium", "f64"), ("odd", "f64"), ("small", "f32")])
+def test_nama_pair_of_hessian_sweeps_is_bitwise_the_two_sweeps(name, precision, monkeypatch):
+    """NAMA's two Hessian oracles of an iteration (SmpcController.cu:1331, :1341-1345) in ONE pass over the operator blocks
+    (k_stream_gemv with two right-hand sides): every buffer and every accepted step as with the two sweeps one after the other."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    runs = []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("RAPIDNET_NAMA_PAIR", pair)
+        s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision)
+        s.initialiseSmpcController(dh, ah)
+        s.setAlgorithm("namaAlgorithm", 5)
+        h, v, t = s.algorithmNama(10)
+        bufs = [s.get(b) for b, _ in FBE_PAIRS] + [s.get(capi.BUF_X), s.get(capi.BUF_U)]
+        runs.append((h, v, t, bufs, s.fbeCounters()))
+        s.close()
+    (h1, v1, t1, b1, c1), (h0, v0, t0, b0, c0) = runs
+    assert c1["sweep_pairs"] >= 8 and c0["sweep_pairs"] == 0, (c1, c0)
+    assert np.array_equal(t1, t0) and np.array_equal(v1, v0) and np.array_equal(h1, h0)
+    for x, y in zip(b1, b0):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("alg", ALGS)
 def test_steps_match_oracle(alg):
     """every step of one iteration, each fed by the previous one, compared after each call"""
