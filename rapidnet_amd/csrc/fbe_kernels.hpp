@@ -687,6 +687,128 @@ __global__ void __launch_bounds__(ELT_THREADS) k_ls_finish(const double *evalPar
     if (threadIdx.x == 0) out[c * LS_SCAL + q] = sh[0];
 }
 
+// The primal terms of computeValueFbe on the matrix cores: quad_c = sum_i p_i du_i' (W du_i) for up to LS_K candidate states (or the
+// current state: plain != 0) -- W du for a slab of 16 nodes is one shared-operator product, the same MFMA loop as the sweep's
+// (slab_mfma over W stored padded like every shared operator), and the dot with du rides in the epilogue.  k_value_terms / k_ls_value
+// do this on the vector ALUs at a tenth of their peak (33 us for one state, 25 us per candidate on the 493-scenario tree: every W
+// element crosses LDS-fed FMAs 16 or 8 nodes at a time); 10 864 x 114 x 114 is 0.3 GFLOP, 4 us of fp64 MFMA time.
+// A workgroup owns slabs blockIdx, blockIdx + grid, ...; a thread keeps its elements of (u, udir) of the slab's nodes and of their
+// parents in registers and advances them candidate by candidate with k_trial_step's update (trial_elem: the state the sequential
+// trial would have), so the candidates share one round of loads.  Summation over j inside (W du)_t is the MFMA's, not the serial
+// loop's: the values differ from k_value_terms's in the last bits; both searches (batched and trial by trial) and the reference
+// value they are compared with come from THIS kernel whenever it is the one in use, so the accept / stop decisions are consistent.
+// partials[block * blockStride + c * candStride + {0, 1}] = {quad_c, lin_c}
+constexpr int VM_WAVES = 8;
+constexpr int VM_MAXE = 6;            // elements of the 16 x nu slab per thread at most (nu <= 192)
+constexpr int VM_KMAX = 32;           // k-steps (of 4) of W a wave keeps in registers at most
+template <typename T>
+__global__ void __launch_bounds__(64 * VM_WAVES) k_value_mfma(const T *u, const T *udir, const T *prevU, const int *parent, const T *prob, const T *Wp, int mp, int kp,
+                                                              const T *alpha, int nu, int nodes, LsTaus<T> ts, int plain, double *partials, int blockStride,
+                                                              int candStride, int firstNode, int SB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fbe_smem[];
+    T *sB = reinterpret_cast<T *>(fbe_smem);            // [16][SB] du of the slab's nodes, zero beyond nu and for nodes that do not count
+    __shared__ double sq[VM_WAVES][LS_K], sl[VM_WAVES][LS_K];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = (nu + 15) / 16, ksteps = kp / 4;
+    const int nCand = plain ? 1 : ts.n;
+    if (lane < LS_K) { sq[wave][lane] = 0; sl[wave][lane] = 0; }               // per-wave running sums of every candidate (lane 0 adds to them)
+    // nu <= 128 (at most one 16-row tile of W per wave, K <= 128): the wave's A fragments of W -- the same for every slab and candidate --
+    // are loaded ONCE into registers, so the products' inner loop reads LDS only (with the fragments fetched from L2 group by group the
+    // launch was bound by that latency: one workgroup per CU, 65 us for four candidates on the 493-scenario tree)
+    const bool wInRegs = tiles <= VM_WAVES && ksteps <= VM_KMAX;
+    T wreg[VM_KMAX];
+    if (wInRegs) {
+        const T *Ap = Wp + (size_t)(wave < tiles ? wave : 0) * 16 + (lane & 15) + (size_t)(lane >> 4) * mp;
+#pragma unroll
+        for (int ks = 0; ks < VM_KMAX; ks++) wreg[ks] = Ap[(size_t)(ks < ksteps ? ks : 0) * 4 * mp];
+    }
+    for (int i = threadIdx.x; i < 16 * SB; i += 64 * VM_WAVES) sB[i] = (T)0;      // the padding columns stay zero
+    const int slabs = (nodes + 15) / 16, perSlab = 16 * nu;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int node0 = slab * 16;
+        T un[VM_MAXE], dn[VM_MAXE], up[VM_MAXE], dp[VM_MAXE], al[VM_MAXE], pb[VM_MAXE];
+        int pos[VM_MAXE];                       // LDS position of the element, -1: none; bit 30: the node does not count (du = 0, no lin)
+        bool rootPar[VM_MAXE];
+#pragma unroll
+        for (int e = 0; e < VM_MAXE; e++) {
+            const int idx = (int)threadIdx.x + e * 64 * VM_WAVES;
+            const bool has = idx < perSlab;
+            const int r = has ? idx / nu : 0, k = has ? idx - r * nu : 0;
+            const int node = node0 + r < nodes ? node0 + r : nodes - 1;
+            const bool live = has && node0 + r < nodes && node >= firstNode;     // sharded: the replicated crown counts on rank 0 only
+            const int par = parent[node];
+            pos[e] = has ? (r * SB + k) | (live ? 0 : (1 << 30)) : -1;
+            rootPar[e] = par < 0;
+            pb[e] = prob[node];
+            un[e] = u[(size_t)node * nu + k];
+            dn[e] = plain ? (T)0 : udir[(size_t)node * nu + k];
+            up[e] = par < 0 ? prevU[k] : u[(size_t)par * nu + k];
+            dp[e] = (plain || par < 0) ? (T)0 : udir[(size_t)par * nu + k];
+            al[e] = alpha[(size_t)node * nu + k];
+        }
+        for (int c = 0; c < nCand; c++) {
+            __syncthreads();                    // the previous candidate's (slab's) products have read sB
+            double q = 0, l = 0;
+            const T tau = plain ? (T)0 : ts.tau[c];
+#pragma unroll
+            for (int e = 0; e < VM_MAXE; e++) {
+                if (pos[e] < 0) continue;
+                if (!plain) {
+                    un[e] = trial_elem(un[e], tau, dn[e]);
+                    if (!rootPar[e]) up[e] = trial_elem(up[e], tau, dp[e]);      // the root's predecessor is prevU: not part of the iterate
+                }
+                const bool live = !(pos[e] & (1 << 30));
+                sB[pos[e] & ~(1 << 30)] = live ? un[e] - up[e] : (T)0;
+                if (live) l += (double)(pb[e] * un[e]) * (double)al[e];
+            }
+            __syncthreads();
+            const int col = lane & 15;
+            const int nodeC = node0 + col < nodes ? node0 + col : nodes - 1;
+            const T pc = prob[nodeC];
+            if (wInRegs) {
+                if (wave < tiles) {
+                    typename Mfma16<T>::acc_t acc = {0, 0, 0, 0};
+                    const T *Bp = sB + col * SB + (lane >> 4);
+#pragma unroll
+                    for (int g = 0; g < VM_KMAX / 4; g++) {
+                        if (g * 4 < ksteps) {      // ksteps is a whole number of groups of 4 (pad_k)
+                            T b[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) b[i] = Bp[(g * 4 + i) * 4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc = Mfma16<T>::run(wreg[g * 4 + i], b[i], acc);
+                        }
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = wave * 16 + Mfma16<T>::row(lane, reg);
+                        if (gr < nu) q += (double)(pc * sB[col * SB + gr]) * (double)acc[reg];
+                    }
+                }
+            } else
+            for (int t0 = wave; t0 < tiles; t0 += VM_WAVES) {
+                typename Mfma16<T>::acc_t acc[1];
+                slab_mfma<T, 1, RN_SLAB_KU, false>(acc, Wp, mp, t0, VM_WAVES, tiles, ksteps, sB, SB, lane);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = t0 * 16 + Mfma16<T>::row(lane, reg);
+                    if (gr < nu) q += (double)(pc * sB[col * SB + gr]) * (double)acc[0][reg];      // du = 0 for the nodes that do not count
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); l += __shfl_down(l, off); }
+            if (lane == 0) { sq[wave][c] += q; sl[wave][c] += l; }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nCand) {
+        double a = 0, b = 0;
+        for (int k = 0; k < VM_WAVES; k++) { a += sq[k][threadIdx.x]; b += sl[k][threadIdx.x]; }
+        partials[(size_t)blockIdx.x * blockStride + (size_t)threadIdx.x * candStride + 0] = a;
+        partials[(size_t)blockIdx.x * blockStride + (size_t)threadIdx.x * candStride + 1] = b;
+    }
+}
+
 // updatePrimalInfeasibity inside the loops: fold k_absmax's partials (first-index ties, as the host fold of rn_update_primal_infeasibility)
 // into out[0..4) = (v_xi, -v_xi, v_psi, -v_psi): the form a MAX all-reduce over the ranks can combine (largest magnitude and its sign)
 __global__ void __launch_bounds__(ELT_THREADS) k_inf_fold(const Partial *partials, int nblocks, double *out) {

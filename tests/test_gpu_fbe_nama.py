@@ -263,6 +263,63 @@ def test_steps_match_oracle(alg):
 
 
 @pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_batched_line_search_is_bitwise_the_sequential_one(alg, mfma, monkeypatch):
+    """the candidates of a line search evaluated in batches (two passes + one read-back) against the trials one by one: the same
+    accepted steps, values and buffers to the last bit -- with the value's primal terms on the matrix cores (k_value_mfma) and on
+    the vector ALUs (k_value_terms / k_ls_value)"""
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    monkeypatch.setenv("RAPIDNET_VALUE_MFMA", mfma)
+    runs = []
+    for seq in ("0", "1"):
+        monkeypatch.setenv("RAPIDNET_LS_SEQUENTIAL", seq)
+        s = capi.Solver(p["network"], p["tree"], p["config"])
+        s.initialiseSmpcController(dh, ah)
+        s.setAlgorithm(alg, 5)
+        h, v, t = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(10)
+        runs.append((h, v, t, [s.get(b) for b, _ in FBE_PAIRS], s.fbeCounters()))
+        s.close()
+    (h1, v1, t1, b1, c1), (h0, v0, t0, b0, c0) = runs
+    assert c1["sequential"] == 0 and c1["batches"] >= c1["searches"] >= 1 and c0["sequential"] == c0["searches"] >= 1, (c1, c0)
+    assert np.array_equal(t1, t0) and np.array_equal(v1, v0) and np.array_equal(h1, h0)
+    for x, y in zip(b1, b0):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("kind", ["positive", "tiny"])
+def test_line_search_direction_rule(alg, kind):
+    """the two early exits of the line searches (SmpcController.cu:1262-1270, :1370-1379): a direction of positive slope leaves tau = 1
+    and applies nothing, a slope below 1e-4 in magnitude gives tau = 0.  The HIP path reads the slope together with the values of the
+    first candidate batch -- the state afterwards must be the oracle's all the same."""
+    p, o, s = make_pair("small", alg)
+    fbe = alg == "globalFbeAlgorithm"
+    for it in range(2):
+        o.solve_step(); s.solveStep()
+        o.prox(); s.proximalFunG()
+        o.residual(); s.computeFixedPointResidual()
+        if fbe:
+            o.gradient_fbe(); s.computeGradientFbe()
+        else:
+            o.nama_residual(); s.updateFixedPointResidualNamaAlgorithm()
+        if it > 0:
+            vo, vs = o.value_fbe(), s.computeValueFbe()
+            o.lbfgs_direction(); s.computeLbfgsDirection()
+            # FBE: slope = <grad, dir>; NAMA: slope = -<res, dir>
+            yx, yp = (o.get("gradXi"), o.get("gradPsi")) if fbe else (-o.get("resXi"), -o.get("resPsi"))
+            scale = 1.0 if kind == "positive" else -1e-7 / max(float(np.dot(yx, yx) + np.dot(yp, yp)), 1e-300)
+            for name, bid, v in (("dirXi", capi.BUF_LBFGS_DIR_XI, scale * yx), ("dirPsi", capi.BUF_LBFGS_DIR_PSI, scale * yp)):
+                o.set(name, v); s.set(bid, v)
+            to = o.line_search_fbe(vo) if fbe else o.line_search_ame(vo)
+            ts = s.computeLineSearchLbfgsUpdate(vs) if fbe else s.computeLineSearchAmeLbfgsUpdate(vs)
+            assert to == (1.0 if kind == "positive" else 0.0) and ts == to
+            compare_fbe(s, o, alg, REL_TOL, "line search with a %s slope" % kind)
+            assert s.fbeCounters()["searches"] == 0
+        o.dual_update(); s.dualUpdate()
+
+
+@pytest.mark.parametrize("alg", ALGS)
 def test_soft_constraint_branch_value(alg):
     """penalties small enough that the soft branch trips: the g terms of the FBE value are exercised"""
     p, o, s = make_pair("small", alg, penalty_x=2.0, penalty_xs=1.0)
