@@ -2873,19 +2873,33 @@ __global__ void __launch_bounds__(AFF_THREADS) k_affine_beta(AffineArgs<T> a) {
 }
 
 // small utilities ------------------------------------------------------------------------------------
+// (one workgroup each, once per control step; the columns are requested eight at a time -- one at a time the loop was a chain of
+//  `cols` dependent round trips, 35-50 us for a 63 x 114 matrix -- and added in the same order as before)
 template <typename T>
-__global__ void k_bw0(const T *B, int nx, int nu, const T *prevU, const T *prevUhat, T *bw0) {   // bw0 = B (prevU - prevUhat)
+__global__ void k_bw0(const T *__restrict__ B, int nx, int nu, const T *__restrict__ prevU, const T *__restrict__ prevUhat, T *__restrict__ bw0) {   // bw0 = B (prevU - prevUhat)
     for (int r = threadIdx.x; r < nx; r += blockDim.x) {
         T s = 0;
-        for (int j = 0; j < nu; j++) s += B[r + (size_t)j * nx] * (prevU[j] - prevUhat[j]);
+        for (int j0 = 0; j0 < nu; j0 += 8) {
+            T m[8], d[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int j = j0 + i < nu ? j0 + i : nu - 1; m[i] = B[r + (size_t)j * nx]; d[i] = prevU[j] - prevUhat[j]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (j0 + i < nu) s += m[i] * d[i];
+        }
         bw0[r] = s;
     }
 }
 template <typename T>
-__global__ void k_gemv_small(const T *M, int rows, int cols, const T *x, T *y) {   // y = M x, one block
+__global__ void k_gemv_small(const T *__restrict__ M, int rows, int cols, const T *__restrict__ x, T *__restrict__ y) {   // y = M x, one block
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
         T s = 0;
-        for (int j = 0; j < cols; j++) s += M[r + (size_t)j * rows] * x[j];
+        for (int j0 = 0; j0 < cols; j0 += 8) {
+            T m[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int j = j0 + i < cols ? j0 + i : cols - 1; m[i] = M[r + (size_t)j * rows]; v[i] = x[j]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (j0 + i < cols) s += m[i] * v[i];
+        }
         y[r] = s;
     }
 }

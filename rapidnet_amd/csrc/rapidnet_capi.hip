@@ -682,6 +682,7 @@ struct Ctx : CtxBase {
         UP(d_Gd, s->matGd, nx * nd) UP(d_Lhat, s->matLhat, nu * nd) UP(d_alpha1, s->costAlpha1, nu) UP(d_W, s->costW, nu * nu)
         UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
 #undef UP
+        if (d_Wp) { if (int rc = upload_padded(d_Wp, s->costW, nu, nu)) return rc; }   // k_value_mfma's copy of W (rn_set_algorithm may come before the factor step)
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
             if (int rc = dalloc(&d_A, (size_t)d.nodes * strideA)) return rc;
         }

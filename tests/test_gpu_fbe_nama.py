@@ -201,6 +201,23 @@ def test_loop_matches_oracle(name, structured, alg):
     assert c["searches"] >= 1 and c["sequential"] == 0 and c["searches"] <= c["batches"] <= 3 * c["searches"], c
 
 
+@pytest.mark.parametrize("alg", ALGS)
+def test_algorithm_selected_before_the_factor_step(alg):
+    """the order of the C++ host (Engine::create selects the algorithm right after rn_create, the factor step comes later): everything
+    the loops derive from the uploaded system -- k_value_mfma's padded copy of W among it -- must be (re)built by the factor step"""
+    p = synth.make_problem("small")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.set_algorithm(alg, 5); o.initialise(dh, ah); o.fbe_reset()
+    s = capi.Solver(p["network"], p["tree"], p["config"])
+    s.setAlgorithm(alg, 5)
+    s.initialiseSmpcController(dh, ah)
+    ho, vo, to = o.fbe_nama(8)
+    hs, vs, ts = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(8)
+    assert np.array_equal(ts, to) and relmax(vs, vo) < REL_TOL
+    compare_fbe(s, o, alg, 1e-8, "algorithm selected before the factor step")
+
+
 @pytest.mark.parametrize("name,precision", [("medium", "f64"), ("odd", "f64"), ("small", "f32")])
 def test_nama_pair_of_hessian_sweeps_is_bitwise_the_two_sweeps(name, precision, monkeypatch):
     """NAMA's two Hessian oracles of an iteration (SmpcController.cu:1331, :1341-1345) in ONE pass over the operator blocks
