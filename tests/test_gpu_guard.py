@@ -115,8 +115,10 @@ def test_sharded_batches_under_guard(guard, name, world, cut, structured, kw, tr
 @pytest.mark.parametrize("alg", fbe.ALGS)
 def test_fbe_nama_loops_under_guard(guard, alg):
     fbe.test_loop_matches_oracle("small", False, alg)
+    fbe.test_loop_matches_oracle("odd", False, alg)          # odd ny: the streaming kernel's two right-hand sides (NAMA) and k_value_mfma on ragged tiles
     fbe.test_loop_matches_oracle("medium", True, alg)
-    guard["contexts"] = 2
+    fbe.test_line_search_direction_rule(alg, "positive")
+    guard["contexts"] = 4
 
 
 def test_barcelona31_under_guard(guard):
