@@ -24,7 +24,11 @@ python3 bench.py --gpus 2 --steps 20 --warmup 5 --allow-oversubscribe --cpu-iter
 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_strict.out 2> $O/bench_2ranks_strict.err; echo "strict rc=$?" | tee -a $O/bench_2ranks_strict.out; tail -3 $O/bench_2ranks_strict.err >> $O/bench_2ranks_strict.out
 ( time RAPIDNET_BENCH_FAULT=before_comm_init:1 python3 bench.py --gpus 2 --steps 20 --warmup 5 --allow-oversubscribe --no-cpu-baseline --other-configs "" ) > $O/bench_2ranks_fault.out 2> $O/bench_2ranks_fault.err; echo "fault rc=$?" | tee -a $O/bench_2ranks_fault.out; grep -h "injected\|real\|giving up\|rank" $O/bench_2ranks_fault.err | tail -8 >> $O/bench_2ranks_fault.out
 python3 bench.py --precision f32 --other-configs "" --cpu-iterations 5 > $O/barcelona493_f32_1gpu.json 2>/dev/null
-python3 tools/time_fbe_nama.py barcelona493 30 > $O/fbe_nama_timing.jsonl 2>/dev/null
+python3 tools/time_fbe_nama.py barcelona493 40 > $O/fbe_nama_timing.jsonl 2>/dev/null
+for alg in fbe nama; do
+  rm -rf $O/ksf; rocprofv3 --kernel-trace --stats --output-format csv -d $O/ksf -o k -- python3 tools/profile_fbe.py barcelona493 40 0 $alg > $O/${alg}_profile_run.txt 2>/dev/null || exit 1
+  cp $(find $O/ksf -name k_kernel_stats.csv | head -1) $O/${alg}_kernel_stats.csv; rm -rf $O/ksf
+done
 echo "fbe done"
 bash tools/stream_vs_nodes.sh "6 7 8 9 10 11 12 16" > $O/stream_vs_nodes.txt 2>/dev/null
 echo "all done"

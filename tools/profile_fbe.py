@@ -1,4 +1,4 @@
-"""One global-FBE run for a kernel-level profile: rocprofv3 --kernel-trace --stats -- python3 tools/profile_fbe.py [workload] [iterations] [structured]"""
+"""One global-FBE (or NAMA) run for a kernel-level profile: rocprofv3 --kernel-trace --stats -- python3 tools/profile_fbe.py [workload] [iterations] [structured 0|1] [fbe|nama]"""
 import os
 import sys
 import time
@@ -14,9 +14,11 @@ p = synth.make_problem(name)
 dh, ah = synth.forecast_at(p["forecast"], 0)
 s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured)
 s.initialiseSmpcController(dh, ah)
-s.setAlgorithm("globalFbeAlgorithm", 5)
-s.algorithmGlobalFbe(3)
+nama = len(sys.argv) > 4 and sys.argv[4] == "nama"
+s.setAlgorithm("namaAlgorithm" if nama else "globalFbeAlgorithm", 5)
+run = s.algorithmNama if nama else s.algorithmGlobalFbe
+run(3)
 t = time.perf_counter()
-h, v, tau = s.algorithmGlobalFbe(iters)
+h, v, tau = run(iters)
 print("ms per iteration %.4f, tau %s" % (1e3 * (time.perf_counter() - t) / iters, [float(x) for x in tau[:12]]))
 s.close()
