@@ -393,6 +393,9 @@ struct Ctx : CtxBase {
         for (void *p : ipcOpened) (void)hipIpcCloseMemHandle(p);
         if (d_inbox) (void)hipFree(d_inbox);
         for (void *p : allocs) (void)hipFree(p);
+        if (evFork) (void)hipEventDestroy(evFork);
+        if (evJoin) (void)hipEventDestroy(evJoin);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -683,10 +686,11 @@ struct Ctx : CtxBase {
         UP(d_dy, dy.data(), (size_t)N * ny) UP(d_blo, blo.data(), ny) UP(d_bhi, bhi.data(), ny)
 #undef UP
         if (d_Wp) { if (int rc = upload_padded(d_Wp, s->costW, nu, nu)) return rc; }   // k_value_mfma's copy of W (rn_set_algorithm may come before the factor step)
+        if (int rc = stream_split_setup()) return rc;
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
             if (int rc = dalloc(&d_A, (size_t)d.nodes * strideA)) return rc;
+            if (std::getenv("RAPIDNET_DEBUG_ALLOC")) std::fprintf(stderr, "rapidnet: operator blocks at %p, %zu bytes\n", (void *)d_A, (size_t)d.nodes * strideA * sizeof(T));
         }
-        if (int rc = stream_split_setup()) return rc;
         RN_HIP(hipMemsetAsync(d_my, 0, (size_t)d.nodes * 2 * nv * sizeof(T), stream));   // structured mode never writes m1
         ExpandArgs<T> ea{};
         ea.tr = tree_dev(); ea.nx = nx; ea.nu = nu; ea.nv = nv; ea.ny = ny; ea.LD = LD; ea.strideA = strideA; ea.nodes = d.nodes;
@@ -1037,9 +1041,9 @@ struct Ctx : CtxBase {
     void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
-        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_sk, nv + nx, d_v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk, nv + nx, a.v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
-        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), d_v, nv, d_lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
+        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
@@ -1071,8 +1075,8 @@ struct Ctx : CtxBase {
             return;
         }
 #endif
-        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, d_sk, nv + nx, d_v, nv, a.my, 2 * nv);
-        launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, d_v, nv, d_lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
+        launch_gemm<EPI_V>(d_RTp, nv, nv + nx, a.sk, nv + nx, a.v, nv, a.my, 2 * nv);
+        launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, a.v, nv, a.lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
     // crown handling of the forward sweep: 0 = crown launches of their own; 1 = every chain workgroup walks its crown path and
     // the first descendant chain of a crown node writes it; 2 (sharded) = crown nodes dealt round-robin to the workgroups
@@ -1215,6 +1219,24 @@ struct Ctx : CtxBase {
         RN_HIP(hipGetLastError());
         return RN_OK;
         };
+        if (pair && stream2 && !prof) {      // (while profiling every interval is bracketed on the one stream)
+            // the two right-hand sides' helper chains (five dependent, latency-bound launches each) do not touch each other's buffers:
+            // the second runs on a stream of its own with a scratch set of its own, forked behind the streaming pass and joined here
+            SweepArgs<T> b = a;
+            b.w = hessianInput2; b.my = d_myB; b.qa = d_qaB;
+            b.x = d_xdir; b.u = d_udir; b.hx = d_hxDir;
+            b.sk = d_skB; b.rkq = d_rkqB; b.v = d_vB; b.lvb = d_lvbB; b.bw = d_bwB;
+            RN_HIP(hipEventRecord(evFork, stream));
+            RN_HIP(hipStreamWaitEvent(stream2, evFork, 0));
+            std::swap(stream, stream2);
+            int rcB = helpers(b);
+            if (rcB == RN_OK && hipEventRecord(evJoin, stream) != hipSuccess) rcB = RN_E_HIP;
+            std::swap(stream, stream2);
+            if (rcB) return rcB;
+            if (int rc = helpers(a)) return rc;
+            RN_HIP(hipStreamWaitEvent(stream, evJoin, 0));
+            return RN_OK;
+        }
         if (int rc = helpers(a)) return rc;
         if (pair) {
             SweepArgs<T> b = a;
