@@ -443,6 +443,7 @@ def main():
 
     precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
     problem = synth.make_problem(args.workload)
+    data_sha256 = synth.fingerprint(problem)      # of the data as generated: taken before anything (a control step advances currentX / prevU in place) touches them
     nodes_full = int(problem["tree"]["nodes"][0])
     dh, ah = synth.forecast_at(problem["forecast"], 0)
     cut_stage = -1
@@ -841,7 +842,7 @@ def main():
                 # which data were solved: a version tag of the generator and a fingerprint of the numbers themselves.  Version f1
                 # (round 3 on) re-centres the control bounds of the BASELINE workloads for feasibility: same
                 # dimensions, operators, tree and step size -- the kernels do the same work -- but not the iterates of rounds 1-2
-                "data_version": synth.data_tag(args.workload), "data_sha256": synth.fingerprint(problem),
+                "data_version": synth.data_tag(args.workload), "data_sha256": data_sha256,
                 "ms_per_controlStep_500it": head["ms_per_controlStep_500it_derived"],
                 "ms_per_controlStep_500it_measured": head["ms_per_controlStep_500it_measured"],
                 "parallelism": "1 GPU" if not sharded else ("subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_stage if not fallback_reason[0]

@@ -54,3 +54,14 @@ def test_hip_path_matches_golden(name, k):
     assert _rel(s.get(capi.BUF_UPD_XI)[::st], g["updXi_%d" % k]) < tol
     assert _rel(s.get(capi.BUF_UPD_PSI)[::st], g["updPsi_%d" % k]) < tol
     assert _rel(hist, g["hist_%d" % k]) < tol
+
+
+@pytest.mark.parametrize("name,tag,sha", [
+    ("barcelona31", "barcelona31@f1", "103920dfca1472403653ca6f4d52b6e6c4c85ad4a9aa66838b9e59013127f13d"),
+    ("barcelona493", "barcelona493@f1", "f101b3696558280e0116267475edef9510c82363bc90f9fdda9bbca8afa9655f"),
+])
+def test_generated_data_are_the_pinned_version(name, tag, sha):
+    """the data `bench.py` solves are what BASELINE.md says they are: the generator's version tag and the fingerprint of the numbers
+    (`config.data_version` / `config.data_sha256` of the JSON line); a change of the generator has to change the tag"""
+    assert synth.data_tag(name) == tag
+    assert synth.fingerprint(synth.make_problem(name)) == sha
