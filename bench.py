@@ -86,7 +86,7 @@ def _pmc_medians(directory, counter):
     return {k: (statistics.median(v.values()), len(v)) for k, v in out.items()}
 
 
-def measure_traffic(args):
+def measure_traffic(args, extra_probe_args=(), launcher_env=False):
     """HBM bytes per launch of k_stream_gemv and of the fused dual update FROM THE PMC COUNTERS OF THIS RUN, collected as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: FETCH_SIZE and WRITE_SIZE in separate passes
     (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-probe ...`, the program itself behind `--`),
@@ -107,7 +107,10 @@ def measure_traffic(args):
         return {}, src
     tmp = tempfile.mkdtemp(prefix="rn_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    probe = ["python3", os.path.abspath(__file__), "--traffic-probe", "--workload", args.workload, "--steps", "40", "--warmup", "20"]
+    if launcher_env:     # called by a rank's supervisor: the probe is a one-process run of its own, not a rank of this job
+        env = {k: v for k, v in env.items() if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE",
+                                                                                                "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "RAPIDNET_BENCH_FAULT"))}
+    probe = ["python3", os.path.abspath(__file__), "--traffic-probe", "--workload", args.workload, "--steps", "40", "--warmup", "20"] + list(extra_probe_args)
     if args.precision:
         probe += ["--precision", args.precision]
     med = {}
@@ -273,7 +276,16 @@ def supervise(args):
         th.join(10.0)
         return rc, found[0]
 
-    rc, line = run_worker(base, dict(os.environ), '"metric"', None)
+    wenv = dict(os.environ)
+    if rank == 0 and not (args.no_traffic or args.structured or args.alt_exchange_only or args.traffic_probe):
+        # HBM traffic of rank 0's shard from the PMC counters: two one-process runs of the sharded path on this rank's device
+        # (`--emulate-world N`: rank 0's shard, one-rank communicator) under rocprofv3, before the rank's worker starts -- the other
+        # ranks' workers wait for it in the rendezvous.  Handed to the worker, which puts it into `roofline.traffic`.
+        t, src = measure_traffic(args, ("--emulate-world", str(world)), launcher_env=True)
+        if isinstance(src, dict) and src.get("how"):
+            src["how"] = "rank 0's shard, measured by one-process runs of the sharded path (--emulate-world %d) on rank 0's device before the job: " % world + src["how"]
+        wenv["RAPIDNET_BENCH_TRAFFIC_JSON"] = json.dumps({"traffic": t, "source": src})
+    rc, line = run_worker(base, wenv, '"metric"', None)
     if rc != 0:
         print("bench.py rank %d: the worker ended with code %s" % (rank, rc), file=sys.stderr, flush=True)
         os._exit(rc if rc and rc > 0 else 1)
@@ -387,6 +399,12 @@ def main():
     measured_traffic, measured_source = ({}, None)
     if world == 1 and args.gpus == 1 and not args.no_traffic and not args.structured and not args.force_shard and args.emulate_world == 0:
         measured_traffic, measured_source = measure_traffic(args)   # child processes; nothing in this process has touched the GPU yet
+    if world > 1 and os.environ.get("RAPIDNET_BENCH_TRAFFIC_JSON"):      # rank 0's worker: what its supervisor measured before starting it
+        try:
+            handed = json.loads(os.environ["RAPIDNET_BENCH_TRAFFIC_JSON"])
+            measured_traffic, measured_source = handed.get("traffic") or {}, handed.get("source")
+        except ValueError:
+            pass
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
@@ -692,7 +710,7 @@ def main():
             # collected on this workload with exactly the kernel sources this run executes; traffic_source says which
             traffic, traffic_source = {}, {"measured_in_this_run": False, "file": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if measured_traffic and workload == args.workload and not sharded:
+            if measured_traffic and workload == args.workload and (not sharded or (world > 1 and rank == 0)):   # N > 1: rank 0's shard, measured by its supervisor
                 traffic, traffic_source = measured_traffic, measured_source
             elif os.path.exists(tpath) and workload == "barcelona493" and precision == "f64" and not sharded:
                 try:

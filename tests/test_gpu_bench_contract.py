@@ -107,6 +107,10 @@ def test_gpus_2_spawns_its_own_ranks():
     w = d["configs"][0]
     assert "error" not in w, w
     assert w["n_gpus"] == 2 and w["dtype"] == "f32" and w["value"] > 0 and sum(w["per_rank"]["local_nodes"]) == 86289 + 273 and w["cpu_baseline"]["value"] > 0
+    # HBM traffic of rank 0's shard from the PMC counters (measured by rank 0's supervisor through one-process runs of the sharded path)
+    rf = d["roofline"]
+    assert rf["traffic_source"]["measured_in_this_run"] and "rank 0's shard" in rf["traffic_source"]["how"], rf["traffic_source"]
+    assert 0.99 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.05 * rf["algorithmic_bytes_per_launch"]
     # the one-shot exchange pass is attempted last and reported either way (here: no RCCL communicator, so it says why it did not run)
     assert "alt_exchange" in d and ("error" in d["alt_exchange"] or d["alt_exchange"]["value"] > 0), d.get("alt_exchange")
 
