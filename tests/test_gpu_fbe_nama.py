@@ -202,6 +202,23 @@ def test_loop_matches_oracle(name, structured, alg):
 
 
 @pytest.mark.parametrize("alg", ALGS)
+def test_loop_matches_oracle_at_the_headline_dimensions(alg):
+    """the 31-scenario Barcelona-sized tree (nx = 63, nu = 114, nv = 97: the headline's per-node dimensions, so the streaming kernel runs
+    its two-slots-per-thread instantiation -- with two right-hand sides in NAMA -- and k_value_mfma its eight-tile, 32-k-step form
+    with W in registers) against the oracle: same step lengths, same values, same iterates"""
+    p, o, s = make_pair("barcelona31", alg)
+    iters = 8
+    ho, vo, to = o.fbe_nama(iters)
+    hs, vs, ts = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(iters)
+    assert np.array_equal(ts, to), (ts, to)
+    assert relmax(vs, vo) < REL_TOL
+    assert relmax(hs, ho) < 1e-7
+    compare_fbe(s, o, alg, 1e-8, "%s barcelona31 after %d iterations" % (alg, iters))
+    c = s.fbeCounters()
+    assert c["sequential"] == 0 and (alg != "namaAlgorithm" or c["sweep_pairs"] == iters - 1), c
+
+
+@pytest.mark.parametrize("alg", ALGS)
 def test_algorithm_selected_before_the_factor_step(alg):
     """the order of the C++ host (Engine::create selects the algorithm right after rn_create, the factor step comes later): everything
     the loops derive from the uploaded system -- k_value_mfma's padded copy of W among it -- must be (re)built by the factor step"""
