@@ -134,3 +134,30 @@ def test_control_step_is_bitwise_repeatable(problem):
     assert np.array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("alg", ["globalFbeAlgorithm", "namaAlgorithm"])
+def test_fbe_nama_loops_against_the_oracle_at_full_size(problem, alg):
+    """the quasi-Newton loops on the 10 864-node tree (three sweeps per iteration; NAMA's pair of Hessian sweeps in one pass over the
+    4 GB of operator blocks, the value terms on the matrix cores, the batched line search): same accepted steps as the oracle, values
+    and iterates within the bounds of the small-tree tests"""
+    from oracle.oracle import Oracle
+
+    p, (dh, ah) = problem
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.set_algorithm(alg, 5)
+    o.initialise(dh, ah)
+    o.fbe_reset()
+    s = _solver(problem, False)
+    s.setAlgorithm(alg, 5)
+    iters = 6
+    ho, vo, to = o.fbe_nama(iters)
+    hs, vs, ts = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(iters)
+    assert np.array_equal(ts, to), (ts, to)
+    assert relmax(vs, vo) < 1e-9
+    for bid, nm in ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_XI, "xi"), (capi.BUF_PSI, "psi"), (capi.BUF_LBFGS_DIR_XI, "dirXi"), (capi.BUF_LBFGS_DIR_PSI, "dirPsi")):
+        assert relmax(s.get(bid), o.get(nm)) < 1e-8, nm
+    assert np.abs(hs - ho).max() <= 1e-7 * np.abs(ho).max()
+    c = s.fbeCounters()
+    assert c["sequential"] == 0 and (alg != "namaAlgorithm" or c["sweep_pairs"] == iters - 1), c
+    s.close()
