@@ -304,7 +304,20 @@ def make_feasible(problem, margin=0.25):
 
 
 def make_problem(name, max_iterations=500, sim_horizon=2, penalty_x=1e6, penalty_xs=1e4, step_size=None, feasible=None):
-    """Returns {"network","tree","config","forecast"} dicts (reference JSON schema) for a named config."""
+    """Returns {"network","tree","config","forecast"} dicts (reference JSON schema) for a named config.
+
+    The generator's linear algebra (an SVD, a least-squares solve, matrix products) runs with ONE BLAS thread: a threaded BLAS
+    blocks its reductions by the thread count, so the same seed gave data that differed in the last bits between a 256-thread host
+    and an 8-thread one (`fingerprint` told them apart: bench lines of one round carried two different `data_sha256`)."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:      # not installed: the data are then only reproducible per host
+        return _make_problem(name, max_iterations, sim_horizon, penalty_x, penalty_xs, step_size, feasible)
+    with threadpool_limits(limits=1):
+        return _make_problem(name, max_iterations, sim_horizon, penalty_x, penalty_xs, step_size, feasible)
+
+
+def _make_problem(name, max_iterations, sim_horizon, penalty_x, penalty_xs, step_size, feasible):
     if name.endswith("_infeasible") and name[:-11] in CONFIGS:
         name, feasible = name[:-11], False
     if feasible is None:
