@@ -727,6 +727,8 @@ def main():
                         traffic_source["not_measured_in_this_run_because"] = measured_source["why_not"]
                 except Exception:
                     traffic = {}
+            if not traffic and measured_source and measured_source.get("why_not"):
+                traffic_source.setdefault("why_not", measured_source["why_not"])
             dual["traffic"] = traffic.get("k_dual_stage_bytes_per_launch" if kinfo["dual_stage"] else "k_dual_fused_bytes_per_launch")
             if structured:   # no streaming kernel: the fused dual update is the dominant (HBM-bound) kernel
                 roofline = {"kernel": dual_kernel, "bound": "hbm", "achieved": dual["achieved"], "peak": 8000.0, "unit": "GB/s",

