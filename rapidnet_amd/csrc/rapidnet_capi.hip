@@ -849,13 +849,7 @@ struct Ctx : CtxBase {
         int G, NL;
         stream_shape(&G, &NL);
         const int D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE, groups = (ny / G) / D;
-        int r = d.nodes % numCUs;
-        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
-        bool forcedR = false;
-        if (const char *e = std::getenv("RAPIDNET_STREAM_SPLIT_R")) {   // tuning runs: how many blocks at the end of the launch are dealt to two workgroups
-            const int want = std::atoi(e);
-            if (want > 0) { r = std::min(want, std::min(STREAM_SPLIT_STAGES * K, d.nodes - 1)); forcedR = true; }
-        }
+        const int r = d.nodes % numCUs, cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
         // which instantiation the launches run: the one with the split's second code path allocates fewer registers (122 instead of
         // 150), so two workgroups share a CU -- start-up and drain of the launch overlap better, the steady state is slower in fp64 and
         // FASTER in fp32 (half-size blocks: the per-workgroup prologue and epilogue weigh double there).  Same-box A/B, one | two per
@@ -864,7 +858,7 @@ struct Ctx : CtxBase {
         // = 0.84 of the HBM peak).  So: fp32 always, fp64 for launches of fewer than 8 rounds.
         streamTwoPerCU = sizeof(T) == 4 || d.nodes < 8 * numCUs;
         if (const char *e = std::getenv("RAPIDNET_STREAM_KERNEL")) streamTwoPerCU = std::atoi(e) != 0;   // tuning runs
-        if (!mode || !streamTwoPerCU || structured || d.nodes <= numCUs || r == 0 || (2 * r > numCUs && !forcedR) || groups < 2) return RN_OK;
+        if (!mode || !streamTwoPerCU || structured || d.nodes <= numCUs || r == 0 || 2 * r > numCUs || groups < 2) return RN_OK;
         if (d.N - cs < STREAM_SPLIT_STAGES || r > STREAM_SPLIT_STAGES * K) return RN_OK;     // (the cut never moves the chain region's END)
         if (int rc = dalloc(&d_my2, (size_t)r * 2 * d.nv)) return rc;
         splitFirst = d.nodes - r;
