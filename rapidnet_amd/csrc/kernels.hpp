@@ -286,6 +286,9 @@ struct SweepArgs {
     // 0: the primal iterates x, u, v are not stored by this sweep (inner iterations of a device-resident batch: only Hx feeds
     // the dual update; the last iteration of every batch and every step-wise call store them)
     int writePrimal;
+    // the few tree-table entries the crown steps start from, by value (a table load in front of the first batch of requests is one
+    // more dependent round trip on the critical workgroup of the v / Lv launch): stageCum[1], stageCum[2], childStart[0], childCount[0]
+    int s1, e1, rootC0, rootNc;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -1016,7 +1019,7 @@ __device__ __forceinline__ void up_crown_presummed_flat(const SweepArgs<T> &a, i
 template <typename T>
 __device__ __forceinline__ void up_root_from_presummed(const SweepArgs<T> &a, int tid, int nthreads) {
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
-    const int c0 = a.tr.childStart[0], nc = a.tr.childCount[0], s1 = a.tr.stageCum[1];
+    const int c0 = a.rootC0, nc = a.rootNc, s1 = a.s1;
     for (int t = tid; t < per; t += nthreads) {
         if (t < nv) {
             T sum = 0;
@@ -1065,7 +1068,7 @@ __device__ __forceinline__ void up_root_from_presummed(const SweepArgs<T> &a, in
 template <typename T>
 __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int tid, int nthreads, T *slab = nullptr, int SB = 0) {
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx, per = nv + nx;
-    const int c0n = a.tr.childStart[0], nc = a.tr.childCount[0], s1 = a.tr.stageCum[1];
+    const int c0n = a.rootC0, nc = a.rootNc, s1 = a.s1;
     const int total = nc * per;
     // the root's own terms, requested with the first batch
     T rb = 0, rm = 0;
@@ -1644,7 +1647,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     // derives the root's step from the same inputs (up_root_from_presummed).
     RN_KT(0);
     if (foldRoot == 2) {
-        const int s1 = a.tr.stageCum[1], e1 = a.tr.stageCum[2];
+        const int s1 = a.s1, e1 = a.e1;
         const int lo = s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16;
         const int hi = e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16;
         if (ONESHOT && a.peer.nranks > 0 && (blockIdx.x == 0 || lo < hi)) {   // one-shot exchange: the workgroups that use the all-reduced sums take them out of the inbox
@@ -1669,7 +1672,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
         // has swept the caches and TLBs
         // (RN_CROWN2_FALLBACK builds force the two-function path below, which otherwise only very wide crowns take)
-        if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && crownScratch > 0 && a.tr.stageCum[2] >= 16 && (int)blockDim.x >= a.nv + a.nx) {
+        if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && crownScratch > 0 && a.e1 >= 16 && (int)blockDim.x >= a.nv + a.nx) {
             // all 16 nodes of this workgroup's slab are crown nodes: their [s; kappa] columns go straight into the slab buffer (the
             // children's values through a scratch area BEHIND the slab buffers, sized by the host), so the launch's critical
             // workgroup neither drains its stores nor reads its slab back from global memory
@@ -1679,7 +1682,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
                 for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) sB[(i / padc) * SB + per + i % padc] = (T)0;
             }
             slabReady = true;
-        } else if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && a.tr.childCount[0] * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
+        } else if (!RN_CROWN2_FALLBACK && blockIdx.x == 0 && a.rootNc * (a.nv + 2 * a.nx) <= 16 * (SB + SV) && (int)blockDim.x >= a.nv + a.nx) {
             up_crown2_wg0<T>(a, sB, threadIdx.x, blockDim.x);
         } else {
             if (blockIdx.x == 0) up_root_from_presummed<T>(a, threadIdx.x, blockDim.x);

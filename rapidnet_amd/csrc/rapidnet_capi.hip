@@ -506,6 +506,8 @@ struct Ctx : CtxBase {
         a.tr = tree_dev();
         a.nx = d.nx; a.nu = d.nu; a.nv = d.nv; a.ny = ny; a.LD = LD; a.strideA = strideA; a.N = d.N; a.nodes = d.nodes;
         a.cutSums = (cutStage > 0) ? d_cut : nullptr;
+        a.s1 = h_stageCum.size() > 1 ? h_stageCum[1] : d.nodes; a.e1 = h_stageCum.size() > 2 ? h_stageCum[2] : d.nodes;
+        a.rootC0 = h_childStart.empty() ? 0 : h_childStart[0]; a.rootNc = h_childCount.empty() ? 0 : h_childCount[0];
         a.cutStage = cutStage;
         a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
         a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
