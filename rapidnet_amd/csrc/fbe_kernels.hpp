@@ -129,16 +129,24 @@ __global__ void k_lbfgs_diffs(T *S, T *Y, const T *y, const T *yPrev, const T *g
     }
 }
 
+// scale * (an update that has been rounded already): the product must not be contracted into the update's multiply-add
+template <typename T>
+__device__ __forceinline__ T lbfgs_scaled(T scale, T rounded) {
+#pragma clang fp contract(off)
+    return scale * rounded;
+}
 // One step of the two-loop recursion AND the dot product the next step needs, in one pass over the direction
 // (SmpcController::twoLoopRecursionLbfgs, SmpcController.cu:1175-1229; the reference issues Sdot + Saxpy per step):
 //   mode -1: dir = scale * src                          (start: src = gradient, scale = -1; between the loops: src = dir, scale = H0)
 //   mode  0: alpha_c = rho_c scal[0]; dir -= alpha_c vec           (vec = Y_c)
 //   mode  1: dir += (alpha_c - rho_c scal[0]) vec                  (vec = S_c)
 //   next != nullptr: partials[block][0] = <next, dir_new> over the block's elements (k_dots order), for k_dots_finish
+//   post != 0 (with mode 0, the first loop's last step): the scaling between the loops rides along, dir = scale * (dir - alpha_c vec)
+//   -- the update rounded as the step stores it, then the product: the two roundings of the two passes it replaces
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *src, const T *vec, const double *scal, double rho, double *alphaArr, int c,
                                                              int mode, T scale, const T *next, double *partials, long long n, long long first,
-                                                             const double *prevPartials, int nPrev) {
+                                                             const double *prevPartials, int nPrev, int post = 0) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     T coef = 0;
@@ -166,7 +174,11 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
             d = reinterpret_cast<VT *>(dir)[i];
             const VT vv = reinterpret_cast<const VT *>(vec)[i];
 #pragma unroll
-            for (int e = 0; e < VN; e++) d[e] += coef * vv[e];
+            for (int e = 0; e < VN; e++) d[e] = fma_rn(coef, vv[e], d[e]);      // one rounding, spelled out (not left to the compiler's contraction choice)
+            if (post) {
+#pragma unroll
+                for (int e = 0; e < VN; e++) d[e] = lbfgs_scaled(scale, d[e]);
+            }
         }
         reinterpret_cast<VT *>(dir)[i] = d;
         if (next) {
@@ -177,7 +189,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
     }
     for (long long i = nvec * VN + gid; i < n; i += stride) {
         T d;
-        if (mode < 0) d = scale * src[i]; else { d = dir[i]; d += coef * vec[i]; }
+        if (mode < 0) d = scale * src[i]; else { d = fma_rn(coef, vec[i], dir[i]); if (post) d = lbfgs_scaled(scale, d); }
         dir[i] = d;
         if (next && i >= first) acc[0] += (double)next[i] * (double)d;
     }
