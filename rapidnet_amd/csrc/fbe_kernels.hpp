@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, co
     double acc[DOT_MAX];
 #pragma unroll
     for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
-    const long long nvec = n / VN;   // the six vectors are allocations of their own: 16-byte aligned
+    // S and Y are L-BFGS columns after the first accepted pairs (columns are exchanged with the scratch pair, not copied): a column
+    // starts at a multiple of n values, 16-byte aligned only if n allows -- otherwise the scalar walk, as in k_dots
+    const unsigned long long misal = (unsigned long long)S | (unsigned long long)Y | (unsigned long long)y | (unsigned long long)yPrev | (unsigned long long)g | (unsigned long long)gPrev;
+    const long long nvec = (misal & 15ull) ? 0 : n / VN;
     const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
     for (long long i = gid; i < nvec; i += stride) {
         const VT yv = reinterpret_cast<const VT *>(y)[i], ypv = reinterpret_cast<const VT *>(yPrev)[i];
