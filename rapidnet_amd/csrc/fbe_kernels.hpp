@@ -62,13 +62,13 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
             if (j < g.cnt) {
                 const VT av = reinterpret_cast<const VT *>(g.a[j])[i], bv = reinterpret_cast<const VT *>(g.b[j])[i];
 #pragma unroll
-                for (int e = 0; e < VN; e++) acc[j] += (i * VN + e >= g.first) ? (double)av[e] * (double)bv[e] : 0.0;
+                for (int e = 0; e < VN; e++) if (i * VN + e >= g.first) acc[j] = fma_rn((double)av[e], (double)bv[e], acc[j]);
             }
     }
     for (long long i = nvec * VN + (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < g.n; i += (long long)gridDim.x * ELT_THREADS) {
 #pragma unroll
         for (int j = 0; j < DOT_MAX; j++)
-            if (j < g.cnt && i >= g.first) acc[j] += (double)g.a[j][i] * (double)g.b[j][i];
+            if (j < g.cnt && i >= g.first) acc[j] = fma_rn((double)g.a[j][i], (double)g.b[j][i], acc[j]);
     }
     dots_block_reduce(acc, g.partials);
 }
@@ -141,12 +141,14 @@ __device__ __forceinline__ T lbfgs_scaled(T scale, T rounded) {
 //   mode  0: alpha_c = rho_c scal[0]; dir -= alpha_c vec           (vec = Y_c)
 //   mode  1: dir += (alpha_c - rho_c scal[0]) vec                  (vec = S_c)
 //   next != nullptr: partials[block][0] = <next, dir_new> over the block's elements (k_dots order), for k_dots_finish
+//   src != nullptr with mode 0 (the first loop's first step inside the loops): the direction is not read but formed, dir = srcScale * src
+//   (= -gradient: the start of the recursion rides along; its dot product came out of k_lbfgs_diffs_dots)
 //   post != 0 (with mode 0, the first loop's last step): the scaling between the loops rides along, dir = scale * (dir - alpha_c vec)
 //   -- the update rounded as the step stores it, then the product: the two roundings of the two passes it replaces
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *src, const T *vec, const double *scal, double rho, double *alphaArr, int c,
                                                              int mode, T scale, const T *next, double *partials, long long n, long long first,
-                                                             const double *prevPartials, int nPrev, int post = 0) {
+                                                             const double *prevPartials, int nPrev, int post = 0, T srcScale = 0) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     T coef = 0;
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
     double acc[DOT_MAX];
 #pragma unroll
     for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
-    const unsigned long long misal = (unsigned long long)dir | (unsigned long long)(mode < 0 ? src : vec) | (unsigned long long)(next ? next : dir);
+    const unsigned long long misal = (unsigned long long)dir | (unsigned long long)(mode < 0 ? src : vec) | (unsigned long long)(next ? next : dir) | (unsigned long long)(src ? src : dir);
     const long long nvec = (misal & 15ull) ? 0 : n / VN;
     const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
     for (long long i = gid; i < nvec; i += stride) {
@@ -171,7 +173,11 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
 #pragma unroll
             for (int e = 0; e < VN; e++) d[e] = scale * sv[e];
         } else {
-            d = reinterpret_cast<VT *>(dir)[i];
+            if (src) {
+                const VT sv = reinterpret_cast<const VT *>(src)[i];
+#pragma unroll
+                for (int e = 0; e < VN; e++) d[e] = srcScale * sv[e];
+            } else d = reinterpret_cast<VT *>(dir)[i];
             const VT vv = reinterpret_cast<const VT *>(vec)[i];
 #pragma unroll
             for (int e = 0; e < VN; e++) d[e] = fma_rn(coef, vv[e], d[e]);      // one rounding, spelled out (not left to the compiler's contraction choice)
@@ -184,14 +190,14 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
         if (next) {
             const VT nv = reinterpret_cast<const VT *>(next)[i];
 #pragma unroll
-            for (int e = 0; e < VN; e++) acc[0] += (i * VN + e >= first) ? (double)nv[e] * (double)d[e] : 0.0;
+            for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[0] = fma_rn((double)nv[e], (double)d[e], acc[0]);
         }
     }
     for (long long i = nvec * VN + gid; i < n; i += stride) {
         T d;
-        if (mode < 0) d = scale * src[i]; else { d = fma_rn(coef, vec[i], dir[i]); if (post) d = lbfgs_scaled(scale, d); }
+        if (mode < 0) d = scale * src[i]; else { d = fma_rn(coef, vec[i], src ? srcScale * src[i] : dir[i]); if (post) d = lbfgs_scaled(scale, d); }
         dir[i] = d;
-        if (next && i >= first) acc[0] += (double)next[i] * (double)d;
+        if (next && i >= first) acc[0] = fma_rn((double)next[i], (double)d, acc[0]);
     }
     // the coefficient of the first loop is kept for the second one; written after every block has read scal / alphaArr is not
     // required: nobody reads alphaArr[c] in mode 0, and the next launch is stream-ordered behind this one
@@ -202,7 +208,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_fused(T *dir, const T *sr
 // H0 scaling need (<g,g>, <S,Y>, <Y,Y>, <S,S>, :1131-1156) in the same pass
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, const T *y, const T *yPrev, const T *g, const T *gPrev, double *partials, long long n,
-                                                                  long long first) {
+                                                                  long long first, int extra = 0, const T *sPrev = nullptr) {
+    // extra != 0 (inside the loops): also <S, g> (dot 4) and <sPrev, g> (dot 5; sPrev = the newest column so far, may be null) -- whichever
+    // of the two is the newest column after the host's skip decision, its negative is the dot product the two-loop recursion starts with
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     double acc[DOT_MAX];
@@ -210,7 +218,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, co
     for (int j = 0; j < DOT_MAX; j++) acc[j] = 0;
     // S and Y are L-BFGS columns after the first accepted pairs (columns are exchanged with the scratch pair, not copied): a column
     // starts at a multiple of n values, 16-byte aligned only if n allows -- otherwise the scalar walk, as in k_dots
-    const unsigned long long misal = (unsigned long long)S | (unsigned long long)Y | (unsigned long long)y | (unsigned long long)yPrev | (unsigned long long)g | (unsigned long long)gPrev;
+    const unsigned long long misal = (unsigned long long)S | (unsigned long long)Y | (unsigned long long)y | (unsigned long long)yPrev | (unsigned long long)g | (unsigned long long)gPrev |
+                                     (unsigned long long)(sPrev ? sPrev : g);
     const long long nvec = (misal & 15ull) ? 0 : n / VN;
     const long long stride = (long long)gridDim.x * ELT_THREADS, gid = (long long)blockIdx.x * ELT_THREADS + threadIdx.x;
     for (long long i = gid; i < nvec; i += stride) {
@@ -223,19 +232,29 @@ __global__ void __launch_bounds__(ELT_THREADS) k_lbfgs_diffs_dots(T *S, T *Y, co
         reinterpret_cast<VT *>(Y)[i] = dv;
         if (i * VN + VN - 1 < first) continue;    // replicated crown elements: counted on rank 0 only (first = 0 there)
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (i * VN + e >= first) ? (double)gv[e] * (double)gv[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[0] = fma_rn((double)gv[e], (double)gv[e], acc[0]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (i * VN + e >= first) ? (double)sv[e] * (double)dv[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[1] = fma_rn((double)sv[e], (double)dv[e], acc[1]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[2] += (i * VN + e >= first) ? (double)dv[e] * (double)dv[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[2] = fma_rn((double)dv[e], (double)dv[e], acc[2]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[3] += (i * VN + e >= first) ? (double)sv[e] * (double)sv[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[3] = fma_rn((double)sv[e], (double)sv[e], acc[3]);
+        if (extra) {
+#pragma unroll
+            for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[4] = fma_rn((double)sv[e], (double)gv[e], acc[4]);
+            if (sPrev) {
+                const VT pv = reinterpret_cast<const VT *>(sPrev)[i];
+#pragma unroll
+                for (int e = 0; e < VN; e++) if (i * VN + e >= first) acc[5] = fma_rn((double)pv[e], (double)gv[e], acc[5]);
+            }
+        }
     }
     for (long long i = nvec * VN + gid; i < n; i += stride) {
         const T sv = y[i] - yPrev[i], dv = g[i] - gPrev[i];
         S[i] = sv; Y[i] = dv;
         if (i < first) continue;
-        acc[0] += (double)g[i] * (double)g[i]; acc[1] += (double)sv * (double)dv; acc[2] += (double)dv * (double)dv; acc[3] += (double)sv * (double)sv;
+        acc[0] = fma_rn((double)g[i], (double)g[i], acc[0]); acc[1] = fma_rn((double)sv, (double)dv, acc[1]); acc[2] = fma_rn((double)dv, (double)dv, acc[2]); acc[3] = fma_rn((double)sv, (double)sv, acc[3]);
+        if (extra) { acc[4] = fma_rn((double)sv, (double)g[i], acc[4]); if (sPrev) acc[5] = fma_rn((double)sPrev[i], (double)g[i], acc[5]); }
     }
     dots_block_reduce(acc, partials);
 }
@@ -269,16 +288,16 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg
             r[e] = hx[e] - z[e];
             gn[e] = -r[e];
             const double diff = (a.countCrown || i * VN + e >= a.crownElems) ? (double)(t - z[e]) : 0.0;   // sharded: the replicated crown counts on rank 0 only
-            if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
+            if (c < nx) d2x = fma_rn(diff, diff, d2x); else if (c < 2 * nx) d2s = fma_rn(diff, diff, d2s);
             if (++c == ny) c = 0;
         }
         reinterpret_cast<VT *>(a.z)[i] = z;
         reinterpret_cast<VT *>(a.res)[i] = r;
         if (gneg) reinterpret_cast<VT *>(gneg)[i] = gn;
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)w[e] * (double)r[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (a.countCrown || i * VN + e >= a.crownElems) acc[0] = fma_rn((double)w[e], (double)r[e], acc[0]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)r[e] * (double)r[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (a.countCrown || i * VN + e >= a.crownElems) acc[1] = fma_rn((double)r[e], (double)r[e], acc[1]);
         c0 += cstep; if (c0 >= ny) c0 -= ny;
     }
     for (long long i = nvec * VN + gid; i < a.n; i += stride) {
@@ -290,8 +309,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_res(DualArgs<T> a, T *gneg
         if (gneg) gneg[i] = -r;
         if (!a.countCrown && i < a.crownElems) continue;
         const double diff = (double)(t - z);
-        if (c < nx) d2x += diff * diff; else if (c < 2 * nx) d2s += diff * diff;
-        acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r;
+        if (c < nx) d2x = fma_rn(diff, diff, d2x); else if (c < 2 * nx) d2s = fma_rn(diff, diff, d2s);
+        acc[0] = fma_rn((double)a.w[i], (double)r, acc[0]); acc[1] = fma_rn((double)r, (double)r, acc[1]);
     }
     for (int off = 32; off > 0; off >>= 1) { d2x += __shfl_down(d2x, off); d2s += __shfl_down(d2s, off); }
     if ((threadIdx.x & 63) == 0) { sx[threadIdx.x >> 6] = d2x; ss[threadIdx.x >> 6] = d2s; }
@@ -329,13 +348,13 @@ __global__ void __launch_bounds__(ELT_THREADS) k_prox_soft_res(DualArgs<T> a, T 
 #pragma unroll
         for (int e = 0; e < VN; e++) r[e] = one(i * VN + e);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[0] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)a.w[i * VN + e] * (double)r[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (a.countCrown || i * VN + e >= a.crownElems) acc[0] = fma_rn((double)a.w[i * VN + e], (double)r[e], acc[0]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) acc[1] += (a.countCrown || i * VN + e >= a.crownElems) ? (double)r[e] * (double)r[e] : 0.0;
+        for (int e = 0; e < VN; e++) if (a.countCrown || i * VN + e >= a.crownElems) acc[1] = fma_rn((double)r[e], (double)r[e], acc[1]);
     }
     for (long long i = nvec * VN + gid; i < a.n; i += stride) {
         const T r = one(i);
-        if (a.countCrown || i >= a.crownElems) { acc[0] += (double)a.w[i] * (double)r; acc[1] += (double)r * (double)r; }
+        if (a.countCrown || i >= a.crownElems) { acc[0] = fma_rn((double)a.w[i], (double)r, acc[0]); acc[1] = fma_rn((double)r, (double)r, acc[1]); }
     }
     dots_block_reduce(acc, dotPartials);
 }
@@ -544,9 +563,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_ls_eval(DualArgs<T> a, const T 
                 const T r = hx - z;
                 if (counted) {
                     const double diff = (double)(t - z);
-                    acc[c][0] += (double)w * (double)r;
-                    acc[c][1] += (double)r * (double)r;
-                    if (col < nx) acc[c][2] += diff * diff; else if (col < 2 * nx) acc[c][3] += diff * diff;
+                    acc[c][0] = fma_rn((double)w, (double)r, acc[c][0]);
+                    acc[c][1] = fma_rn((double)r, (double)r, acc[c][1]);
+                    if (col < nx) acc[c][2] = fma_rn(diff, diff, acc[c][2]); else if (col < 2 * nx) acc[c][3] = fma_rn(diff, diff, acc[c][3]);
                 }
             }
         }
