@@ -831,11 +831,18 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
 // 62 x 223 values back) disappears.  Children are added in ascending order, as k_cut_partial_sums does.  One more workgroup
 // (blockIdx = nParents, when fin.partials != nullptr) does the bookkeeping of the previous iteration's dual update.
 constexpr int UPCUT_THREADS = 1024;
-template <typename T, bool SPLIT = false>
+// GATHER (one-shot exchange): every workgroup takes the other ranks' packets for ITS parent out of the inbox right behind its own pushes
+// and leaves the all-rank sums in `out` -- what the collective would have left there -- so the exchange is gathered by as many
+// workgroups as there are cut parents (223 values x ranks each) instead of by the one critical workgroup of the v / Lv launch
+// (3 791 x ranks: +5 us there), and every later kernel is the RCCL path's.  The dist^2 tail is gathered by the bookkeeping workgroup.
+template <typename T, bool SPLIT = false, bool GATHER = false>
 __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, T *out, int nParents, int lanesPer, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
         if (threadIdx.x >= ELT_THREADS) return;      // the bookkeeping is written for ELT_THREADS threads
-        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
+        const unsigned int tailIdx = (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx);
+        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, tailIdx);
+        if (GATHER && a.peer.nranks > 0 && a.peerTail && threadIdx.x < 64)      // (the wave of thread 0, which pushed the local tail)
+            peer_gather_small<T>(a.peer, a.peerSeq, out, (int)tailIdx, (int)tailIdx + 2, threadIdx.x, 64, reinterpret_cast<IterState *>(a.iterState));
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -922,6 +929,8 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
         out[(size_t)blockIdx.x * w + tt] = sum;
         if (a.peer.nranks > 0) peer_push(a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)tt, sum);   // one-shot exchange: straight to every peer
     }
+    if (GATHER && a.peer.nranks > 0)      // (thread tt gathers the very elements it pushed)
+        peer_gather_small<T>(a.peer, a.peerSeq, out, (int)blockIdx.x * w, ((int)blockIdx.x + 1) * w, threadIdx.x, UPCUT_THREADS, reinterpret_cast<IterState *>(a.iterState));
 }
 // Crown region (stages < c*), one node: children are summed explicitly (loads batched CHAIN_PF at a time).
 template <typename T>

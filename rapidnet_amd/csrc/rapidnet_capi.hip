@@ -1152,8 +1152,15 @@ struct Ctx : CtxBase {
             FinArgs fin{};
             if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             const size_t ldsCut = (size_t)(UPCUT_THREADS / lanesPer) * (nv + 2 * nx) * sizeof(T);
-            if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
-            else hipLaunchKernelGGL((k_up_chain_cut<T, false>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+            // one-shot exchange: gathered right here, by every cut parent's own workgroup (RAPIDNET_ONESHOT_GATHER=0: by the crown kernels, the first form)
+            static const int gatherHere = [] { const char *e = std::getenv("RAPIDNET_ONESHOT_GATHER"); return e ? std::atoi(e) : 1; }();
+            const int grid = nk(k) + (pendingFin ? 1 : 0);
+            if (oneShot && gatherHere) {
+                if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+                else hipLaunchKernelGGL((k_up_chain_cut<T, false, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+                a.peer.nranks = 0;      // d_cut holds the all-rank sums: every later launch of this sweep is the collective path's
+            } else if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
+            else hipLaunchKernelGGL((k_up_chain_cut<T, false>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
             pendingFin = false;
         } else if (phase != 2) {
             // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
