@@ -1218,10 +1218,13 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
 // iteration counter and puts the rank-local dist^2 into the payload's tail -- which would otherwise be a launch of its own
 // (k_finalize_optimistic) on the critical path of every iteration.
 constexpr int CUT_THREADS = 256;   // = ELT_THREADS (the bookkeeping block's reduction is written for it)
-template <typename T>
+template <typename T, bool GATHER = false>
 __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a, T *out, int nParents, FinArgs fin) {
     if ((int)blockIdx.x >= nParents) {
-        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx));
+        const unsigned int tailIdx = (unsigned int)nParents * (unsigned int)(a.nv + 2 * a.nx);
+        finalize_optimistic_body<T>(fin, a.peer.nranks > 0 ? &a.peer : nullptr, a.peerSeq, tailIdx);
+        if (GATHER && a.peer.nranks > 0 && a.peerTail && threadIdx.x < 64)      // one-shot exchange gathered here (see k_up_chain_cut)
+            peer_gather_small<T>(a.peer, a.peerSeq, out, (int)tailIdx, (int)tailIdx + 2, threadIdx.x, 64, reinterpret_cast<IterState *>(a.iterState));
         return;
     }
     const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
@@ -1239,6 +1242,8 @@ __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a
         out[(size_t)blockIdx.x * w + t] = s;
         if (a.peer.nranks > 0) peer_push(a.peer, a.peerSeq, (unsigned int)blockIdx.x * (unsigned int)w + (unsigned int)t, s);
     }
+    if (GATHER && a.peer.nranks > 0)
+        peer_gather_small<T>(a.peer, a.peerSeq, out, (int)blockIdx.x * w, ((int)blockIdx.x + 1) * w, threadIdx.x, blockDim.x, reinterpret_cast<IterState *>(a.iterState));
 }
 
 // ------------------------------------------------------------------------------------------------------

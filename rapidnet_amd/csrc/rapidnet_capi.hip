@@ -1141,6 +1141,9 @@ struct Ctx : CtxBase {
             }
             prof_end(e0);
         }
+        // one-shot exchange: gathered by the launch that produces the cut parents' sums, every parent's workgroup its own (RAPIDNET_ONESHOT_GATHER=0:
+        // by the crown kernels, the first form)
+        static const int gatherHere = [] { const char *e = std::getenv("RAPIDNET_ONESHOT_GATHER"); return e ? std::atoi(e) : 1; }();
         auto helpers = [&](SweepArgs<T> &a) -> int {
         e1 = prof_begin(1);
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
@@ -1152,8 +1155,6 @@ struct Ctx : CtxBase {
             FinArgs fin{};
             if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             const size_t ldsCut = (size_t)(UPCUT_THREADS / lanesPer) * (nv + 2 * nx) * sizeof(T);
-            // one-shot exchange: gathered right here, by every cut parent's own workgroup (RAPIDNET_ONESHOT_GATHER=0: by the crown kernels, the first form)
-            static const int gatherHere = [] { const char *e = std::getenv("RAPIDNET_ONESHOT_GATHER"); return e ? std::atoi(e) : 1; }();
             const int grid = nk(k) + (pendingFin ? 1 : 0);
             if (oneShot && gatherHere) {
                 if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
@@ -1178,7 +1179,10 @@ struct Ctx : CtxBase {
             if (!mergedCut) {   // (k_up_chain_cut has already left the payload in d_cut)
                 FinArgs fin{};
                 if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
-                hipLaunchKernelGGL(k_cut_partial_sums<T>, dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
+                if (oneShot && gatherHere) {
+                    hipLaunchKernelGGL((k_cut_partial_sums<T, true>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
+                    a.peer.nranks = 0;      // d_cut holds the all-rank sums
+                } else hipLaunchKernelGGL((k_cut_partial_sums<T, false>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
                 pendingFin = false;
             }
             if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
