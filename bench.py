@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--structured", action="store_true", help="RN_OPS_STRUCTURED: no per-node operator blocks (see DESIGN.md)")
     ap.add_argument("--profile-steps", type=int, default=40, help="steps of the per-launch hipEvent pass (0 = skip)")
     ap.add_argument("--repeats", type=int, default=7, help="further timed regions of --steps steps after the contract's one (median / min / max in the JSON line)")
-    ap.add_argument("--other-configs", default="barcelona31,wide4096", help="comma list of further BASELINE.json configs timed in the same run on 1 GPU "
-                    "(their own roofline objects, in the `configs` array of the JSON line); '' = none")
+    ap.add_argument("--other-configs", default="barcelona31,wide4096,barcelona493:f32", help="comma list of further BASELINE.json configs timed in the same run on 1 GPU "
+                    "(their own roofline objects, in the `configs` array of the JSON line); 'name:f32' / 'name:f64' picks the precision "
+                    "(barcelona493:f32 = the headline tree in the reference's only precision, Configuration.h:31); '' = none")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure the HBM traffic of the dominant kernels in this run (two short rocprofv3 --pmc child runs, "
                     "started before this process touches the GPU); roofline.traffic then falls back to profiles/traffic.json if its kernel fingerprint matches")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)   # the child run the counters are collected on
@@ -55,6 +56,10 @@ def parse():
     ap.add_argument("--alt-exchange-only", action="store_true", help=argparse.SUPPRESS)   # the second worker of a rank: times the one-shot exchange (see supervise)
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)              # N > 1: the process that does a rank's GPU work (started by the rank's supervisor)
     ap.add_argument("--no-alt-exchange", action="store_true", help="N > 1: skip the extra pass that times the one-shot exchange at the cut beside the RCCL one")
+    ap.add_argument("--time-budget", type=float, default=480.0, help="N > 1: wall-clock budget (seconds) of a rank's supervisor, covering the PMC pre-pass, the worker that produces the "
+                    "JSON line and the optional one-shot-exchange worker; rank 0's line is on stdout no later than this, whatever the optional parts do")
+    ap.add_argument("--no-shard-ceiling", action="store_true", help="1 GPU: skip the `shard_ceiling` object (rank 0's shard of a 2 / 4 / 8-rank partition through the whole sharded path on this one GPU)")
+    ap.add_argument("--no-quasi-newton", action="store_true", help="1 GPU: skip the `quasi_newton` object (global-FBE / NAMA loops, dense and structured)")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
     return ap.parse_args()
@@ -86,7 +91,7 @@ def _pmc_medians(directory, counter):
     return {k: (statistics.median(v.values()), len(v)) for k, v in out.items()}
 
 
-def measure_traffic(args, extra_probe_args=(), launcher_env=False):
+def measure_traffic(args, extra_probe_args=(), launcher_env=False, limit=150.0):
     """HBM bytes per launch of k_stream_gemv and of the fused dual update FROM THE PMC COUNTERS OF THIS RUN, collected as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: FETCH_SIZE and WRITE_SIZE in separate passes
     (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-probe ...`, the program itself behind `--`),
@@ -118,7 +123,7 @@ def measure_traffic(args, extra_probe_args=(), launcher_env=False):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + probe,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=150)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=limit)
             if r.returncode != 0:
                 src["why_not"] = "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, r.stderr[-300:])
                 return {}, src
@@ -218,22 +223,86 @@ def _fault(point, rank):
         os._exit(17)
 
 
+def _job_tag():
+    """One name per launch, the same in every rank's supervisor (all on one node): the rendezvous port + the launcher's run id."""
+    return "%s_%s" % (os.environ.get("MASTER_PORT", "0"), "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "none") if c.isalnum())[:24])
+
+
+def _line_file(world):
+    """Where rank 0's result line is kept from the moment it exists (besides stderr): $RAPIDNET_BENCH_LINE_FILE, else
+    gpurun_out/bench_line_n<N>.json under the repository (the driver pulls gpurun_out/), else /tmp."""
+    path = os.environ.get("RAPIDNET_BENCH_LINE_FILE")
+    if path:
+        return path
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        if os.access(d, os.W_OK):
+            return os.path.join(d, "bench_line_n%d.json" % world)
+    except OSError:
+        pass
+    return "/tmp/rapidnet_bench_line_n%d.json" % world
+
+
+def _fake_worker(args, rank):
+    """Test double of a rank's worker ($RAPIDNET_BENCH_FAKE_WORKER = 'headline=<s>,total=<s>,alt=<s>[,fail=<code>][,hang_rank=<r>]'):
+    no GPU, no torch -- it sleeps and prints what a worker prints, so that the SUPERVISOR's protocol (time budget, partial
+    lines, a slow or hanging optional job, a worker that dies after the headline) is checked on the CPU in seconds
+    (tests/test_bench_supervisor.py).  Never reached without that variable."""
+    spec = dict(kv.split("=") for kv in os.environ["RAPIDNET_BENCH_FAKE_WORKER"].split(",") if "=" in kv)
+    f = lambda k, d: float(spec.get(k, d))
+    if args.alt_exchange_only:
+        time.sleep(f("alt", 0.5))
+        if rank == 0:
+            print(json.dumps({"alt_exchange": {"value": 1.0, "fake": True}}), flush=True)
+        os._exit(0)
+    line = {"metric": "apg_iterations_per_sec", "value": 123.0, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "fake": True}
+    if "fail_at" in spec and int(f("fail_rank", 0)) == rank:      # dies before any headline exists
+        time.sleep(f("fail_at", 1.0))
+        os._exit(int(f("fail", 1)))
+    time.sleep(f("headline", 0.5))
+    if rank == 0:
+        print(json.dumps(dict(line, partial="headline measured; secondary configs and CPU baseline pending")), flush=True)
+    if int(f("hang_rank", -1)) == rank:
+        time.sleep(3600)
+    time.sleep(max(0.0, f("total", 1.0) - f("headline", 0.5)))
+    if int(f("fail", 0)) and int(f("fail_rank", 0)) == rank:
+        os._exit(int(f("fail", 0)))
+    if rank == 0:
+        print(json.dumps(dict(line, complete=True)), flush=True)
+    os._exit(0)
+
+
 def supervise(args):
     """N > 1: what the launcher starts for a rank is this SUPERVISOR, which never touches the GPU.  It runs the rank's work as child
     processes, one after the other, so that at no time more than one process per rank holds the device:
-      1. the worker (`--worker`): everything the JSON line reports, RCCL exchange; rank 0's worker prints the line;
+      0. rank 0 only: HBM traffic of its shard from the PMC counters (two rocprofv3 passes of a one-process run);
+      1. the worker (`--worker`): everything the JSON line reports, RCCL exchange; rank 0's worker prints the line -- a first,
+         PARTIAL one as soon as the headline is measured, the complete one at its end;
       2. unless --no-alt-exchange: a second worker (`--worker --alt-exchange-only`) that times the one-shot exchange at the cut.
-         It writes into peers' memory from kernels and no multi-GPU node was available to rehearse that, so nothing it does can
-         take the headline with it: an error, a crash or a time-out (420 s, the child is killed by its PID) ends up in the line
-         as `alt_exchange.error`.
-    A worker that fails in step 1 ends this process with its code at once (the launcher then ends the other ranks); a supervisor
-    that is ended (SIGTERM from the launcher) takes its worker with it."""
+    Everything runs against ONE wall-clock budget (--time-budget, 480 s; the driver's limit is 600 s): steps 0 and 2 are optional and
+    get what the budget leaves (step 0: at most 150 s per pass and only while 330 s remain for the rest; step 2: at most 120 s,
+    skipped below 30 s -- rank 0 decides and tells the other supervisors through a file, so that either all ranks start it or
+    none), step 1 gets the rest.  Rank 0's line is written to a file (gpurun_out/bench_line_n<N>.json) and echoed to stderr the
+    moment it exists, and printed on stdout when step 2 has ended or the budget is used up, whichever comes first -- also when this
+    supervisor is told to go (SIGTERM) and when the worker dies after the headline was measured (the line then says `partial`).
+    A worker that fails BEFORE any headline exists ends this process with its code at once (the launcher then ends the other
+    ranks); a supervisor that is ended takes its worker with it."""
     import ctypes
     import signal
     import subprocess
+    import threading
 
+    t_start = time.time()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    budget = max(30.0, float(args.time_budget))
+    remaining = lambda: budget - (time.time() - t_start)
     child = [None]
+    best = [None]          # rank 0: the most complete result line seen so far (text)
+    printed = [False]
+    line_path = _line_file(world)
+    flag_path = "/tmp/rapidnet_bench_%s" % _job_tag()       # + ".headline": rank 0 has a line; + ".alt": rank 0's decision on step 2
+    lock = threading.Lock()
 
     def _die_with_parent():                      # the worker gets SIGKILL if this process disappears without a word
         try:
@@ -241,20 +310,52 @@ def supervise(args):
         except Exception:   # noqa: BLE001
             pass
 
+    def keep(text):
+        """rank 0: a (more complete) result line exists -- file + stderr at once"""
+        with lock:
+            first = best[0] is None
+            best[0] = text
+        try:
+            with open(line_path + ".tmp", "w") as f:
+                f.write(text + "\n")
+            os.replace(line_path + ".tmp", line_path)
+            if first:
+                open(flag_path + ".headline", "w").close()
+        except OSError:
+            pass
+        print("bench.py: result line so far (also in %s): %s" % (line_path, text), file=sys.stderr, flush=True)
+
+    def emit(note=None):
+        """rank 0: print the best line on stdout, ONCE"""
+        with lock:
+            if printed[0] or best[0] is None:
+                return best[0] is not None
+            printed[0] = True
+            text = best[0]
+        if note:
+            try:
+                d = json.loads(text)
+                d["partial"] = (d.get("partial", "") + "; " if d.get("partial") else "") + note
+                text = json.dumps(d)
+            except ValueError:
+                pass
+        print(text, flush=True)
+        return True
+
     def _on_term(signum, _frame):
         if child[0] is not None and child[0].poll() is None:
             child[0].kill()
+        if rank == 0 and emit("the supervisor was ended by signal %d before the run was complete" % signum):
+            os._exit(0)
         os._exit(128 + signum)
 
     signal.signal(signal.SIGTERM, _on_term)
     signal.signal(signal.SIGINT, _on_term)
     base = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"]
 
-    def run_worker(cmd, env, key, limit):
+    def run_worker(cmd, env, key, limit, on_line=None):
         """(exit code or None after a time-out, the last stdout line that is a JSON object holding `key`)"""
         child[0] = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, preexec_fn=_die_with_parent)
-        import threading
-
         found = [None]
 
         def pump():
@@ -262,13 +363,15 @@ def supervise(args):
                 t = ln.strip()
                 if t.startswith("{") and key in t:
                     found[0] = t
+                    if on_line:
+                        on_line(t)
                 elif t:
                     print(t, file=sys.stderr, flush=True)
 
         th = threading.Thread(target=pump, daemon=True)
         th.start()
         try:
-            rc = child[0].wait(timeout=limit)
+            rc = child[0].wait(timeout=max(1.0, limit))
         except subprocess.TimeoutExpired:
             child[0].kill()
             child[0].wait()
@@ -276,32 +379,73 @@ def supervise(args):
         th.join(10.0)
         return rc, found[0]
 
+    for suffix in (".headline", ".alt"):          # a stale file of an earlier job on the same port
+        try:
+            if rank == 0:
+                os.remove(flag_path + suffix)
+        except OSError:
+            pass
     wenv = dict(os.environ)
-    if rank == 0 and not (args.no_traffic or args.structured or args.alt_exchange_only or args.traffic_probe):
+    if rank == 0 and not (args.no_traffic or args.structured or args.alt_exchange_only or args.traffic_probe or os.environ.get("RAPIDNET_BENCH_FAKE_WORKER")):
         # HBM traffic of rank 0's shard from the PMC counters: two one-process runs of the sharded path on this rank's device
         # (`--emulate-world N`: rank 0's shard, one-rank communicator) under rocprofv3, before the rank's worker starts -- the other
         # ranks' workers wait for it in the rendezvous.  Handed to the worker, which puts it into `roofline.traffic`.
-        t, src = measure_traffic(args, ("--emulate-world", str(world)), launcher_env=True)
-        if isinstance(src, dict) and src.get("how"):
-            src["how"] = "rank 0's shard, measured by one-process runs of the sharded path (--emulate-world %d) on rank 0's device before the job: " % world + src["how"]
+        per_pass = min(150.0, (remaining() - 330.0) / 2.0)
+        if per_pass >= 40.0:
+            t, src = measure_traffic(args, ("--emulate-world", str(world)), launcher_env=True, limit=per_pass)
+            if isinstance(src, dict) and src.get("how"):
+                src["how"] = "rank 0's shard, measured by one-process runs of the sharded path (--emulate-world %d) on rank 0's device before the job: " % world + src["how"]
+        else:
+            t, src = {}, {"measured_in_this_run": False, "how": None, "why_not": "skipped: budget (%.0f s left of %.0f)" % (remaining(), budget)}
         wenv["RAPIDNET_BENCH_TRAFFIC_JSON"] = json.dumps({"traffic": t, "source": src})
-    rc, line = run_worker(base, wenv, '"metric"', None)
+    # ---- step 1: the worker.  It may use what is left of the budget (a margin for printing aside).
+    rc, line = run_worker(base, wenv, '"metric"', remaining() - 5.0, on_line=keep if rank == 0 else None)
     if rc != 0:
-        print("bench.py rank %d: the worker ended with code %s" % (rank, rc), file=sys.stderr, flush=True)
-        os._exit(rc if rc and rc > 0 else 1)
+        why = "did not finish within the time budget of %.0f s (killed)" % budget if rc is None else "ended with code %s" % rc
+        print("bench.py rank %d: the worker %s" % (rank, why), file=sys.stderr, flush=True)
+        if rank == 0:
+            if emit("rank 0's worker %s after the headline was measured: what it had not finished is missing" % why):
+                os._exit(0)
+            os._exit(rc if rc and rc > 0 else 1)
+        # another rank: if rank 0 already holds a headline the job has a result -- leave quietly (a non-zero code would make the
+        # launcher end rank 0's supervisor before it prints); otherwise fail the job at once
+        os._exit(0 if (rc is None or os.path.exists(flag_path + ".headline")) else (rc if rc > 0 else 1))
+    # ---- step 2: the optional one-shot-exchange worker, within what the budget leaves; ONE decision for all ranks (rank 0's)
     alt = None
     if not (args.structured or args.no_alt_exchange or args.alt_exchange_only or args.traffic_probe):
-        env = {k: v for k, v in os.environ.items() if k != "RAPIDNET_BENCH_FAULT"}
-        env["RAPIDNET_BENCH_STORE_PREFIX"] = "alt_exchange"      # the launcher's store is shared with step 1: keys of its own
-        rc2, aline = run_worker(base + ["--alt-exchange-only"], env, '"alt_exchange"', 420.0)
-        if aline is not None:
+        if rank == 0:
+            left = remaining()
+            limit = min(120.0, left - 15.0)
+            decision = "run %.1f" % limit if limit >= 30.0 else "skip"
             try:
-                alt = json.loads(aline)["alt_exchange"]
-            except ValueError:
-                alt = None
-        if alt is None:
-            alt = {"error": "the one-shot exchange job did not finish within 420 s (killed)" if rc2 is None
-                   else "the one-shot exchange job ended with code %d and no result (see stderr)" % rc2}
+                with open(flag_path + ".alt.tmp", "w") as f:
+                    f.write(decision)
+                os.replace(flag_path + ".alt.tmp", flag_path + ".alt")
+            except OSError:
+                decision = "skip"
+        else:
+            decision, t_wait = None, time.time()
+            while decision is None and time.time() - t_wait < 20.0:
+                try:
+                    decision = open(flag_path + ".alt").read().strip() or None
+                except OSError:
+                    time.sleep(0.1)
+            decision = decision or "skip"
+        if decision.startswith("run"):
+            limit = float(decision.split()[1])
+            env = {k: v for k, v in os.environ.items() if k != "RAPIDNET_BENCH_FAULT"}
+            env["RAPIDNET_BENCH_STORE_PREFIX"] = "alt_exchange"      # the launcher's store is shared with step 1: keys of its own
+            rc2, aline = run_worker(base + ["--alt-exchange-only"], env, '"alt_exchange"', min(limit, max(1.0, remaining() - 5.0)))
+            if aline is not None:
+                try:
+                    alt = json.loads(aline)["alt_exchange"]
+                except ValueError:
+                    alt = None
+            if alt is None:
+                alt = {"error": "the one-shot exchange job did not finish within its %.0f s (killed)" % limit if rc2 is None
+                       else "the one-shot exchange job ended with code %d and no result (see stderr)" % rc2}
+        else:
+            alt = {"error": "skipped: budget (%.0f s of %.0f left after the headline run)" % (remaining(), budget)}
     if rank == 0:
         if line is None:
             print("bench.py: rank 0's worker ended without a result line", file=sys.stderr, flush=True)
@@ -309,8 +453,14 @@ def supervise(args):
         if alt is not None:
             out = json.loads(line)
             out["alt_exchange"] = alt
-            line = json.dumps(out)
-        print(line, flush=True)
+            with lock:
+                best[0] = json.dumps(out)
+        emit()
+        for suffix in (".headline", ".alt"):
+            try:
+                os.remove(flag_path + suffix)
+            except OSError:
+                pass
     os._exit(0)
 
 
@@ -394,6 +544,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))     # one child process per rank, started before anything touches the GPU
+    if args.worker and os.environ.get("RAPIDNET_BENCH_FAKE_WORKER"):
+        _fake_worker(args, rank)        # test double (tests/test_bench_supervisor.py); never returns
     if args.traffic_probe:              # the run the PMC counters are collected on: iterations only
         args.no_cpu_baseline, args.dense_only, args.profile_steps, args.repeats, args.other_configs, args.no_traffic = True, True, 0, 0, "", True
     measured_traffic, measured_source = ({}, None)
@@ -414,6 +566,10 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    def emit_partial(obj, what):
+        """rank 0's worker under a supervisor: a result line that is not complete yet, on the real stdout (the supervisor's pipe)"""
+        os.write(saved_stdout, (json.dumps(dict(obj, partial=what)) + "\n").encode())
     if sharded:
         import torch
         import torch.distributed as dist
@@ -773,25 +929,39 @@ def main():
                 if not all_ok:
                     alt_res = {"error": "set-up failed: %s" % why}
                 else:
-                    ok, err, dt_alt = True, "", None
-                    try:
+                    # Every rank runs the SAME sequence of gloo collectives whatever happens to it: a reader's time-out (RN_E_COMM) raises
+                    # on the rank(s) it happened on -- since round 5 on every rank of the batch, the flag rides in the per-batch MAX
+                    # all-reduce -- and a rank that skipped a barrier its peers are in would hang the job until the supervisor's limit.
+                    def guarded(fn):
+                        try:
+                            fn()
+                            return True, ""
+                        except capi.RapidNetError as e:
+                            return False, str(e)
+
+                    def warm():
                         s.setExchangeTransport(1)
                         s.apgReset()
-                        beat("one-shot exchange: timed region (%s)" % workload)
                         for _ in range(4):
                             iterate(20)
                         iterate(warmup)
-                        barrier()
+                        s.synchronize()
+
+                    beat("one-shot exchange: warm-up (%s)" % workload)
+                    ok, err = guarded(warm)
+                    all_ok, why = agree(ok, err, "one-shot warm-up")
+                    dt_alt = None
+                    if all_ok:
+                        beat("one-shot exchange: timed region (%s)" % workload)
+                        dist.barrier()
                         t0 = time.perf_counter()
-                        iterate(steps)
-                        barrier()
+                        ok, err = guarded(lambda: (iterate(steps), s.synchronize()))
+                        dist.barrier()                      # reached by every rank, failed or not
                         dt_alt = time.perf_counter() - t0
-                    except capi.RapidNetError as e:      # a reader's time-out: every rank's readers are bounded, so every rank gets here
-                        ok, err = False, str(e)
-                    all_ok, why = agree(ok, err, "one-shot timed region")
+                        all_ok, why = agree(ok, err, "one-shot timed region")
                     if all_ok:
                         dt_alt = max_over_ranks(dt_alt)
-                        alt_res = {"kind": "one-shot exchange at the cut: peer-written {payload, tag} packets gathered by the crown kernels (rn_set_exchange_transport 1); per-batch collectives over RCCL",
+                        alt_res = {"kind": "one-shot exchange at the cut: peer-written {payload, tag} packets gathered by the cut parents' own workgroups (rn_set_exchange_transport 1); per-batch collectives over RCCL",
                                    "value": steps / dt_alt, "unit": "iterations/s", "ms_per_step": 1e3 * dt_alt / steps,
                                    "same_context_rccl": {"value": steps / dt, "ms_per_step": 1e3 * dt / steps},
                                    "speedup_vs_rccl_same_context": dt / dt_alt}
@@ -882,8 +1052,9 @@ def main():
             out["structured_mode"] = {"error": struct_error}
         if head.get("per_rank"):
             out["per_rank"] = head["per_rank"]
-        if others and sharded:   # should a secondary config take the job down, the headline is on record
-            print("bench.py: headline so far: %s" % json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "config")}), file=sys.stderr, flush=True)
+        if args.worker:   # under a supervisor (N > 1): the headline is on record from here on -- a first, partial line; the supervisor keeps
+            # the most complete one it has seen and prints ONE (supervise): nothing that follows can take the headline with it
+            emit_partial(out, "headline measured; secondary configs (wide4096), the one-shot exchange pass and the CPU baseline pending")
     entries = []
     for w in others:
         prec_w = "f32" if w.startswith("wide") else "f64"
@@ -903,8 +1074,9 @@ def main():
                 entry.update({"n_gpus": world, "local_nodes": int(r["nodes"]), "per_rank": r["per_rank"],
                               "parallelism": "subtree sharding below stage %d, 1 RCCL all-reduce/iteration" % cut_w if not fallback_reason[0]
                               else "subtree sharding below stage %d, FALLBACK exchange through torch.distributed (%s)" % (cut_w, fallback_reason[0])})
+            if not args.no_cpu_baseline:
+                beat("CPU baseline (%s)%s" % (w, "" if rank == 0 else ": waiting for rank 0"), 1300.0)   # every rank: the others wait in the next collective
             if rank == 0 and not args.no_cpu_baseline:
-                beat("CPU baseline (%s)" % w, 1200.0)
                 entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
             del pw
         except AgreedFailure as e:   # every rank raised it together: reported, the run goes on
@@ -943,14 +1115,17 @@ def main():
             sr.close()
         except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
             replay = {"error": "%s: %s" % (type(e).__name__, e)}
+    beat("closing: rank 0's CPU baseline, then the last barrier", 1300.0)      # every rank the same limit (rank 0 times the CPU legs meanwhile)
     if rank == 0:
         if replay is not None:
             out["replay_path"] = replay
         if entries:
             out["configs"] = entries
+        if args.worker:
+            emit_partial(out, "headline and secondary configs measured; CPU baseline pending")
         if not args.no_cpu_baseline and not args.traffic_probe and (not sharded or world > 1):
             # rank 0 only, after every timed region (the other ranks wait at the closing barrier)
-            beat("CPU baseline (%s)" % args.workload, 1200.0)
+            beat("CPU baseline (%s)" % args.workload, 1300.0)
             out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

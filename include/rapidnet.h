@@ -164,8 +164,6 @@ int rn_device_memory_info(rn_ctx *ctx, size_t info[4]);
  * the iteration tables and the checkpoint buffers for batches of up to maxIterations iterations, so that no later
  * rn_apg_iterate / rn_control_action allocates device memory.  (1 022 iterations are reserved by rn_create.) */
 int rn_reserve_iterations(rn_ctx *ctx, int maxIterations);
-/* test hook for a caller's leak check: the NEXT rn_control_action allocates `bytes` of device memory that stay with the context */
-int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes);
 
 /* Extension (the reference always cold-starts, SmpcController.cu:1509): when on,
  * rn_control_action keeps the duals of the previous control step and only restarts the momentum. */
@@ -262,7 +260,15 @@ void *rn_stream(rn_ctx *ctx);
 /* see DESIGN.md "multi-GPU"; ncclUniqueId bytes are produced by rn_comm_unique_id on rank 0 and
  * distributed by the caller (bench.py uses torch.distributed for that). */
 int rn_comm_unique_id(void *id128 /* 128 bytes out */);
+/* id128 == NULL records rank / nranks without creating a communicator (the exchange is then a test's job, rapidnet_debug.h).
+ * The communicator is created non-blocking and polled: a rank whose peers do not arrive within the time-out ($RAPIDNET_COMM_TIMEOUT_S,
+ * default 120 s; rn_comm_init_timeout: `timeoutSeconds`) gets RN_E_COMM back -- never a hang (the reference exits on any failure,
+ * Configuration.h:38-81) -- and the context stays usable without a communicator. */
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
+int rn_comm_init_timeout(rn_ctx *ctx, int rank, int nranks, const void *id128, double timeoutSeconds);
+/* asynchronous errors of the communicator (ncclCommGetAsyncError: a peer died, a link went down): RN_E_COMM if RCCL reports one.
+ * The library asks once per batch of rn_apg_iterate by itself. */
+int rn_comm_check(rn_ctx *ctx);
 /* Path of the RCCL image the library bound (an image the process has already loaded -- e.g. the one PyTorch links --
  * is reused, never a second copy), written as a C string into buf; RN_E_COMM when RCCL cannot be loaded. */
 int rn_comm_library(char *buf, size_t n);
@@ -296,12 +302,6 @@ int rn_get_history_parts(rn_ctx *ctx, int first, int n, double *out /* 4*n */);
  * through the exact path because a tree-global prox distance exceeded its threshold, exact batches still to run before the
  * optimistic path is tried again (back-off after a replay)}. */
 int rn_get_counters(rn_ctx *ctx, long out[4]);
-/* Test hooks for the sharded sweep: run rn_solve_step in two halves around the exchange -- phase 1 stops after the
- * cut parents' LOCAL children sums are in the exchange buffer, phase 2 resumes from a buffer the caller has summed
- * over the shards (rn_debug_cut_buffer reads / writes it: cutParents * (nv + 2 nx) reals).  rn_comm_init with
- * id128 == NULL records rank / nranks without creating an RCCL communicator. */
-int rn_debug_sweep_phase(rn_ctx *ctx, int phase);
-int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n);
 
 /* ---- multi-GPU through the boundary: partition + communicator + cut stage in one call --------------------------------
  * The reference is single-GPU: its seam for a whole solver is `Engine(SmpcConfiguration*)` / `SmpcController(string)`
@@ -338,8 +338,9 @@ void rn_partition_destroy(rn_partition *p);
 
 /* rn_create for rank `rank` of `nranks`: partition (above) + rn_create on the local tree + rn_set_tree_errors (local rows)
  * + rn_comm_init + rn_set_cut_stage + rn_set_cut_children_moments.  id128 = the ncclUniqueId of rn_comm_unique_id (rank 0's,
- * distributed by the caller); NULL creates no RCCL communicator (the exchange is then a test's job: rn_debug_* hooks or
- * rn_debug_local_group_join).  nranks == 1 gives a plain unsharded context. */
+ * distributed by the caller); NULL creates no RCCL communicator (rn_comm_init may follow -- a caller that wants to keep the context when
+ * the communicator cannot be created within its time-out does it that way; here a failed set-up destroys the context).
+ * nranks == 1 gives a plain unsharded context. */
 int rn_create_sharded(const rn_dims *dims, const rn_tree *tree, const double *errorDemandNode, const double *errorPriceNode,
                       int precision, int device, int rank, int nranks, int cutStage, const void *id128, rn_ctx **out);
 /* what a sharded context is: info = {rank, nranks, cut stage (-1: none), cut parents, ranks the RCCL communicator itself
@@ -347,20 +348,6 @@ int rn_create_sharded(const rn_dims *dims, const rn_tree *tree, const double *er
 int rn_shard_info(rn_ctx *ctx, int info[7]);
 /* index in the FULL tree of every local node (rn_get returns local node-major arrays); identity for unsharded contexts */
 int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
-
-/* Test facility: an in-process stand-in for the communicator, so that the device-resident sharded path (checkpoint, dist^2
- * tail, verdict vote, replay) can run with several ranks on a box where RCCL cannot (one GPU: "Duplicate GPU detected").
- * rn_debug_set_allreduce installs a callback that is called wherever the library would call ncclAllReduce(sum, in place):
- * devBuf / count / isF64 / op describe the payload and the reduction, stream is the context's hipStream_t; it must return 0 after the reduced
- * values are (or are stream-ordered to be) in devBuf.  rn_debug_local_group_* is such a callback inside the library for
- * `nranks` contexts of ONE process, each driven by its own host thread: stream sync, barrier, every rank sums the payloads
- * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s
- * ($RAPIDNET_GROUP_TIMEOUT_S when the group is created) fails the others with RN_E_COMM instead of hanging them. */
-typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, int op /* 0 = sum, 2 = max (ncclRedOp_t) */, void *stream);
-int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
-int rn_debug_local_group_create(int nranks, void **group);
-int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);
-int rn_debug_local_group_destroy(void *group);
 
 /* ---- one-shot exchange at the cut (opt-in transport for the per-iteration exchange) ------------------
  * The reference has no counterpart (single GPU).  What is exchanged is exactly what solveSumChildren computes at the cut
@@ -374,11 +361,10 @@ int rn_debug_local_group_destroy(void *group);
  *   rn_peer_inbox_connect  maps the peers' inboxes (hipIpcOpenMemHandle);
  *   rn_set_exchange_transport(ctx, 1)   one-shot inside rn_apg_iterate batches; 0 (default): the collective.
  * A reader that waits longer than 2 s ($RAPIDNET_ONESHOT_TIMEOUT_MS) for a peer's packets gives up: the batch returns
- * RN_E_COMM (never a hang).  rn_debug_peer_inbox_connect_local wires the inboxes of `nranks` contexts of ONE process (tests:
- * same address space, no IPC handle needed), contexts in rank order. */
+ * RN_E_COMM (never a hang), and every rank of the job returns it for that batch (the flag rides in the per-batch MAX all-reduce).
+ * rn_peer_inbox_connect is once per context.  (Tests wire the inboxes of contexts of one process: rapidnet_debug.h.) */
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64 /* 64 bytes out */);
 int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 bytes, rank order */, int nranks);
-int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks);
 int rn_set_exchange_transport(rn_ctx *ctx, int transport);
 
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
@@ -389,8 +375,6 @@ int rn_set_exchange_transport(rn_ctx *ctx, int transport);
 int rn_guard_check(rn_ctx *ctx, long *badBytes);
 /* process-wide tally of the checks rn_destroy makes in guard mode: out = {contexts checked so far, red-zone bytes found overwritten} */
 int rn_guard_report(long out[2]);
-/* test of the detector itself: overwrites `nbytes` (1 .. 256) right behind the payload of the context's first buffer */
-int rn_debug_guard_poke(rn_ctx *ctx, int nbytes);
 
 #ifdef __cplusplus
 }

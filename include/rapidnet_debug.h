@@ -1,0 +1,48 @@
+/* rapidnet_debug.h -- TEST HOOKS of librapidnet_hip.so.  Not part of the drop-in boundary (include/rapidnet.h): nothing here replaces a
+ * member of the reference; the parity tests use these entry points the way the reference's own tests reach into protected members
+ * (TestSmpcController.cu:134-159).  A production caller has no use for them. */
+#ifndef RAPIDNET_DEBUG_H_
+#define RAPIDNET_DEBUG_H_
+
+#include "rapidnet.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* test hook for a caller's leak check (SmpcController.cu:1612-1623): the NEXT rn_control_action allocates `bytes` of device memory
+ * that stay with the context */
+int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes);
+
+/* Test hooks for the sharded sweep: run rn_solve_step in two halves around the exchange -- phase 1 stops after the
+ * cut parents' LOCAL children sums (solveSumChildren, Utilities.cu:168-201) are in the exchange buffer, phase 2 resumes from a
+ * buffer the caller has summed over the shards (rn_debug_cut_buffer reads / writes it: cutParents * (nv + 2 nx) reals). */
+int rn_debug_sweep_phase(rn_ctx *ctx, int phase);
+int rn_debug_cut_buffer(rn_ctx *ctx, int write, double *host, size_t n);
+
+/* An in-process stand-in for the communicator, so that the device-resident sharded path (checkpoint, dist^2 tail, verdict vote,
+ * replay) can run with several ranks on a box where RCCL cannot (one GPU: "Duplicate GPU detected").
+ * rn_debug_set_allreduce installs a callback that is called wherever the library would call ncclAllReduce(in place):
+ * devBuf / count / isF64 / op describe the payload and the reduction, stream is the context's hipStream_t; it must return 0 after the
+ * reduced values are (or are stream-ordered to be) in devBuf.  rn_debug_local_group_* is such a callback inside the library for
+ * `nranks` contexts of ONE process, each driven by its own host thread: stream sync, barrier, every rank sums the payloads
+ * in rank order (bitwise the same on all ranks), barrier.  A rank that does not arrive within 120 s
+ * ($RAPIDNET_GROUP_TIMEOUT_S when the group is created) fails the others with RN_E_COMM instead of hanging them. */
+typedef int (*rn_allreduce_fn)(void *user, void *devBuf, size_t count, int isF64, int op /* 0 = sum, 2 = max (ncclRedOp_t) */, void *stream);
+int rn_debug_set_allreduce(rn_ctx *ctx, rn_allreduce_fn fn, void *user);
+int rn_debug_local_group_create(int nranks, void **group);
+int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank);
+int rn_debug_local_group_destroy(void *group);
+
+/* one-shot exchange: wires the inboxes (rn_peer_inbox_create) of `nranks` contexts of ONE process -- same address space, no IPC
+ * handle needed -- contexts in rank order */
+int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks);
+
+/* test of the guard-mode detector itself (rn_guard_check): overwrites `nbytes` (1 .. 256) right behind the payload of the context's
+ * first buffer */
+int rn_debug_guard_poke(rn_ctx *ctx, int nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPIDNET_DEBUG_H_ */

@@ -53,7 +53,7 @@ def kernel_sources_sha256():
 
 def _hip_deps():
     """Everything librapidnet_hip.so is compiled from (first entry = the translation unit)."""
-    return kernel_sources() + [os.path.join(CSRC, "partition.hpp"), os.path.join(ROOT, "include", "rapidnet.h")]
+    return kernel_sources() + [os.path.join(CSRC, "partition.hpp"), os.path.join(ROOT, "include", "rapidnet.h"), os.path.join(ROOT, "include", "rapidnet_debug.h")]
 
 
 def build_hip(force=False, verbose=False, defines=(), out=None):
@@ -99,7 +99,7 @@ def build_host(force=False):
     srcs = [os.path.join(hdir, f) for f in ("DataModel.cpp", "Engine.cpp", "SmpcController.cpp", "NullSpace.cpp")]
     deps = srcs + [os.path.join(hdir, f) for f in ("DataModel.hpp", "Engine.hpp", "SmpcController.hpp", "JsonLite.hpp", "Configuration.h", "NullSpace.hpp")]
     build_hip()
-    hdr = [os.path.join(ROOT, "include", "rapidnet.h")]
+    hdr = [os.path.join(ROOT, "include", "rapidnet.h"), os.path.join(ROOT, "include", "rapidnet_debug.h")]
     if force or _stale(LIB_HOST, deps + hdr):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-fPIC", "-shared", "-o", LIB_HOST] + srcs +
                               ["-L" + HERE, "-lrapidnet_hip", "-Wl,-rpath,$ORIGIN"])

@@ -20,7 +20,7 @@ ALG_APG, ALG_GLOBAL_FBE, ALG_NAMA = 0, 1, 2
 ALGORITHMS = {"proximalAlgorithm": ALG_APG, "globalFbeAlgorithm": ALG_GLOBAL_FBE, "namaAlgorithm": ALG_NAMA}  # Engine.cu:151-163
 OP_PHI, OP_PSI, OP_D, OP_F, OP_OMEGA, OP_THETA, OP_G = range(7)
 
-# every symbol include/rapidnet.h declares
+# every symbol include/rapidnet.h (the boundary) and include/rapidnet_debug.h (test hooks, rn_debug_*) declare
 SYMBOLS = [
     "rn_create", "rn_destroy", "rn_last_error", "rn_synchronize", "rn_factor_step", "rn_set_tree_errors",
     "rn_set_uncertainty", "rn_update_state_control", "rn_eliminate_input_disturbance_coupling", "rn_set_parameters",
@@ -28,7 +28,7 @@ SYMBOLS = [
     "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
-    "rn_comm_unique_id", "rn_comm_init", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
+    "rn_comm_unique_id", "rn_comm_init", "rn_comm_init_timeout", "rn_comm_check", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
@@ -157,6 +157,8 @@ def load():
     lib.rn_stream.restype = vp
     lib.rn_comm_unique_id.argtypes = [dp]
     lib.rn_comm_init.argtypes = [vp, ip, ip, dp]
+    lib.rn_comm_init_timeout.argtypes = [vp, ip, ip, dp, C.c_double]
+    lib.rn_comm_check.argtypes = [vp]
     lib.rn_comm_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.rn_set_cut_stage.argtypes = [vp, ip]
     lib.rn_get_history_parts.argtypes = [vp, ip, ip, dp]
@@ -555,13 +557,21 @@ class Solver:
         return a.value, b.value
 
     # ---- multi-GPU ------------------------------------------------------------------------------------------
-    def commInit(self, rank, nranks, unique_id_bytes):
-        """unique_id_bytes None: record rank / nranks only (tests emulate the exchange with debugCutBuffer)."""
+    def commInit(self, rank, nranks, unique_id_bytes, timeout=None):
+        """unique_id_bytes None: record rank / nranks only (tests emulate the exchange with debugCutBuffer).
+        timeout (seconds; None: $RAPIDNET_COMM_TIMEOUT_S or 120): a rank whose peers do not arrive gets RapidNetError (RN_E_COMM)
+        back instead of waiting for ever; the context stays usable without a communicator."""
         if unique_id_bytes is None:
             self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), None))
             return
         buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
-        self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
+        if timeout is None:
+            self._check(self.lib.rn_comm_init(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
+        else:
+            self._check(self.lib.rn_comm_init_timeout(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p), float(timeout)))
+
+    def commCheck(self):
+        self._check(self.lib.rn_comm_check(self.h))
 
     def debugSweepPhase(self, phase):
         self._check(self.lib.rn_debug_sweep_phase(self.h, int(phase)))

@@ -565,7 +565,11 @@ __global__ void __launch_bounds__(ELT_THREADS) k_ls_eval(DualArgs<T> a, const T 
                     const double diff = (double)(t - z);
                     acc[c][0] = fma_rn((double)w, (double)r, acc[c][0]);
                     acc[c][1] = fma_rn((double)r, (double)r, acc[c][1]);
-                    if (col < nx) acc[c][2] = fma_rn(diff, diff, acc[c][2]); else if (col < 2 * nx) acc[c][3] = fma_rn(diff, diff, acc[c][3]);
+                    // (selects, not branches: `if (box) acc[c][2] ... else acc[c][3] ...` was compiled into ONE update of acc[c][2 + half], a
+                    //  dynamically indexed array -- all 24 accumulators in scratch, 112 bytes per lane)
+                    const double d2b = fma_rn(diff, diff, acc[c][2]), d2s = fma_rn(diff, diff, acc[c][3]);
+                    acc[c][2] = col < nx ? d2b : acc[c][2];
+                    acc[c][3] = (col >= nx && col < 2 * nx) ? d2s : acc[c][3];
                 }
             }
         }

@@ -532,7 +532,10 @@ template <typename T, int NL, bool SPLIT, int NR = 1>
 __global__ void __launch_bounds__(STREAM_THREADS, RN_STREAM_MINW) k_stream_gemv(SweepArgs<T> a, int G, int node0, StreamSplit<T> sp, StreamRhs2<T> r2) {
     static_assert(NR == 1 || !SPLIT, "two right-hand sides: unsplit launches only");
     typedef typename Slot<T>::type VT;
-    constexpr int VPL = Slot<T>::N, D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE;
+    // (two right-hand sides in fp32: 4 values per slot x 2 accumulator sets -- a group one span shorter (NL = 4: one span per group)
+    //  keeps the kernel inside its registers: 150-172 instead of 256 + 20-28 bytes of scratch per lane with the full depth.  The
+    //  order in which a thread meets its columns does not depend on the depth: same sums, bit for bit)
+    constexpr int VPL = Slot<T>::N, D0 = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE, D = (NR == 2 && sizeof(T) == 4) ? (NL == 4 ? 1 : D0 - 1) : D0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh_y = reinterpret_cast<T *>(smem_raw);          // ny (+ G of zero padding is not needed: guarded reads)
     T *sh_red = sh_y + ((a.ny + 3) & ~3);               // G * LD
@@ -2560,7 +2563,8 @@ __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Parti
 // also carries the ranks' verdicts.  pack: out[0] = this rank's verdict (tail != nullptr: the all-reduced dist^2 of the batch's
 // last iteration is checked first against the thresholds), out[1 + 4 i ...] = (v_xi, -v_xi, v_psi, -v_psi) of iteration first + i,
 // v = the signed entry at the rank's arg-max |.|: the maxima over the ranks give the largest magnitude of either sign, hence the
-// entry at the tree-global arg-max (equal magnitudes of opposite sign on two ranks: the positive one).
+// entry at the tree-global arg-max (equal magnitudes of opposite sign on two ranks: the positive one).  out[1 + 4 n] = this rank's
+// commFail flag (one-shot exchange): after the MAX every rank knows that some reader gave up, and all of them fail the batch.
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_batch_close_pack(const T *tail, IterState *st, double thrX, double thrS, const double *histParts,
                                                                   int first, int n, double *out) {
@@ -2571,13 +2575,15 @@ __global__ void __launch_bounds__(ELT_THREADS) k_batch_close_pack(const T *tail,
             if (dX > thrX || dS > thrS) st->violated = 1;
             out[0] = st->violated ? 1.0 : 0.0;
         } else out[0] = 0.0;
+        out[1 + 4 * (size_t)n] = st->commFail ? 1.0 : 0.0;
     }
     for (int i = threadIdx.x; i < n; i += ELT_THREADS) {
         const double vx = histParts[4 * (size_t)(first + i) + 1], vp = histParts[4 * (size_t)(first + i) + 3];
         out[1 + 4 * i] = vx; out[2 + 4 * i] = -vx; out[3 + 4 * i] = vp; out[4 + 4 * i] = -vp;
     }
 }
-__global__ void __launch_bounds__(ELT_THREADS) k_batch_close_unpack(const double *in, double *hist, int first, int n) {
+__global__ void __launch_bounds__(ELT_THREADS) k_batch_close_unpack(const double *in, double *hist, int first, int n, IterState *st) {
+    if (threadIdx.x == 0 && in[1 + 4 * (size_t)n] > 0.0) st->commFail = 1;      // a reader gave up on SOME rank: the batch is invalid on every rank
     for (int i = threadIdx.x; i < n; i += ELT_THREADS) {
         const double gx = in[1 + 4 * i] >= in[2 + 4 * i] ? in[1 + 4 * i] : -in[2 + 4 * i];
         const double gp = in[3 + 4 * i] >= in[4 + 4 * i] ? in[3 + 4 * i] : -in[4 + 4 * i];

@@ -16,10 +16,18 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/rapidnet.h"
+#include "../../include/rapidnet_debug.h"
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>      // types only (ncclConfig_t and its initializer): every RCCL function is bound at run time, nothing is linked
+#define RN_HAVE_RCCL_CONFIG 1
+#else
+#define RN_HAVE_RCCL_CONFIG 0
+#endif
 #include "fbe_kernels.hpp"
 #include "partition.hpp"
 
@@ -76,6 +84,7 @@ namespace rn {
     } while (0)
 
 // ---- minimal RCCL binding, resolved at run time (so single-GPU users never load it) ---------------------
+struct UniqueId128 { char b[128]; };
 struct NcclApi {
     void *h = nullptr;
     int (*GetUniqueId)(void *) = nullptr;
@@ -83,6 +92,10 @@ struct NcclApi {
     int (*CommDestroy)(void *) = nullptr;
     int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*InitRank)(void **, int, struct UniqueId128, int) = nullptr;
+    int (*InitRankConfig)(void **, int, struct UniqueId128, int, void *) = nullptr;   // NCCL >= 2.14
+    int (*GetAsyncError)(void *, int *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     std::string path;   // file the bound image was loaded from (rn_comm_library)
     bool load() {
         if (h) return true;
@@ -97,13 +110,17 @@ struct NcclApi {
         CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
         CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
         GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+        InitRank = (int (*)(void **, int, UniqueId128, int))dlsym(h, "ncclCommInitRank");
+        InitRankConfig = (int (*)(void **, int, UniqueId128, int, void *))dlsym(h, "ncclCommInitRankConfig");
+        GetAsyncError = (int (*)(void *, int *))dlsym(h, "ncclCommGetAsyncError");
+        CommAbort = (int (*)(void *))dlsym(h, "ncclCommAbort");
         Dl_info info;
         if (AllReduce && dladdr((void *)AllReduce, &info) && info.dli_fname) path = info.dli_fname;
-        return GetUniqueId && AllReduce && dlsym(h, "ncclCommInitRank");
+        return GetUniqueId && AllReduce && InitRank;
     }
 };
 static NcclApi g_nccl;
-struct UniqueId128 { char b[128]; };
+constexpr int NCCL_IN_PROGRESS = 7;   // ncclInProgress
 static std::atomic<long> g_guardContexts{0}, g_guardBadBytes{0};   // guard mode: contexts checked when they were destroyed / red-zone bytes found overwritten
 static std::atomic<long> g_liveContexts{0};   // contexts of this process (rn_device_memory_info: a device-wide figure is only the caller's own while this is 1)
 
@@ -139,7 +156,8 @@ struct CtxBase {
     virtual int algorithmic_bytes(double *, double *) const = 0;
     virtual int synchronize() = 0;
     virtual void *stream_handle() = 0;
-    virtual int comm_init(int, int, const void *) = 0;
+    virtual int comm_init(int, int, const void *, double timeoutSeconds = -1.0) = 0;
+    virtual int comm_check() = 0;
     virtual int set_cut_stage(int) = 0;
     virtual int hist_parts(int, int, double *) = 0;
     virtual int counters(long *) = 0;
@@ -372,7 +390,12 @@ struct Ctx : CtxBase {
         }
         RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
         hipEvent_t ev = prof_begin(4);
-        const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
+        int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
+        if (rc == NCCL_IN_PROGRESS && commNonblocking) {   // (the first collective of a non-blocking communicator connects its channels on a helper thread)
+            bool timedOut = false;
+            rc = comm_wait(comm, rc, commTimeoutS, &timedOut);
+            if (timedOut) { prof_end(ev); err = std::string(what) + ": still in progress after the communicator's time-out"; return RN_E_COMM; }
+        }
         prof_end(ev);
         RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
@@ -1119,7 +1142,9 @@ struct Ctx : CtxBase {
         // to every peer, the crown launch gathers them -- no collective in between
         const bool oneShot = transport == 1 && peerReady && inBatch && phase == 0 && a.cutSums != nullptr && hessianInput == nullptr;
         if (oneShot) {
-            if (++peerSeq == 0) ++peerSeq;      // 0 is the "never written" tag
+            // 0 is the "never written" tag; the wrap skips TWO values (... fffffffe, ffffffff, 2, 3 ...) so that the parity -- which of the
+            // two inbox buffers an exchange uses -- keeps alternating (the tag 2 of four billion exchanges ago is long overwritten)
+            if (++peerSeq == 0) peerSeq = 2;
             a.peer = h_peer; a.peerSeq = peerSeq; a.peerTail = (pendingFin && carryTail) ? 1 : 0;
         }
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = a.chainStage;
@@ -1346,7 +1371,7 @@ struct Ctx : CtxBase {
             if (int rc = dalloc(&nl, cap)) return rc;
             if (int rc = dalloc(&nh, cap)) return rc;
             if (int rc = dalloc(&np, (size_t)4 * cap)) return rc;
-            if (int rc = dalloc(&d_histGlob, (size_t)4 * cap + 1)) return rc;
+            if (int rc = dalloc(&d_histGlob, (size_t)4 * cap + 2)) return rc;
             RN_HIP(hipStreamSynchronize(stream));
             if (d_hist && histCap) {
                 RN_HIP(hipMemcpy(nh, d_hist, histCap * sizeof(double), hipMemcpyDeviceToDevice));
@@ -1575,6 +1600,9 @@ struct Ctx : CtxBase {
     int peer_inbox_connect(const void *handles, int n) override {
         RN_CHECK(handles && n == nranks, RN_E_ARG, "rn_peer_inbox_connect: one 64-byte handle per rank expected");
         RN_CHECK(d_inbox != nullptr, RN_E_STATE, "rn_peer_inbox_connect before rn_peer_inbox_create");
+        // once per context: the sequence numbers of the ranks advance together from the connect on, and a second connect of one rank
+        // would restart its tags over packets its peers still hold (a new set of peers needs a new context)
+        RN_CHECK(!peerReady, RN_E_STATE, "rn_peer_inbox_connect: the inboxes of this context are already connected");
         RN_HIP(hipSetDevice(device));
         for (int r = 0; r < nranks; r++) {
             if (r == rank) { h_peer.inbox[r] = d_inbox; continue; }
@@ -1592,6 +1620,7 @@ struct Ctx : CtxBase {
         RN_CHECK(peers && n == nranks, RN_E_ARG, "rn_debug_peer_inbox_connect_local: one context per rank expected");
         for (int r = 0; r < nranks; r++) {
             RN_CHECK(peers[r] && peers[r]->peer_inbox_ptr(), RN_E_STATE, "rn_debug_peer_inbox_connect_local: a rank has no inbox (rn_peer_inbox_create)");
+            RN_CHECK(!peerReady, RN_E_STATE, "rn_debug_peer_inbox_connect_local: the inboxes of this context are already connected");
             h_peer.inbox[r] = peers[r]->peer_inbox_ptr();
         }
         RN_CHECK(h_peer.inbox[rank] == d_inbox, RN_E_ARG, "rn_debug_peer_inbox_connect_local: contexts must be given in rank order");
@@ -1694,8 +1723,11 @@ struct Ctx : CtxBase {
     int globalize_history(int first, int n, T *tail) {
         hipLaunchKernelGGL(k_batch_close_pack<T>, dim3(1), dim3(ELT_THREADS), 0, stream, (const T *)tail, d_state, penX / stepSize, penXs / stepSize,
                            (const double *)d_histParts, first, n, d_histGlob);
-        if (int rc = all_reduce(d_histGlob, (size_t)4 * n + 1, true, "ncclAllReduce(verdict + primal infeasibilities)", 2 /* ncclMax */)) return rc;
-        hipLaunchKernelGGL(k_batch_close_unpack, dim3(1), dim3(ELT_THREADS), 0, stream, (const double *)d_histGlob, d_hist, first, n);
+        // (the last element: one-shot exchange, "a reader of this rank gave up waiting" -- the MAX makes it every rank's verdict, so all
+        //  ranks return RN_E_COMM for the batch together instead of the late one alone)
+        if (int rc = all_reduce(d_histGlob, (size_t)4 * n + 2, true, "ncclAllReduce(verdict + primal infeasibilities)", 2 /* ncclMax */)) return rc;
+        hipLaunchKernelGGL(k_batch_close_unpack, dim3(1), dim3(ELT_THREADS), 0, stream, (const double *)d_histGlob, d_hist, first, n, d_state);
+        if (int rc = comm_check()) return rc;
         RN_HIP(hipGetLastError());
         return RN_OK;
     }
@@ -2010,18 +2042,75 @@ struct Ctx : CtxBase {
     }
 
     // ---- multi-GPU ---------------------------------------------------------------------------------------
-    int comm_init(int rk, int nr, const void *id) override {
+    // The communicator of this context.  ncclCommInitRank blocks until every rank of the id has arrived -- for ever if one never does --
+    // so it is created NON-BLOCKING (ncclCommInitRankConfig, blocking = 0) and polled against the wall clock: after `timeoutSeconds`
+    // (< 0: $RAPIDNET_COMM_TIMEOUT_S, default 120) the half-made communicator is aborted and the call returns RN_E_COMM; the context
+    // itself stays usable, without a communicator (the reference would exit(), Configuration.h:38-81; this must neither exit nor hang).
+    // A non-blocking communicator may answer ncclInProgress to a later call as well (the first collective connects the channels on a
+    // helper thread): all_reduce() waits such a call out before anything else is put on the stream.  $RAPIDNET_COMM_BLOCKING=1 (or an
+    // RCCL without the config entry point) takes the plain blocking ncclCommInitRank.
+    bool commNonblocking = false;
+    double commTimeoutS = 120.0;
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    int comm_wait(void *c, int rc, double limitS, bool *timedOut) {   // waits out ncclInProgress; returns the final ncclResult_t
+        *timedOut = false;
+        const double t0 = now_s();
+        while (rc == NCCL_IN_PROGRESS) {
+            int st = 0;
+            const int q = g_nccl.GetAsyncError(c, &st);
+            if (q != 0) return q;
+            if (st != NCCL_IN_PROGRESS) return st;
+            if (now_s() - t0 > limitS) { *timedOut = true; return NCCL_IN_PROGRESS; }
+            std::this_thread::sleep_for(std::chrono::microseconds(500));
+        }
+        return rc;
+    }
+    int comm_init(int rk, int nr, const void *id, double timeoutSeconds = -1.0) override {
         RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
+        RN_CHECK(comm == nullptr, RN_E_STATE, "rn_comm_init: the context already has a communicator");
         rank = rk; nranks = nr;
         optHold = 0;                       // every rank starts its batches aligned (the back-off counter decides which path a batch takes)
         if (id == nullptr) return RN_OK;   // id == NULL: bookkeeping only (tests emulate the exchange)
         RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
         RN_HIP(hipSetDevice(device));
-        typedef int (*init_t)(void **, int, UniqueId128, int);
-        init_t f = (init_t)dlsym(g_nccl.h, "ncclCommInitRank");
+        if (timeoutSeconds < 0) { timeoutSeconds = 120.0; if (const char *e = std::getenv("RAPIDNET_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) timeoutSeconds = v; } }
+        commTimeoutS = timeoutSeconds;
         UniqueId128 u; std::memcpy(u.b, id, 128);
-        const int rc = f(&comm, nr, u, rk);
-        RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+        bool legacy = !(RN_HAVE_RCCL_CONFIG && g_nccl.InitRankConfig && g_nccl.GetAsyncError && g_nccl.CommAbort);
+        if (const char *e = std::getenv("RAPIDNET_COMM_BLOCKING")) { if (std::atoi(e) != 0) legacy = true; }
+        if (legacy) {
+            const int rc = g_nccl.InitRank(&comm, nr, u, rk);
+            if (rc != 0) comm = nullptr;
+            RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+            commNonblocking = false;
+            return RN_OK;
+        }
+#if RN_HAVE_RCCL_CONFIG
+        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+        cfg.blocking = 0;
+        void *c = nullptr;
+        bool timedOut = false;
+        int rc = g_nccl.InitRankConfig(&c, nr, u, rk, &cfg);
+        if (c != nullptr) rc = comm_wait(c, rc, timeoutSeconds, &timedOut);
+        if (rc != 0 || timedOut) {
+            if (c != nullptr) (void)g_nccl.CommAbort(c);      // allowed on a communicator whose set-up is still in progress
+            char b[256];
+            if (timedOut) snprintf(b, sizeof b, "ncclCommInitRank failed: rank %d of %d waited %.1f s for its peers (time-out; the context has no communicator)", rk, nr, timeoutSeconds);
+            else snprintf(b, sizeof b, "ncclCommInitRank failed: %s", g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?");
+            err = b;
+            return RN_E_COMM;
+        }
+        comm = c; commNonblocking = true;
+#endif
+        return RN_OK;
+    }
+    // asynchronous errors of the communicator (a peer that died, a link that went down): asked once per batch, never inside one
+    int comm_check() override {
+        if (!comm || !g_nccl.GetAsyncError) return RN_OK;
+        int st = 0;
+        const int q = g_nccl.GetAsyncError(comm, &st);
+        RN_CHECK(q == 0 && (st == 0 || st == NCCL_IN_PROGRESS), RN_E_COMM,
+                 std::string("RCCL reports an asynchronous error on the communicator: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(q != 0 ? q : st) : "?"));
         return RN_OK;
     }
     int set_allreduce(rn_allreduce_fn fn, void *user) override { arHook = fn; arUser = user; optHold = 0; return RN_OK; }
@@ -2228,6 +2317,8 @@ int rn_comm_unique_id(void *id128) {
     return rn::g_nccl.GetUniqueId(id128) == 0 ? RN_OK : RN_E_COMM;
 }
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128) { RN_GUARD(ctx); return ctx->impl->comm_init(rank, nranks, id128); }
+int rn_comm_init_timeout(rn_ctx *ctx, int rank, int nranks, const void *id128, double timeoutSeconds) { RN_GUARD(ctx); return ctx->impl->comm_init(rank, nranks, id128, timeoutSeconds); }
+int rn_comm_check(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->comm_check(); }
 int rn_comm_library(char *buf, size_t n) {
     if (!buf || n == 0) return RN_E_ARG;
     if (!rn::g_nccl.load()) { buf[0] = 0; return RN_E_COMM; }

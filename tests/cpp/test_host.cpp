@@ -17,6 +17,7 @@
 #include <thread>
 
 #include "../../rapidnet_amd/csrc/host/SmpcController.hpp"
+#include "../../include/rapidnet_debug.h"   // test hooks (leak injection, in-process communicator stand-in)
 
 static int g_failures = 0;
 #define CHECK(cond)                                                                      \

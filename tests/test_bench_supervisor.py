@@ -1,0 +1,96 @@
+"""bench.py --gpus N, the per-rank SUPERVISOR's protocol, on the CPU: the launcher starts two ranks whose workers are test doubles
+($RAPIDNET_BENCH_FAKE_WORKER: they sleep and print what a worker prints; no GPU, no solver), so what is checked is the part that
+has never run on a multi-GPU node -- the wall-clock budget, the partial result line, an optional job that is slow or hangs, a
+worker that dies after the headline.  Whatever the optional parts do, rank 0's ONE line must be on stdout within the budget."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(fake, budget, tmp, tag, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--time-budget", str(budget)] + list(extra)
+    env = dict(os.environ, RAPIDNET_BENCH_FAKE_WORKER=fake, RAPIDNET_BENCH_LINE_FILE=os.path.join(str(tmp), "line_%s.json" % tag), OMP_NUM_THREADS="1")
+    return time.time(), subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _finish(t0, proc, limit):
+    """(elapsed, exit code, JSON lines on stdout, stderr); the pipes are drained by threads, so several runs can be awaited in any order"""
+    import threading
+
+    box = {}
+
+    def wait():
+        out, err = proc.communicate()
+        box.update(out=out, err=err, t=time.time())
+
+    th = threading.Thread(target=wait, daemon=True)
+    th.start()
+    return th, box, t0, proc, limit
+
+
+def _result(handle):
+    th, box, t0, proc, limit = handle
+    th.join(limit)
+    if th.is_alive():
+        proc.kill()
+        th.join(10)
+        raise AssertionError("the run did not end within %d s" % limit)
+    lines = [l for l in box["out"].splitlines() if l.strip().startswith("{")]
+    return box["t"] - t0, proc.returncode, lines, box["err"]
+
+
+def test_supervisor_keeps_the_headline_whatever_the_optional_parts_do(tmp_path):
+    runs = {
+        # everything in time: the complete line, with the second worker's result merged in
+        "plain": _launch("headline=0.5,total=1,alt=0.5", 120, tmp_path, "plain"),
+        # the optional one-shot job hangs: killed at ITS limit (min(120, left - 15) = ~31 s of a 47 s budget), line printed within the budget
+        "alt_hangs": _launch("headline=0.5,total=1,alt=3600", 47, tmp_path, "alt_hangs"),
+        # too little budget left for the optional job: skipped by rank 0's decision on every rank
+        "alt_skipped": _launch("headline=0.5,total=1,alt=3600", 32, tmp_path, "alt_skipped"),
+        # rank 0's worker hangs AFTER the headline was measured: killed at the budget, the partial line is printed, exit code 0
+        "worker_hangs": _launch("headline=0.5,total=1,alt=0.5,hang_rank=0", 30, tmp_path, "worker_hangs"),
+        # rank 0's worker dies after the headline: the partial line is printed
+        "worker_dies": _launch("headline=0.5,total=2,alt=0.5,fail=3,fail_rank=0", 120, tmp_path, "worker_dies"),
+        # the optional job is switched off
+        "no_alt": _launch("headline=0.5,total=1,alt=3600", 120, tmp_path, "no_alt", ("--no-alt-exchange",)),
+    }
+    handles = {k: _finish(t0, p, 200) for k, (t0, p) in runs.items()}
+    res = {k: _result(h) for k, h in handles.items()}
+    for k, (elapsed, rc, lines, err) in res.items():
+        assert rc == 0, (k, rc, err[-1500:])
+        assert len(lines) == 1, (k, lines, err[-1500:])
+    d = {k: json.loads(v[2][0]) for k, v in res.items()}
+    assert d["plain"].get("complete") and d["plain"]["alt_exchange"] == {"value": 1.0, "fake": True} and "partial" not in d["plain"]
+    assert d["alt_hangs"].get("complete") and "did not finish within its" in d["alt_hangs"]["alt_exchange"]["error"]
+    assert res["alt_hangs"][0] < 47 + 15, res["alt_hangs"][0]
+    assert d["alt_skipped"].get("complete") and d["alt_skipped"]["alt_exchange"]["error"].startswith("skipped: budget")
+    assert res["alt_skipped"][0] < 32, res["alt_skipped"][0]          # nobody waited for the optional job
+    assert "complete" not in d["worker_hangs"] and "did not finish within the time budget" in d["worker_hangs"]["partial"] and d["worker_hangs"]["value"] == 123.0
+    assert res["worker_hangs"][0] < 30 + 25, res["worker_hangs"][0]
+    assert "complete" not in d["worker_dies"] and "ended with code 3" in d["worker_dies"]["partial"]
+    assert d["no_alt"].get("complete") and "alt_exchange" not in d["no_alt"]
+    # the line was on file from the moment it existed
+    for k in runs:
+        assert json.load(open(os.path.join(str(tmp_path), "line_%s.json" % k)))["value"] == 123.0
+
+
+def test_a_worker_that_fails_before_any_headline_fails_the_job(tmp_path):
+    """rank 1's worker dies (code 7) while rank 0 has no headline yet: no line, a non-zero exit code, and nobody waits for the budget"""
+    t0, p = _launch("headline=20,total=21,alt=0.5,fail=7,fail_rank=1,fail_at=2", 120, tmp_path, "early")
+    elapsed, rc, lines, err = _result(_finish(t0, p, 120))
+    assert rc != 0 and not lines, (rc, lines, err[-1500:])
+    assert elapsed < 20, elapsed

@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports exactly the symbols include/rapidnet.h declares."""
+"""The C-ABI library loads without a GPU and exports exactly the symbols include/*.h declare: the drop-in boundary
+(rapidnet.h) and the test hooks (rapidnet_debug.h, every one of them named rn_debug_*)."""
 import os
 import re
 
@@ -8,7 +9,12 @@ from rapidnet_amd import capi
 
 def test_every_declared_symbol_is_exported():
     hdr = open(os.path.join(ROOT, "include", "rapidnet.h")).read()
-    declared = set(re.findall(r"\b(rn_[a-z_0-9]+)\s*\(", hdr))
+    dbg = open(os.path.join(ROOT, "include", "rapidnet_debug.h")).read()
+    product = set(re.findall(r"\b(rn_[a-z_0-9]+)\s*\(", hdr))
+    hooks = set(re.findall(r"\b(rn_[a-z_0-9]+)\s*\(", dbg))
+    assert not [s for s in product if s.startswith("rn_debug_")], "test hooks belong in rapidnet_debug.h"
+    assert hooks and all(s.startswith("rn_debug_") for s in hooks), hooks
+    declared = product | hooks
     lib = capi.load()
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
