@@ -379,6 +379,9 @@ def supervise(args):
         th.join(10.0)
         return rc, found[0]
 
+    def say(what):
+        print("bench.py supervisor rank %d [%5.1f s of %.0f]: %s" % (rank, time.time() - t_start, budget, what), file=sys.stderr, flush=True)
+
     for suffix in (".headline", ".alt"):          # a stale file of an earlier job on the same port
         try:
             if rank == 0:
@@ -391,6 +394,7 @@ def supervise(args):
         # (`--emulate-world N`: rank 0's shard, one-rank communicator) under rocprofv3, before the rank's worker starts -- the other
         # ranks' workers wait for it in the rendezvous.  Handed to the worker, which puts it into `roofline.traffic`.
         per_pass = min(150.0, (remaining() - 330.0) / 2.0)
+        say("PMC pre-pass: %s" % ("2 passes of at most %.0f s" % per_pass if per_pass >= 40.0 else "skipped (budget)"))
         if per_pass >= 40.0:
             t, src = measure_traffic(args, ("--emulate-world", str(world)), launcher_env=True, limit=per_pass)
             if isinstance(src, dict) and src.get("how"):
@@ -399,6 +403,7 @@ def supervise(args):
             t, src = {}, {"measured_in_this_run": False, "how": None, "why_not": "skipped: budget (%.0f s left of %.0f)" % (remaining(), budget)}
         wenv["RAPIDNET_BENCH_TRAFFIC_JSON"] = json.dumps({"traffic": t, "source": src})
     # ---- step 1: the worker.  It may use what is left of the budget (a margin for printing aside).
+    say("starting the worker (limit %.0f s)" % (remaining() - 5.0))
     rc, line = run_worker(base, wenv, '"metric"', remaining() - 5.0, on_line=keep if rank == 0 else None)
     if rc != 0:
         why = "did not finish within the time budget of %.0f s (killed)" % budget if rc is None else "ended with code %s" % rc
@@ -431,6 +436,7 @@ def supervise(args):
                 except OSError:
                     time.sleep(0.1)
             decision = decision or "skip"
+        say("worker done; one-shot exchange job: %s" % decision)
         if decision.startswith("run"):
             limit = float(decision.split()[1])
             env = {k: v for k, v in os.environ.items() if k != "RAPIDNET_BENCH_FAULT"}
@@ -446,6 +452,7 @@ def supervise(args):
                        else "the one-shot exchange job ended with code %d and no result (see stderr)" % rc2}
         else:
             alt = {"error": "skipped: budget (%.0f s of %.0f left after the headline run)" % (remaining(), budget)}
+    say("done")
     if rank == 0:
         if line is None:
             print("bench.py: rank 0's worker ended without a result line", file=sys.stderr, flush=True)
@@ -535,6 +542,101 @@ def cpu_baseline(problem_name, problem, precision, timed_iterations=20, sample_l
         "ms_per_iteration_median": 1e3 * med, "ms_per_controlStep_500it": 500.0 * 1e3 * med * (float(nodes_full) / o.nodes),
         "scaled_by_nodes": bool(scaled), "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
     }
+
+
+def shard_ceiling(problem, device, steps, unsharded_ms, profile_steps=40):
+    """1 GPU: what ONE RANK of a W-rank run executes, for W = 2, 4, 8 -- rank 0's shard (the largest: the subtrees are dealt
+    round-robin) of the bench workload through the whole sharded path of the library: rn_partition_create, a real one-rank RCCL
+    communicator (every ncclAllReduce of the path is issued and runs), the cut stage, device-resident batches; then the same
+    context with the one-shot exchange (the rank writes to and reads from its own inbox).  Everything a rank does except the
+    wire and the wait for its peers, so `speedup_before_wire` = unsharded time / this time is the CEILING of the W-GPU
+    speed-up, and `exchange_budget_us_for_3p5x` (W = 8) is what the exchange over xGMI may cost per iteration with north_star's
+    >= 3.5x still met.  The iterates are not the solution (the other ranks' sums are missing); timing only."""
+    from rapidnet_amd import capi, synth
+
+    cut = capi.default_cut_stage(problem["tree"])
+    dh, ah = synth.forecast_at(problem["forecast"], 0)
+    n_it = max(int(steps), 100)
+    rows = []
+    for W in (2, 4, 8):
+        row = {"world": W}
+        try:
+            part = capi.partition_tree(problem["tree"], 0, W, cut)
+            s = capi.Solver(problem["network"], part["tree"], problem["config"], precision="f64", device=device)
+            s.commInit(0, 1, capi.comm_unique_id())
+            s.setCutStage(cut, (part["momE"], part["momP"]))
+            s.initialiseSmpcController(dh, ah)
+            row["local_nodes"] = int(s.nodes)
+
+            def timed(tag):
+                s.apgReset()
+                for _ in range(4):
+                    s.apgIterate(20, history=False)
+                s.synchronize()
+                reg = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    s.apgIterate(n_it, history=False)
+                    s.synchronize()
+                    reg.append(1e3 * (time.perf_counter() - t0) / n_it)
+                s.apgReset()
+                s.apgIterate(5, history=False)
+                s.profileEnable(1); s.profileReset()
+                s.apgIterate(profile_steps, history=False)
+                ms, n = s.profileRead()
+                cms, cn = s.profileReadCollective()
+                s.profileEnable(0)
+                med = float(np.median(reg))
+                return {"ms_per_step": med, "ms_per_step_min": min(reg), "ms_per_step_max": max(reg), "regions": len(reg), "steps_per_region": n_it,
+                        "kernel_classes_us": {"stream_gemv": 1e3 * ms[0] / max(n[0], 1), "recursion+shared_gemms(incl. exchange)": 1e3 * ms[1] / max(n[1], 1),
+                                              "dual_update": 1e3 * ms[2] / max(n[2], 1), "collective_per_step": 1e3 * cms / max(profile_steps, 1)},
+                        "speedup_before_wire": unsharded_ms / med}
+
+            row["rccl_one_rank"] = timed("rccl")
+            s.peerInboxConnect([s.peerInboxCreate()])
+            s.setExchangeTransport(1)
+            row["one_shot"] = timed("oneshot")
+            best = min(row["rccl_one_rank"]["ms_per_step"], row["one_shot"]["ms_per_step"])
+            row["exchange_budget_us_for_3p5x"] = 1e3 * (unsharded_ms / 3.5 - best) if W == 8 else None
+            s.close()
+        except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
+            row["error"] = "%s: %s" % (type(e).__name__, e)
+        rows.append(row)
+    return {"what": "rank 0's shard of a W-rank partition of the bench workload through the whole sharded path on ONE GPU (one-rank RCCL communicator; "
+                    "one-shot: the rank's own inbox): per-rank time without the wire and the wait for peers => ceiling of the W-GPU speed-up",
+            "cut_stage": int(cut), "unsharded_ms_per_step": unsharded_ms, "shards": rows}
+
+
+def quasi_newton(problem, device, iterations=40):
+    """1 GPU: the global-FBE and NAMA outer loops (SmpcController::algorithmGlobalFbe / algorithmNama, SmpcController.cu:1529-1586) on
+    the bench workload, fp64, dense per-node blocks and the structured operator mode: ms per iteration over `iterations`
+    iterations after 3 untimed ones (one rn_algorithm_fbe_nama call: line searches, L-BFGS, read-backs included), the step sizes the
+    line searches took and the library's counters."""
+    from rapidnet_amd import capi, synth
+
+    dh, ah = synth.forecast_at(problem["forecast"], 0)
+    out = {"iterations": iterations, "dtype": "f64", "unit": "ms per iteration"}
+    for structured in (False, True):
+        for alg, key in (("globalFbeAlgorithm", "global_fbe"), ("namaAlgorithm", "nama")):
+            name = "%s_%s" % (key, "structured" if structured else "dense")
+            try:
+                s = capi.Solver(problem["network"], problem["tree"], problem["config"], precision="f64", device=device, structured=structured)
+                s.initialiseSmpcController(dh, ah)
+                s.setAlgorithm(alg, 5)
+                run = s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama
+                run(3)
+                s.synchronize()
+                t0 = time.perf_counter()
+                h, v, tau = run(iterations)
+                dt = time.perf_counter() - t0
+                c = s.fbeCounters()
+                out[name] = {"ms_per_iteration": 1e3 * dt / iterations, "tau_first": [float(x) for x in tau[:8]], "tau_mean": float(np.mean(tau)),
+                             "value_first_last": [float(v[0]), float(v[-1])], "primal_inf_first_last": [float(h[0]), float(h[-1])],
+                             "counters": c if isinstance(c, dict) else [int(x) for x in c]}
+                s.close()
+            except Exception as e:   # noqa: BLE001
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def main():
@@ -1016,7 +1118,7 @@ def main():
     # N > 1: configs[4] -- the wide network, fp32, sharded over the N GPUs like the headline tree (every rank runs it: collectives).
     others = []
     if not args.structured and args.workload == "barcelona493" and not args.traffic_probe:
-        others = [w for w in args.other_configs.split(",") if w and w != args.workload]
+        others = [w for w in args.other_configs.split(",") if w and w != args.workload and w != "%s:%s" % (args.workload, precision)]
         if sharded:
             others = [w for w in others if w == "wide4096"] if world > 1 else []
     out = None
@@ -1056,12 +1158,13 @@ def main():
             # the most complete one it has seen and prints ONE (supervise): nothing that follows can take the headline with it
             emit_partial(out, "headline measured; secondary configs (wide4096), the one-shot exchange pass and the CPU baseline pending")
     entries = []
-    for w in others:
-        prec_w = "f32" if w.startswith("wide") else "f64"
+    for spec in others:
+        w, _, prec_req = spec.partition(":")
+        prec_w = prec_req if prec_req in ("f32", "f64") else ("f32" if w.startswith("wide") else "f64")
         entry = {"workload": w, "dtype": prec_w}
         try:
             beat("problem data (%s)" % w)
-            pw = synth.make_problem(w)
+            pw = problem if w == args.workload else synth.make_problem(w)
             cut_w = capi.default_cut_stage(pw["tree"]) if sharded else -1
             r = run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=min(args.repeats, 4), problem=pw, tree=pw["tree"],
                          precision=prec_w, workload=w, control_step=False, cut_stage=cut_w, fatal=False)
@@ -1078,7 +1181,8 @@ def main():
                 beat("CPU baseline (%s)%s" % (w, "" if rank == 0 else ": waiting for rank 0"), 1300.0)   # every rank: the others wait in the next collective
             if rank == 0 and not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
-            del pw
+            if pw is not problem:
+                del pw
         except AgreedFailure as e:   # every rank raised it together: reported, the run goes on
             entry["error"] = "AgreedFailure: %s" % e
         except Exception as e:   # a config that does not fit this device / host is reported, not fatal for the headline
@@ -1115,12 +1219,31 @@ def main():
             sr.close()
         except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
             replay = {"error": "%s: %s" % (type(e).__name__, e)}
+    # 1 GPU, default run: the one-GPU half of the multi-GPU story and the quasi-Newton loops, timed by THIS run (round 5; they were
+    # builder-run files under profiles/ before)
+    ceiling, qn = None, None
+    if not sharded and not args.structured and args.workload == "barcelona493" and precision == "f64" and not args.traffic_probe and not args.dense_only:
+        unsharded_ms = float(head["spread"]["ms_per_step_median"]) if head.get("spread") else 1e3 * dt / args.steps
+        if not args.no_shard_ceiling:
+            try:
+                ceiling = shard_ceiling(problem, device, args.steps, unsharded_ms, profile_steps=max(args.profile_steps, 20))
+            except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
+                ceiling = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_quasi_newton:
+            try:
+                qn = quasi_newton(problem, device)
+            except Exception as e:   # noqa: BLE001
+                qn = {"error": "%s: %s" % (type(e).__name__, e)}
     beat("closing: rank 0's CPU baseline, then the last barrier", 1300.0)      # every rank the same limit (rank 0 times the CPU legs meanwhile)
     if rank == 0:
         if replay is not None:
             out["replay_path"] = replay
         if entries:
             out["configs"] = entries
+        if ceiling is not None:
+            out["shard_ceiling"] = ceiling
+        if qn is not None:
+            out["quasi_newton"] = qn
         if args.worker:
             emit_partial(out, "headline and secondary configs measured; CPU baseline pending")
         if not args.no_cpu_baseline and not args.traffic_probe and (not sharded or world > 1):

@@ -261,9 +261,10 @@ void *rn_stream(rn_ctx *ctx);
  * distributed by the caller (bench.py uses torch.distributed for that). */
 int rn_comm_unique_id(void *id128 /* 128 bytes out */);
 /* id128 == NULL records rank / nranks without creating a communicator (the exchange is then a test's job, rapidnet_debug.h).
- * The communicator is created non-blocking and polled: a rank whose peers do not arrive within the time-out ($RAPIDNET_COMM_TIMEOUT_S,
- * default 120 s; rn_comm_init_timeout: `timeoutSeconds`) gets RN_E_COMM back -- never a hang (the reference exits on any failure,
- * Configuration.h:38-81) -- and the context stays usable without a communicator. */
+ * ncclCommInitRank waits for every rank of the id; it runs on a helper thread and the caller waits against the wall clock: a rank
+ * whose peers do not arrive within the time-out ($RAPIDNET_COMM_TIMEOUT_S, default 120 s; rn_comm_init_timeout: `timeoutSeconds`)
+ * gets RN_E_COMM back -- never a hang (the reference exits on any failure, Configuration.h:38-81) -- and the context stays usable
+ * without a communicator. */
 int rn_comm_init(rn_ctx *ctx, int rank, int nranks, const void *id128);
 int rn_comm_init_timeout(rn_ctx *ctx, int rank, int nranks, const void *id128, double timeoutSeconds);
 /* asynchronous errors of the communicator (ncclCommGetAsyncError: a peer died, a link went down): RN_E_COMM if RCCL reports one.

@@ -1840,6 +1840,210 @@ __global__ void __launch_bounds__(RN_WIDE_THREADS) k_gemm_vlv_wide(GemmArgs<T> g
 }
 
 // ------------------------------------------------------------------------------------------------------
+// LDS-staged form of the shared-operator products, for launches with MORE slabs than CUs (the whole 493-scenario tree: 679 slabs on
+// 256 CUs; round 5).  k_gemm_vlv / k_gemm_prep_m2 take every A fragment of the shared operator from L2, once per 16-node slab and
+// wave: 297 KB per slab, 200 MB per launch, and the latency of those loads -- not the matrix pipe -- sets the pace (30 us against a
+// 12 us MFMA floor; the register-pipelined k_gemm_vlv_wide only trades latency for occupancy: 31 us).  Here ONE workgroup per CU owns
+// CT consecutive slabs and walks K in chunks of LDSG_KC = 16 columns of the operator; TWO LOADER WAVES copy chunk c + 1 from L2 into
+// the other half of a two-slot LDS ring with global_load_lds_dwordx4 (1 KiB per wave-instruction, no register on the way) while the
+// EIGHT MFMA WAVES multiply chunk c: A and B fragments both come from LDS (ds_read_b64, ~100 cycles, no queue behind a stream), every
+// operator byte is fetched once per CT slabs (164 KB + 137 KB per workgroup instead of 3 x 297 KB), and an MFMA wave never waits for
+// global memory inside the loop.  One s_barrier per chunk: the loaders wait for their own copies (vmcnt(0)) in front of it, the MFMA
+// waves have consumed the chunk they read when they reach it.
+// The operator travels as an LDS IMAGE prepared by the host (LdsImage): per pass of 16 row tiles (256 rows; an MFMA wave owns up to
+// LDSG_TPW = 2 of them) and chunk, 16 columns of `ldm` values, ldm = (rows of the pass) rounded so that ldm % 32 == 16 -- the four
+// k-quarters of a 16x16x4 A fragment then start 128 bytes apart modulo the 256 bytes of one LDS pass: conflict-free ds_read_b64 / b32
+// -- zero padded; a chunk is a whole number of KiB, so the lane-linear copy of global_load_lds reproduces the image as it is.
+// Every output element is the same chain of MFMAs over k (ascending, 4 per instruction) as in k_gemm_vlv: bitwise the same results.
+constexpr int LDSG_MMA = 8, LDSG_LD = 2, LDSG_KC = 16, LDSG_TPW = 2, LDSG_PASS_TILES = LDSG_MMA * LDSG_TPW;
+constexpr int LDSG_THREADS = 64 * (LDSG_MMA + LDSG_LD);
+template <typename T>
+struct LdsImage {
+    const T *img;      // [pass][chunk][LDSG_KC][ldm(pass)]
+    int tiles;         // 16-row tiles of the operator (ceil(m / 16))
+    int chunks;        // kp / LDSG_KC
+};
+__host__ __device__ __forceinline__ int ldsg_pass_tiles(int tiles, int pass) { const int left = tiles - pass * LDSG_PASS_TILES; return left < LDSG_PASS_TILES ? left : LDSG_PASS_TILES; }
+__host__ __device__ __forceinline__ int ldsg_ldm(int passTiles) { const int r = passTiles * 16; return (r % 32 == 16) ? r : r + 16; }
+typedef __attribute__((address_space(1))) const void ldsg_gptr;
+typedef __attribute__((address_space(3))) void ldsg_lptr;
+// end of a chunk step: everything this wave has in flight that the others depend on is complete, then the workgroup's barrier
+__device__ __forceinline__ void ldsg_barrier_mma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void ldsg_barrier_loader() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+// One product  out = epi(M * in)  for the workgroup's CT slabs.  sIn: [CT * 16][SIN] (zero beyond k), ring: 2 slots of LDSG_KC * ldmMax values;
+// sOut != nullptr keeps the results in LDS as well ([CT * 16][SO]).  Called by ALL waves of the workgroup (MFMA waves: wave < LDSG_MMA).
+// On return every wave has passed the barrier behind the last chunk; the epilogue's LDS writes are NOT yet fenced (the caller's next
+// barrier does that).
+template <typename T, int EPI, int CT>
+__device__ __forceinline__ void ldsg_product(const GemmArgs<T> &g, const LdsImage<T> &im, const T *sIn, int SIN, T *ring, int ringSlot, int node0, int wave, int lane,
+                                             T *sOut, int SO) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    const int col = lane & 15, kq = lane >> 4;
+    const int passes = (im.tiles + LDSG_PASS_TILES - 1) / LDSG_PASS_TILES;
+    size_t passOff = 0;
+    for (int p = 0; p < passes; p++) {
+        const int pt = ldsg_pass_tiles(im.tiles, p), ldm = ldsg_ldm(pt);
+        const int chunkVals = LDSG_KC * ldm;
+        if (wave >= LDSG_MMA) {
+            // ---- loader waves: chunk c + 1 into the other slot while chunk c is multiplied
+            const int lw = wave - LDSG_MMA;
+            constexpr int PIECE = 1024 / (int)sizeof(T);            // values per 1 KiB piece (one wave-instruction)
+            const int pieces = chunkVals / PIECE;
+            const T *src = im.img + passOff + (size_t)lane * (16 / sizeof(T));
+            for (int c = -1; c < im.chunks; c++) {
+                if (c + 1 < im.chunks) {
+                    const T *cs = src + (size_t)(c + 1) * chunkVals;
+                    T *dst = ring + (size_t)((c + 1) & 1) * ringSlot;
+                    for (int i = lw; i < pieces; i += LDSG_LD)
+                        __builtin_amdgcn_global_load_lds((ldsg_gptr *)(cs + (size_t)i * PIECE), (ldsg_lptr *)(dst + (size_t)i * PIECE), 16, 0, 0);
+                }
+                ldsg_barrier_loader();
+            }
+        } else {
+            // ---- MFMA waves: row tiles wave and wave + LDSG_MMA of this pass, all CT column tiles (slabs)
+            const int nT = wave < pt ? (wave + LDSG_MMA < pt ? 2 : 1) : 0;
+            acc_t acc[LDSG_TPW][CT];
+#pragma unroll
+            for (int j = 0; j < LDSG_TPW; j++)
+#pragma unroll
+                for (int c = 0; c < CT; c++) acc[j][c] = acc_t{0, 0, 0, 0};
+            // the epilogue's operands (m1_i) of the wave's FIRST tile are requested in front of the loop: nothing in the loop waits for
+            // global memory; a second tile's (operators of more than 8 row tiles per pass with an epilogue operand: not the Barcelona
+            // shapes) are requested in the epilogue -- both sets live across the loop cost 24 more registers and spilled (fp64, CT = 3)
+            T auxv[CT][4], scale[CT];
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                const int node = node0 + c * 16 + col;
+                const int nodeC = node < g.nodes ? node : g.nodes - 1;
+                scale[c] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = (p * LDSG_PASS_TILES + wave) * 16 + Mfma16<T>::row(lane, reg);
+                    auxv[c][reg] = (EPI != EPI_LV && nT > 0) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
+                }
+            }
+            const T *Bp = sIn + (size_t)col * SIN + kq;
+            const int aOff = kq * ldm + wave * 16 + col;              // this lane's element of the wave's first tile, k-step 0 of a chunk
+            ldsg_barrier_mma();                                       // chunk 0 has landed (and the caller's LDS writes are visible)
+            for (int c = 0; c < im.chunks; c++) {
+                const T *Ac = ring + (size_t)(c & 1) * ringSlot + aOff;
+                if (nT > 0) {
+                    T av[LDSG_KC / 4][LDSG_TPW], bv[LDSG_KC / 4][CT];
+#pragma unroll
+                    for (int s = 0; s < LDSG_KC / 4; s++) {
+#pragma unroll
+                        for (int j = 0; j < LDSG_TPW; j++) av[s][j] = Ac[(size_t)(4 * s) * ldm + (j < nT ? j : 0) * (LDSG_MMA * 16)];
+#pragma unroll
+                        for (int cc = 0; cc < CT; cc++) bv[s][cc] = Bp[(size_t)cc * 16 * SIN + c * LDSG_KC + 4 * s];
+                    }
+#pragma unroll
+                    for (int s = 0; s < LDSG_KC / 4; s++)
+#pragma unroll
+                        for (int j = 0; j < LDSG_TPW; j++)
+                            if (j < nT) {
+#pragma unroll
+                                for (int cc = 0; cc < CT; cc++) acc[j][cc] = Mfma16<T>::run(av[s][j], bv[s][cc], acc[j][cc]);
+                            }
+                }
+                ldsg_barrier_mma();
+            }
+            // ---- epilogue
+#pragma unroll
+            for (int j = 0; j < LDSG_TPW; j++) {
+                if (j >= nT) break;
+                const int t = p * LDSG_PASS_TILES + wave + j * LDSG_MMA;
+                if (j > 0 && EPI != EPI_LV) {
+#pragma unroll
+                    for (int c = 0; c < CT; c++) {
+                        const int node = node0 + c * 16 + col;
+                        const int nodeC = node < g.nodes ? node : g.nodes - 1;
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                            auxv[c][reg] = gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CT; c++) {
+                    const int node = node0 + c * 16 + col;
+                    const bool nodeOk = node < g.nodes;
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                        T r = acc[j][c][reg];
+                        if (EPI == EPI_V) r = auxv[c][reg] + scale[c] * r;
+                        if (EPI == EPI_Z) r = auxv[c][reg] + r;
+                        const bool live = gr < g.m;
+                        if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
+                        if (sOut && live) sOut[(size_t)(c * 16 + col) * SO + gr] = nodeOk ? r : (T)0;
+                    }
+                }
+            }
+        }
+        passOff += (size_t)im.chunks * chunkVals;
+        // the next pass's chunk 0 goes into slot 0: the last chunk's barrier has been passed by everybody, slot 0 is free
+    }
+}
+// v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  (k_gemm_vlv's two products), LDS-staged.
+// LDS: sB [CT * 16][SB] | sV [CT * 16][SV] | ring (2 slots); the second product's ring lies over sB, which is dead by then.
+template <typename T, int CT>
+__global__ void __launch_bounds__(LDSG_THREADS) k_gemm_vlv_lds(GemmArgs<T> gV, GemmArgs<T> gL, LdsImage<T> imV, LdsImage<T> imL, int SB, int SV, int ringSlotV, int ringSlotL,
+                                                             SweepArgs<T> a, int foldRoot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);
+    T *sV = sB + (size_t)CT * 16 * SB;
+    T *ringV = sV + (size_t)CT * 16 * SV;
+    T *ringL = sB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv); foldRoot = 2 never comes here
+        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int node0 = blockIdx.x * 16 * CT;
+    const int cnt = gV.nodes - node0 < 16 * CT ? gV.nodes - node0 : 16 * CT;
+    if (wave < LDSG_MMA) {
+        slab_load<T, RN_WIDE_LD>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, LDSG_MMA, lane, 16 * CT);
+        for (int i = threadIdx.x; i < CT * 16 * SV; i += 64 * LDSG_MMA) sV[i] = (T)0;
+    }
+    ldsg_product<T, EPI_V, CT>(gV, imV, sB, SB, ringV, ringSlotV, node0, wave, lane, sV, SV);
+    __syncthreads();                            // v of the slabs is complete in sV; sB is free for the second ring
+    ldsg_product<T, EPI_LV, CT>(gL, imL, sV, SV, ringL, ringSlotL, node0, wave, lane, nullptr, 0);
+}
+// Structured operator mode, first product of the sweep (k_gemm_prep_m2), LDS-staged: the slabs of [a; b] are built in LDS straight
+// from the duals by the MFMA waves while the loaders fetch the first chunk of [Bbt | L'].
+template <typename T, int CT>
+__global__ void __launch_bounds__(LDSG_THREADS) k_gemm_prep_m2_lds(GemmArgs<T> g, LdsImage<T> im, SweepArgs<T> a, int SB, int ringSlot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [CT * 16][SB]
+    T *ring = sB + (size_t)CT * 16 * SB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node0 = blockIdx.x * 16 * CT;
+    const int cnt = g.nodes - node0 < 16 * CT ? g.nodes - node0 : 16 * CT;
+    const int nx = a.nx, ny = a.ny, k = g.k;     // k = nx + nu
+    if (wave < LDSG_MMA) {
+        for (int r = wave; r < 16 * CT; r += LDSG_MMA) {         // one slab row (node) per wave and pass
+            const int node = node0 + (r < cnt ? r : 0);
+            const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
+            const size_t y = (size_t)node * ny;
+            const T sp = a.tr.sqrtp[node];
+            for (int t = lane; t < SB; t += 64) {
+                T val = 0;
+                if (r < cnt && t < k) {
+                    if (t < nx) { val = sp * (dy[t] * sweep_w(a, y + t) + dy[nx + t] * sweep_w(a, y + nx + t)); a.qa[(size_t)node * nx + t] = val; }
+                    else { const int j = t - nx; val = sp * dy[2 * nx + j] * sweep_w(a, y + 2 * nx + j); }
+                }
+                sB[(size_t)r * SB + t] = val;
+            }
+        }
+    }
+    ldsg_product<T, EPI_LV, CT>(g, im, sB, SB, ring, ringSlot, node0, wave, lane, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
 // Utilities.cu:142-155) and the diagonal Hx products (:744-747):
 //   u_i = uhat_i + (u_anc - uhat_anc) + L v_i        root: (prevU - prevUhat)

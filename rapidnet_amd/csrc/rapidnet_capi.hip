@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -22,12 +23,6 @@
 
 #include "../../include/rapidnet.h"
 #include "../../include/rapidnet_debug.h"
-#if __has_include(<rccl/rccl.h>)
-#include <rccl/rccl.h>      // types only (ncclConfig_t and its initializer): every RCCL function is bound at run time, nothing is linked
-#define RN_HAVE_RCCL_CONFIG 1
-#else
-#define RN_HAVE_RCCL_CONFIG 0
-#endif
 #include "fbe_kernels.hpp"
 #include "partition.hpp"
 
@@ -93,7 +88,6 @@ struct NcclApi {
     int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*InitRank)(void **, int, struct UniqueId128, int) = nullptr;
-    int (*InitRankConfig)(void **, int, struct UniqueId128, int, void *) = nullptr;   // NCCL >= 2.14
     int (*GetAsyncError)(void *, int *) = nullptr;
     int (*CommAbort)(void *) = nullptr;
     std::string path;   // file the bound image was loaded from (rn_comm_library)
@@ -111,7 +105,6 @@ struct NcclApi {
         CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
         GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
         InitRank = (int (*)(void **, int, UniqueId128, int))dlsym(h, "ncclCommInitRank");
-        InitRankConfig = (int (*)(void **, int, UniqueId128, int, void *))dlsym(h, "ncclCommInitRankConfig");
         GetAsyncError = (int (*)(void *, int *))dlsym(h, "ncclCommGetAsyncError");
         CommAbort = (int (*)(void *))dlsym(h, "ncclCommAbort");
         Dl_info info;
@@ -390,12 +383,7 @@ struct Ctx : CtxBase {
         }
         RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
         hipEvent_t ev = prof_begin(4);
-        int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
-        if (rc == NCCL_IN_PROGRESS && commNonblocking) {   // (the first collective of a non-blocking communicator connects its channels on a helper thread)
-            bool timedOut = false;
-            rc = comm_wait(comm, rc, commTimeoutS, &timedOut);
-            if (timedOut) { prof_end(ev); err = std::string(what) + ": still in progress after the communicator's time-out"; return RN_E_COMM; }
-        }
+        const int rc = g_nccl.AllReduce(buf, buf, count, f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, op, comm, stream);
         prof_end(ev);
         RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
         return RN_OK;
@@ -523,6 +511,67 @@ struct Ctx : CtxBase {
         for (int j = 0; j < k; j++) for (int i = 0; i < m; i++) tmp[i + (size_t)j * mp] = src[i + (size_t)j * m];
         return upload(dst, tmp.data(), tmp.size());
     }
+    // LDS image of a shared operator for the LDS-staged slab products (kernels.hpp, LdsImage): col-major m x k -> per pass of 16 row tiles
+    // and chunk of 16 columns, 16 columns of ldm values, zero padded
+    T *d_imgRT = nullptr, *d_imgLBL = nullptr, *d_imgBL = nullptr;
+    static size_t lds_image_values(int m, int k) {
+        const int tiles = (m + 15) / 16, chunks = pad4(k) / LDSG_KC;
+        size_t tot = 0;
+        for (int p = 0; p * LDSG_PASS_TILES < tiles; p++) tot += (size_t)chunks * LDSG_KC * ldsg_ldm(ldsg_pass_tiles(tiles, p));
+        return tot;
+    }
+    int upload_lds_image(T *dst, const double *src, int m, int k) {
+        static_assert(LDSG_KC == 4 * RN_SLAB_KU, "the operators' K is padded to whole chunks by pad4");
+        const int tiles = (m + 15) / 16, chunks = pad4(k) / LDSG_KC;
+        std::vector<double> img(lds_image_values(m, k), 0.0);
+        size_t off = 0;
+        for (int p = 0; p * LDSG_PASS_TILES < tiles; p++) {
+            const int pt = ldsg_pass_tiles(tiles, p), ldm = ldsg_ldm(pt);
+            for (int col = 0; col < k; col++)
+                for (int r = 0; r < pt * 16; r++) {
+                    const int row = p * LDSG_PASS_TILES * 16 + r;
+                    if (row < m) img[off + (size_t)col * ldm + r] = src[row + (size_t)col * m];
+                }
+            off += (size_t)chunks * LDSG_KC * ldm;
+        }
+        return upload(dst, img.data(), img.size());
+    }
+    LdsImage<T> lds_image(const T *img, int m, int k) const { return LdsImage<T>{img, (m + 15) / 16, pad4(k) / LDSG_KC}; }
+    static int lds_ring_slot(int m) { return LDSG_KC * ldsg_ldm(ldsg_pass_tiles((m + 15) / 16, 0)); }      // values; pass 0 is the tallest
+    // Slabs per workgroup of the LDS-staged products (0: the L2-fed kernels run).  They pay when a launch has more slabs than CUs --
+    // there the shared operators' fragments, re-read from L2 per slab and wave, set the pace (kernels.hpp) -- and need one
+    // workgroup's LDS to hold CT slabs of both vectors and the two-slot ring: the largest CT <= 3 that fits 160 KB.
+    int ldsCtVlv = -1, ldsCtM2 = -1;
+    bool lds_want() const {
+        int force = -1;
+        if (const char *e = std::getenv("RAPIDNET_SLAB_LDS")) force = std::atoi(e);   // A/B runs and tests: 0 off, 1 on wherever it fits (read when a context launches its first sweep)
+        // OPT-IN (round 5): measured slower than the L2-fed kernels on the 493-scenario tree -- 36.0 against 30.3 us for the v / Lv pair,
+        // 29.6 against 22.4 us for the structured mode's first product (same box, profiles/r05_ab_lds.txt): one workgroup per CU and a
+        // barrier per chunk leave nothing to overlap the prologue, the epilogue and the LDS round trips with, which three co-resident
+        // workgroups of the L2-fed kernel do for each other
+        return force > 0;
+    }
+    size_t lds_bytes_vlv(int ct) const {
+        const int SB = slab_stride(pad4(d.nv + d.nx)), SV = slab_stride(pad4(d.nv));
+        const size_t ringV = (size_t)2 * lds_ring_slot(d.nv), ringL = (size_t)2 * lds_ring_slot(d.nu + d.nx);
+        if (ringL > (size_t)ct * 16 * SB) return (size_t)-1;            // the second product's ring lies over the first slab buffer
+        return ((size_t)ct * 16 * (SB + SV) + ringV) * sizeof(T);
+    }
+    size_t lds_bytes_m2(int ct) const { return ((size_t)ct * 16 * slab_stride(pad4(d.nx + d.nu)) + (size_t)2 * lds_ring_slot(d.nv)) * sizeof(T); }
+    template <typename F3, typename F2>
+    int lds_pick_ct(size_t (Ctx::*bytes)(int) const, F3 f3, F2 f2) {
+        if (!lds_want() || !d_imgRT) return 0;
+        for (int ct : {3, 2}) {
+            const size_t b = (this->*bytes)(ct);
+            if (b == (size_t)-1 || b > 160 * 1024) continue;
+            const void *fn = ct == 3 ? (const void *)f3 : (const void *)f2;
+            if (b <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) return ct;
+            (void)hipGetLastError();
+        }
+        return 0;
+    }
+    int lds_ct_vlv() { if (ldsCtVlv < 0) ldsCtVlv = lds_pick_ct(&Ctx::lds_bytes_vlv, k_gemm_vlv_lds<T, 3>, k_gemm_vlv_lds<T, 2>); return ldsCtVlv; }
+    int lds_ct_m2() { if (ldsCtM2 < 0) ldsCtM2 = lds_pick_ct(&Ctx::lds_bytes_m2, k_gemm_prep_m2_lds<T, 3>, k_gemm_prep_m2_lds<T, 2>); return ldsCtM2; }
     TreeDev<T> tree_dev() const { return TreeDev<T>{d_stageCum, d_parent, d_childStart, d_childCount, d_stageOf, d_sqrtp, d_prob, d_dy}; }
     SweepArgs<T> sweep_args() const {
         SweepArgs<T> a{};
@@ -624,6 +673,7 @@ struct Ctx : CtxBase {
         DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
         DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_hx, n * ny)
         DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lvb, n * (nu + nx)) DA(d_eb, n * nx) DA(d_bw0, nx) DA(d_bw, n * nx)
+        DA(d_imgRT, lds_image_values(nv, nv + nx)) DA(d_imgLBL, lds_image_values(nu + nx, nv)) DA(d_imgBL, lds_image_values(nv, nx + nu))
         DA(d_LBLp, (size_t)pad16(nu + nx) * pad4(nv))
         DA(d_BLp, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_ab, n * (nx + nu))
         DA(d_RTp, (size_t)pad16(nv) * pad4(nv + nx)) DA(d_Lp, (size_t)pad16(nu) * pad4(nv)) DA(d_Bp, (size_t)pad16(nx) * pad4(nu))
@@ -689,6 +739,7 @@ struct Ctx : CtxBase {
             std::copy(h_Bbt.begin(), h_Bbt.end(), BL.begin());
             std::copy(Lt.begin(), Lt.end(), BL.begin() + (size_t)nv * nx);
             if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
+            if (int rc = upload_lds_image(d_imgBL, BL.data(), nv, nx + nu)) return rc;
         }
         {   // [L ; B L]  ((nu+nx) x nv) for the forward GEMM
             std::vector<double> BLm((size_t)nx * nv), LBL((size_t)(nu + nx) * nv);
@@ -698,11 +749,13 @@ struct Ctx : CtxBase {
                 for (int i = 0; i < nx; i++) LBL[nu + i + (size_t)j * (nu + nx)] = BLm[i + (size_t)j * nx];
             }
             if (int rc = upload_padded(d_LBLp, LBL.data(), nu + nx, nv)) return rc;
+            if (int rc = upload_lds_image(d_imgLBL, LBL.data(), nu + nx, nv)) return rc;
         }
         std::vector<double> RTm((size_t)nv * (nv + nx));
         std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
         if (int rc = upload_padded(d_RTp, RTm.data(), nv, nv + nx)) return rc;
+        if (int rc = upload_lds_image(d_imgRT, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
         UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
@@ -993,6 +1046,14 @@ struct Ctx : CtxBase {
         const int SB = slab_stride(g.kp);
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
+            const int lct = lds_ct_m2();
+            if (lct >= 2) {
+                const LdsImage<T> im = lds_image(d_imgBL, nv, nx + nu);
+                const int grid = ((d.nodes + 15) / 16 + lct - 1) / lct;
+                if (lct == 3) hipLaunchKernelGGL((k_gemm_prep_m2_lds<T, 3>), dim3(grid), dim3(LDSG_THREADS), lds_bytes_m2(3), stream, g, im, a, SB, lds_ring_slot(nv));
+                else hipLaunchKernelGGL((k_gemm_prep_m2_lds<T, 2>), dim3(grid), dim3(LDSG_THREADS), lds_bytes_m2(2), stream, g, im, a, SB, lds_ring_slot(nv));
+                return;
+            }
             const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
             if (few_slabs()) hipLaunchKernelGGL((k_gemm_prep_m2<T, true>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
             else hipLaunchKernelGGL((k_gemm_prep_m2<T, false>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
@@ -1067,7 +1128,19 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nSlabs = (d.nodes + 15) / 16;
-            // more slabs than CUs: one workgroup per CU with CT slabs each, every A fragment used CT times (k_gemm_vlv_wide)
+            // more slabs than CUs: the LDS-staged form (loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)
+            if (foldRoot != 2) {
+                const int lct = lds_ct_vlv();
+                if (lct >= 2) {
+                    const LdsImage<T> imV = lds_image(d_imgRT, nv, nv + nx), imL = lds_image(d_imgLBL, nu + nx, nv);
+                    const int grid = (nSlabs + lct - 1) / lct;
+                    const size_t bytes = lds_bytes_vlv(lct);
+                    if (lct == 3) hipLaunchKernelGGL((k_gemm_vlv_lds<T, 3>), dim3(grid), dim3(LDSG_THREADS), bytes, stream, gV, gL, imV, imL, SB, SV, lds_ring_slot(nv), lds_ring_slot(nu + nx), a, foldRoot);
+                    else hipLaunchKernelGGL((k_gemm_vlv_lds<T, 2>), dim3(grid), dim3(LDSG_THREADS), bytes, stream, gV, gL, imV, imL, SB, SV, lds_ring_slot(nv), lds_ring_slot(nu + nx), a, foldRoot);
+                    return;
+                }
+            }
+            // ... or one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
             const int ct = wide_ct(nSlabs, lds);
             if (ct >= 2 && foldRoot != 2) {
                 const int grid = (nSlabs + ct - 1) / ct, threads = 64 * wide_waves();
@@ -2042,66 +2115,54 @@ struct Ctx : CtxBase {
     }
 
     // ---- multi-GPU ---------------------------------------------------------------------------------------
-    // The communicator of this context.  ncclCommInitRank blocks until every rank of the id has arrived -- for ever if one never does --
-    // so it is created NON-BLOCKING (ncclCommInitRankConfig, blocking = 0) and polled against the wall clock: after `timeoutSeconds`
-    // (< 0: $RAPIDNET_COMM_TIMEOUT_S, default 120) the half-made communicator is aborted and the call returns RN_E_COMM; the context
-    // itself stays usable, without a communicator (the reference would exit(), Configuration.h:38-81; this must neither exit nor hang).
-    // A non-blocking communicator may answer ncclInProgress to a later call as well (the first collective connects the channels on a
-    // helper thread): all_reduce() waits such a call out before anything else is put on the stream.  $RAPIDNET_COMM_BLOCKING=1 (or an
-    // RCCL without the config entry point) takes the plain blocking ncclCommInitRank.
-    bool commNonblocking = false;
+    // The communicator of this context.  ncclCommInitRank blocks until every rank of the id has arrived -- for ever if one never does.
+    // It therefore runs on a HELPER THREAD and the caller waits for it against the wall clock: after `timeoutSeconds` (< 0:
+    // $RAPIDNET_COMM_TIMEOUT_S, default 120) the call returns RN_E_COMM and the context stays usable, without a communicator (the
+    // reference would exit(), Configuration.h:38-81; this must neither exit nor hang).  The abandoned helper stays blocked inside RCCL
+    // for as long as RCCL waits (it holds only its own copies of the arguments); should it ever come back with a communicator, it
+    // destroys it.  (First form, round 5: ncclCommInitRankConfig with blocking = 0, polled with ncclCommGetAsyncError and aborted on
+    // time-out -- on the one-GPU box a rank of a two-rank id never came back from that sequence, tests/test_gpu_comm_timeout.py; the
+    // blocking call is also the one every earlier multi-process rehearsal used.)
     double commTimeoutS = 120.0;
-    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    int comm_wait(void *c, int rc, double limitS, bool *timedOut) {   // waits out ncclInProgress; returns the final ncclResult_t
-        *timedOut = false;
-        const double t0 = now_s();
-        while (rc == NCCL_IN_PROGRESS) {
-            int st = 0;
-            const int q = g_nccl.GetAsyncError(c, &st);
-            if (q != 0) return q;
-            if (st != NCCL_IN_PROGRESS) return st;
-            if (now_s() - t0 > limitS) { *timedOut = true; return NCCL_IN_PROGRESS; }
-            std::this_thread::sleep_for(std::chrono::microseconds(500));
-        }
-        return rc;
-    }
+    struct CommJob { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; int rc = -1; void *comm = nullptr; };
     int comm_init(int rk, int nr, const void *id, double timeoutSeconds = -1.0) override {
         RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
         RN_CHECK(comm == nullptr, RN_E_STATE, "rn_comm_init: the context already has a communicator");
-        rank = rk; nranks = nr;
-        optHold = 0;                       // every rank starts its batches aligned (the back-off counter decides which path a batch takes)
-        if (id == nullptr) return RN_OK;   // id == NULL: bookkeeping only (tests emulate the exchange)
+        if (id == nullptr) {               // id == NULL: bookkeeping only (tests emulate the exchange)
+            rank = rk; nranks = nr; optHold = 0;
+            return RN_OK;
+        }
         RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
         RN_HIP(hipSetDevice(device));
         if (timeoutSeconds < 0) { timeoutSeconds = 120.0; if (const char *e = std::getenv("RAPIDNET_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) timeoutSeconds = v; } }
         commTimeoutS = timeoutSeconds;
         UniqueId128 u; std::memcpy(u.b, id, 128);
-        bool legacy = !(RN_HAVE_RCCL_CONFIG && g_nccl.InitRankConfig && g_nccl.GetAsyncError && g_nccl.CommAbort);
-        if (const char *e = std::getenv("RAPIDNET_COMM_BLOCKING")) { if (std::atoi(e) != 0) legacy = true; }
-        if (legacy) {
-            const int rc = g_nccl.InitRank(&comm, nr, u, rk);
-            if (rc != 0) comm = nullptr;
-            RN_CHECK(rc == 0, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
-            commNonblocking = false;
-            return RN_OK;
+        auto job = std::make_shared<CommJob>();
+        const int dev = device;
+        std::thread([job, u, nr, rk, dev] {
+            void *c = nullptr;
+            int rc = hipSetDevice(dev) == hipSuccess ? g_nccl.InitRank(&c, nr, u, rk) : -2;
+            std::unique_lock<std::mutex> lk(job->m);
+            job->rc = rc; job->comm = rc == 0 ? c : nullptr; job->done = true;
+            const bool orphan = job->abandoned;
+            lk.unlock();
+            job->cv.notify_all();
+            if (orphan && rc == 0 && c) { if (g_nccl.CommAbort) (void)g_nccl.CommAbort(c); else if (g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c); }
+        }).detach();
+        {
+            std::unique_lock<std::mutex> lk(job->m);
+            if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeoutSeconds), [&] { return job->done; })) {
+                job->abandoned = true;
+                char b[256];
+                snprintf(b, sizeof b, "ncclCommInitRank failed: rank %d of %d waited %.1f s for its peers (time-out; the context has no communicator)", rk, nr, timeoutSeconds);
+                err = b;
+                return RN_E_COMM;
+            }
         }
-#if RN_HAVE_RCCL_CONFIG
-        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-        cfg.blocking = 0;
-        void *c = nullptr;
-        bool timedOut = false;
-        int rc = g_nccl.InitRankConfig(&c, nr, u, rk, &cfg);
-        if (c != nullptr) rc = comm_wait(c, rc, timeoutSeconds, &timedOut);
-        if (rc != 0 || timedOut) {
-            if (c != nullptr) (void)g_nccl.CommAbort(c);      // allowed on a communicator whose set-up is still in progress
-            char b[256];
-            if (timedOut) snprintf(b, sizeof b, "ncclCommInitRank failed: rank %d of %d waited %.1f s for its peers (time-out; the context has no communicator)", rk, nr, timeoutSeconds);
-            else snprintf(b, sizeof b, "ncclCommInitRank failed: %s", g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?");
-            err = b;
-            return RN_E_COMM;
-        }
-        comm = c; commNonblocking = true;
-#endif
+        RN_CHECK(job->rc == 0 && job->comm, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (job->rc == -2 ? "hipSetDevice on the helper thread" : (g_nccl.GetErrorString ? g_nccl.GetErrorString(job->rc) : "?")));
+        comm = job->comm;
+        rank = rk; nranks = nr;
+        optHold = 0;                       // every rank starts its batches aligned (the back-off counter decides which path a batch takes)
         return RN_OK;
     }
     // asynchronous errors of the communicator (a peer that died, a link that went down): asked once per batch, never inside one

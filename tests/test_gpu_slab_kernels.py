@@ -1,6 +1,7 @@
-"""The shared-operator products v = m1 - RT [s; kappa] / (2p) and [L v; B L v] have three forms: k_gemm_vlv with the
-software-pipelined MFMA loop (at most one slab workgroup per CU, and fp32), k_gemm_vlv with the lean loop (more slabs than
-CUs) and k_gemm_vlv_wide (2 or 3 slabs per workgroup, every operator fragment used for all of them: many slabs per CU).
+"""The shared-operator products v = m1 - RT [s; kappa] / (2p) and [L v; B L v] have four forms: k_gemm_vlv with the
+software-pipelined MFMA loop (at most one slab workgroup per CU, and fp32), k_gemm_vlv with the lean loop, k_gemm_vlv_wide
+(2 or 3 slabs per workgroup, every operator fragment used for all of them) and -- round 5, the default for launches with more slabs
+than CUs -- k_gemm_vlv_lds / k_gemm_prep_m2_lds (operator chunks copied into an LDS ring by loader waves, A and B fragments from LDS).
 Which one a context takes is decided by the tree's size; every output element is the same chain of MFMAs over k in all of
 them, so forcing the wide kernel on a small tree must reproduce the default bit for bit.  (The lean loop and the wide kernel
 at their own sizes are covered by the full-size tests: tests/test_gpu_fullsize.py, tests/test_gpu_baseline_configs.py.)"""
@@ -34,6 +35,23 @@ def test_wide_slab_kernel_is_bitwise_the_default(monkeypatch, name, structured, 
     monkeypatch.delenv("RAPIDNET_VLV_WIDE", raising=False)
     h0, o0, _ = run(p, structured, precision)
     monkeypatch.setenv("RAPIDNET_VLV_WIDE", str(ct))     # read when a context launches its first sweep
+    h1, o1, _ = run(p, structured, precision)
+    assert np.array_equal(h0, h1)
+    for b in BUFS:
+        assert np.array_equal(o0[b], o1[b]), b
+
+
+@pytest.mark.parametrize("name,structured,precision", [("medium", False, "f64"), ("medium", True, "f64"), ("ragged", False, "f64"),
+                                                       ("barcelona31", False, "f64"), ("barcelona31", True, "f64"), ("medium", False, "f32"),
+                                                       ("wide16", False, "f32"), ("wide16", True, "f32")])
+def test_lds_staged_slab_kernels_are_bitwise_the_default(monkeypatch, name, structured, precision):
+    """RAPIDNET_SLAB_LDS=1 forces the LDS-staged products on trees that would not take them by themselves (fewer slabs than CUs):
+    same chain of MFMAs over k for every output element => the same bits.  wide16: operators of 20 and 35 row tiles -- several
+    passes of 16 tiles, MFMA waves with two tiles each, the second tile's epilogue operands fetched late."""
+    p = synth.make_problem(name)
+    monkeypatch.setenv("RAPIDNET_SLAB_LDS", "0")
+    h0, o0, _ = run(p, structured, precision)
+    monkeypatch.setenv("RAPIDNET_SLAB_LDS", "1")
     h1, o1, _ = run(p, structured, precision)
     assert np.array_equal(h0, h1)
     for b in BUFS:
