@@ -2044,6 +2044,173 @@ __global__ void __launch_bounds__(LDSG_THREADS) k_gemm_prep_m2_lds(GemmArgs<T> g
 }
 
 // ------------------------------------------------------------------------------------------------------
+// REGISTER-RESIDENT form of the shared-operator products, for launches with more slabs than CUs (round 5).  The shared operators are
+// tiny -- RT: 7 row tiles x 160 columns, [L; BL]: 12 row tiles x 97 columns on the Barcelona network -- and every slab multiplies the
+// SAME operator: one 16-row tile over the full K is 40 (25) fp64 values per lane in the MFMA's A layout.  So a wave loads its tiles
+// ONCE -- FOUR waves, one per SIMD, each with the SIMD's whole register file to itself (512 per lane, arch + accumulation registers:
+// MFMA operands may live in either): wave w keeps RT's tiles w, w + 4 (160 registers) and [L; BL]'s tiles w, w + 4, w + 8 (150) --
+// and the workgroup, one per CU and PERSISTENT, walks the slabs blockIdx,
+// blockIdx + gridDim, ...: per slab two barriers and nothing but LDS reads (the slab's [s; kappa], then its v) between the MFMAs.  No
+// operator byte crosses the L2 in steady state (k_gemm_vlv re-reads 297 KB per slab: 200 MB per launch, and waits for it a third of
+// its time: profiles/r05_sq_counters.json), no barrier per K-chunk (the LDS-staged form above: slower than the L2-fed kernel).
+// The next slab's input is requested into registers before the current slab's MFMAs and written into the other half of a
+// double-buffered slab after them.  Same chain of MFMAs over k for every output element as in k_gemm_vlv: bitwise the same results
+// (the k-steps beyond k that the padded operators carry multiply zeros and are left out).
+// KSV / KSL: k-steps (of 4) of the two products = ceil(k / 4), compile-time: the tiles live in registers.
+constexpr int REGG_WAVES = 4, REGG_THREADS = 64 * REGG_WAVES;   // one wave per SIMD: it may use the whole register file (512 per lane)
+// acc[j] += A[j] (16 x 4 KS, in registers) * B (4 KS x 16, LDS) for the NT tiles of a wave.  One wave per SIMD: nobody else covers a
+// wait, so the B fragments of group g + 1 (REGG_G k-steps) are requested before the MFMAs of group g and pinned behind them (the
+// scheduling barriers keep the compiler from sinking the requests to their first use: "request, wait, multiply" leaves the matrix
+// pipe idle for an LDS round trip per group -- measured: 34 instead of 30 us for the whole launch).  KS is a compile-time constant:
+// the loop unrolls completely, the two fragment sets are renamed, no copies.
+constexpr int REGG_G = 4;
+template <typename T, int KS, int NT>
+__device__ __forceinline__ void regg_mfma(typename Mfma16<T>::acc_t (&acc)[NT], const T (&A)[NT][KS], const T *Bp) {
+    T bc[REGG_G], bn[REGG_G];
+#pragma unroll
+    for (int i = 0; i < REGG_G; i++) bc[i] = Bp[4 * (i < KS ? i : KS - 1)];
+#pragma unroll
+    for (int g = 0; g < KS; g += REGG_G) {
+        if (g + REGG_G < KS) {
+#pragma unroll
+            for (int i = 0; i < REGG_G; i++) bn[i] = Bp[4 * (g + REGG_G + i < KS ? g + REGG_G + i : KS - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < REGG_G; i++)
+            if (g + i < KS) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[j] = Mfma16<T>::run(A[j][g + i], bc[i], acc[j]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + REGG_G < KS) {
+#pragma unroll
+            for (int i = 0; i < REGG_G; i++) { asm volatile("" ::"v"(bn[i])); bc[i] = bn[i]; }
+        }
+    }
+}
+// the slab loop's barriers: LDS traffic complete, then s_barrier -- NOT __syncthreads(), whose fence also drains the vector-memory
+// counter: the next slab's input (requested a slab ahead) and this slab's result stores would be waited for at every barrier
+__device__ __forceinline__ void regg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// REGG_TV / REGG_TL: row tiles per wave of the two operators (ceil(tiles / 4)); NST: staged input values per thread (ceil(16 k / 256))
+template <typename T, int KSV, int KSL, int NST, int REGG_TV, int REGG_TL>
+__global__ void __launch_bounds__(REGG_THREADS, 1) k_gemm_vlv_reg(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int nSlabs) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    T *sB0 = reinterpret_cast<T *>(gemm_smem);  // [2][16][SB] slabs of [s; kappa], double-buffered
+    T *sV = sB0 + (size_t)2 * 16 * SB;           // [16][SV] v of the slab, zero beyond gV.m
+    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tilesV = (gV.m + 15) / 16, tilesL = (gL.m + 15) / 16;     // <= REGG_WAVES * REGG_TV, REGG_WAVES * REGG_TL (the host checks)
+    // ---- the operator tiles of this wave, once per launch: tiles wave, wave + 4, ... (padded col-major operators: mp rows, zero beyond m and k)
+    T aV[REGG_TV][KSV], aL[REGG_TL][KSL];
+#pragma unroll
+    for (int j = 0; j < REGG_TV; j++) {
+        const int t = wave + REGG_WAVES * j;
+        const T *pV = gV.M + (size_t)(t < tilesV ? t : 0) * 16 + col + (size_t)kq * gV.mp;
+#pragma unroll
+        for (int s = 0; s < KSV; s++) aV[j][s] = pV[(size_t)(4 * s) * gV.mp];
+    }
+#pragma unroll
+    for (int j = 0; j < REGG_TL; j++) {
+        const int t = wave + REGG_WAVES * j;
+        const T *pL = gL.M + (size_t)(t < tilesL ? t : 0) * 16 + col + (size_t)kq * gL.mp;
+#pragma unroll
+        for (int s = 0; s < KSL; s++) aL[j][s] = pL[(size_t)(4 * s) * gL.mp];
+    }
+    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv): workgroup 0 owns the root's slab and takes it first
+        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 16 * SV; i += REGG_THREADS) sV[i] = (T)0;
+    // the slab's input [16 nodes][k], staged through registers: element e = tid + REGG_THREADS * j  ->  row e / kst, column e % kst
+    const int kst = gV.k;
+    T stage[NST];
+    auto stage_load = [&](int slab) {
+        const int node0 = slab * 16;
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int e = (int)threadIdx.x + REGG_THREADS * j, r = e / kst, kk = e - r * kst;
+            const bool live = slab < nSlabs && r < 16 && node0 + r < gV.nodes;
+            stage[j] = live ? gV.in[(size_t)(node0 + r) * gV.ldin + kk] : (T)0;
+        }
+    };
+    auto stage_write = [&](T *dst) {
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int e = (int)threadIdx.x + REGG_THREADS * j, r = e / kst, kk = e - r * kst;
+            if (r < 16) dst[r * SB + kk] = stage[j];
+        }
+    };
+    // (columns k .. 4 ceil(k / 4) of both slab buffers are zeroed here once; the k-steps stop there)
+    for (int i = threadIdx.x; i < 2 * 16 * 4; i += REGG_THREADS) { const int r = i >> 2, c = kst + (i & 3); if (c < SB) sB0[(size_t)r * SB + c] = (T)0; }
+    RN_KT(0);
+    stage_load((int)blockIdx.x);
+    stage_write(sB0);
+    __syncthreads();
+    RN_KT(1);
+    int it = 0;
+    for (int slab = blockIdx.x; slab < nSlabs; slab += gridDim.x, it++) {
+        const T *sB = sB0 + (size_t)(it & 1) * 16 * SB;
+        const int node = slab * 16 + col;
+        const bool nodeOk = node < gV.nodes;
+        const int nodeC = nodeOk ? node : gV.nodes - 1;
+        stage_load(slab + (int)gridDim.x);        // the next slab's input: in flight behind this slab's MFMAs
+        // ---- v = m1 - RT [s; kappa] / (2 p)
+        {
+            T auxv[REGG_TV][4];
+            const T scale = (T)(-0.5) / gV.prob[nodeC];
+#pragma unroll
+            for (int j = 0; j < REGG_TV; j++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
+                    auxv[j][reg] = gemm_aux<T, EPI_V>(gV, nodeC, gr < gV.m ? gr : gV.m - 1);
+                }
+            acc_t acc[REGG_TV];
+#pragma unroll
+            for (int j = 0; j < REGG_TV; j++) acc[j] = acc_t{0, 0, 0, 0};
+            regg_mfma<T, KSV, REGG_TV>(acc, aV, sB + (size_t)col * SB + kq);     // (tiles past the end multiply tile 0 again: dropped below)
+            if (it < 3) RN_KT(2 + 4 * it);
+#pragma unroll
+            for (int j = 0; j < REGG_TV; j++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
+                    const T r = auxv[j][reg] + scale * acc[j][reg];
+                    if (wave + REGG_WAVES * j < tilesV && gr < gV.m) {
+                        if (gV.out && nodeOk) gV.out[(size_t)node * gV.ldout + gr] = r;
+                        sV[(size_t)col * SV + gr] = nodeOk ? r : (T)0;
+                    }
+                }
+        }
+        regg_barrier();                          // v of the slab is complete in sV
+        if (it < 3) RN_KT(3 + 4 * it);
+        // ---- [L v ; B L v]
+        {
+            acc_t acc[REGG_TL];
+#pragma unroll
+            for (int j = 0; j < REGG_TL; j++) acc[j] = acc_t{0, 0, 0, 0};
+            regg_mfma<T, KSL, REGG_TL>(acc, aL, sV + (size_t)col * SV + kq);
+            if (it < 3) RN_KT(4 + 4 * it);
+            if (nodeOk) {
+#pragma unroll
+                for (int j = 0; j < REGG_TL; j++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
+                        if (wave + REGG_WAVES * j < tilesL && gr < gL.m) gL.out[(size_t)node * gL.ldout + gr] = acc[j][reg];
+                    }
+            }
+        }
+        stage_write(sB0 + (size_t)((it + 1) & 1) * 16 * SB);
+        regg_barrier();                          // the next slab's input is in place; sV may be overwritten
+        if (it < 3) RN_KT(5 + 4 * it);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
 // Utilities.cu:142-155) and the diagonal Hx products (:744-747):
 //   u_i = uhat_i + (u_anc - uhat_anc) + L v_i        root: (prevU - prevUhat)

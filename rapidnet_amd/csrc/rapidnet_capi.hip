@@ -538,6 +538,30 @@ struct Ctx : CtxBase {
     }
     LdsImage<T> lds_image(const T *img, int m, int k) const { return LdsImage<T>{img, (m + 15) / 16, pad4(k) / LDSG_KC}; }
     static int lds_ring_slot(int m) { return LDSG_KC * ldsg_ldm(ldsg_pass_tiles((m + 15) / 16, 0)); }      // values; pass 0 is the tallest
+    // The register-resident persistent form of the v / Lv products (k_gemm_vlv_reg) is instantiated for the operators of the Barcelona
+    // network -- RT: 97 x 160 (7 row tiles, 40 k-steps), [L; BL]: 177 x 97 (12 row tiles, 25 k-steps): BASELINE.json configs 1-3 -- and
+    // was meant for launches with more slabs than CUs (each workgroup then walks 2-3 slabs with its tiles loaded once).
+    int regVlv = -1;
+    bool reg_want(int nSlabs) {
+        if (regVlv < 0) {
+            int force = -1;
+            if (const char *e = std::getenv("RAPIDNET_SLAB_REG")) force = std::atoi(e);   // A/B runs and tests: 0 off, 1 on whenever the shape fits
+            const bool shape = d.nv == 97 && d.nx == 63 && d.nu == 114;
+            const int SB = slab_stride(pad4(d.nv + d.nx)), SV = slab_stride(pad4(d.nv));
+            const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
+            regVlv = 0;
+            // OPT-IN (round 5): measured 31.7-34 against 30.2 us on the 493-scenario tree (same box, profiles/r05_ab_slab_reg.txt).  In-kernel
+            // stamps (profiles/r05_ktiming_slab_reg.txt): 679 slabs on 256 persistent workgroups are 3 slabs for two thirds of them (2.65 on
+            // average: the L2-fed kernel's 679 small workgroups balance themselves); the v product runs at 2/3 of the matrix pipe's rate with
+            // two accumulation chains per wave (its tiles come out of the accumulation registers through v_accvgpr_read), the [Lv; BLv]
+            // product at the full rate; and with ONE wave per SIMD nothing covers the epilogues and barriers (1.4 us per slab).
+            if (shape && force > 0 &&
+                (bytes <= 64 * 1024 || hipFuncSetAttribute((const void *)k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess))
+                regVlv = 1;
+            else (void)hipGetLastError();
+        }
+        return regVlv == 1;
+    }
     // Slabs per workgroup of the LDS-staged products (0: the L2-fed kernels run).  They pay when a launch has more slabs than CUs --
     // there the shared operators' fragments, re-read from L2 per slab and wave, set the pace (kernels.hpp) -- and need one
     // workgroup's LDS to hold CT slabs of both vectors and the two-slot ring: the largest CT <= 3 that fits 160 KB.
@@ -1128,7 +1152,16 @@ struct Ctx : CtxBase {
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
             const int nSlabs = (d.nodes + 15) / 16;
-            // more slabs than CUs: the LDS-staged form (loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)
+            // more slabs than CUs, Barcelona-shaped operators: the register-resident persistent form (every wave keeps its operator tiles in
+            // registers for the whole launch; kernels.hpp, k_gemm_vlv_reg)
+            if (foldRoot != 2 && reg_want(nSlabs)) {
+                int grid = std::min(nSlabs, numCUs);
+                if (const char *e = std::getenv("RAPIDNET_SLAB_REG_GRID")) { const int g = std::atoi(e); if (g > 0) grid = std::min(grid, g); }   // tests: several slabs per workgroup on a small tree
+                const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
+                hipLaunchKernelGGL((k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>), dim3(grid), dim3(REGG_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs);
+                return;
+            }
+            // ... or the LDS-staged form (opt-in: loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)
             if (foldRoot != 2) {
                 const int lct = lds_ct_vlv();
                 if (lct >= 2) {

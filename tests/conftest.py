@@ -71,3 +71,75 @@ def pytest_sessionstart(session):
 def pytest_sessionfinish(session, exitstatus):
     if _progress["stop"] is not None:
         _progress["stop"].set()
+
+
+# ---- the full-size oracle run, behind the other tests ----------------------------------------------------------------------------
+# tests/test_gpu_fullsize.py::test_500_iterations_against_the_oracle_at_full_size needs the CPU oracle's 500 iterations on the
+# 10 864-node tree: ~0.2 s each on one host core, 100 s in which the GPU has nothing to do.  When that test is part of the session,
+# the oracle's run starts on a background thread as soon as the tests are collected (its C code runs without the GIL; every Oracle
+# instance owns its state) and the test collects the snapshots -- iterates after 2, 100 and 500 iterations, the affine terms, two
+# operators at four nodes, the primal-infeasibility history -- when it gets there.  Same oracle, same inputs, same comparisons.
+class _FullSizeOracle:
+    NAME = "barcelona493"
+    VECS = ("x", "u", "v", "updXi", "updPsi", "dualXi", "resPsi", "primalPsi", "accPsi")
+
+    def __init__(self):
+        self.thread, self.snap, self.error, self.problem = None, None, None, None
+
+    def start(self):
+        import threading
+
+        from oracle.oracle import Oracle
+        from rapidnet_amd import synth
+
+        p = synth.make_problem(self.NAME)
+        dh, ah = synth.forecast_at(p["forecast"], 0)
+        self.problem = (p, (dh, ah))
+        o = Oracle(p["network"], p["tree"], p["config"])      # created on the main thread (the aliasing switch of the C file is process-wide)
+
+        def run():
+            try:
+                o.initialise(dh, ah)
+                snap = {"static": {nm: o.get(nm) for nm in ("uhat", "e", "beta", "xmax", "umax")}, "dims": (o.nv, o.nx, o.nu, o.nodes)}
+                nv, nx, nu = o.nv, o.nx, o.nu
+                phi, ftil = o.get("Phi").reshape(-1, nv * 2 * nx), o.get("Ftil").reshape(-1, nv * nu)
+                snap["ops"] = {n: (phi[n].copy(), ftil[n].copy()) for n in (0, 5, 4000, o.nodes - 1)}
+                del phi, ftil
+                snap["hist2"] = o.apg(2)
+                snap[2] = {nm: o.get(nm) for nm in self.VECS}
+                o.apg_reset()
+                th, hist, done = [1.0, 1.0], [], 0
+                for total in (100, 500):
+                    for _ in range(total - done):
+                        th = o.apg_continue(1, th)
+                        hist.append(o.primal_infeasibility())
+                    done = total
+                    snap[total] = {nm: o.get(nm) for nm in self.VECS}
+                snap["hist"] = hist
+                self.snap = snap
+            except BaseException as e:   # noqa: BLE001 -- handed to the test
+                self.error = e
+
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def result(self):
+        if self.thread is None:
+            self.start()
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.problem, self.snap
+
+
+_fullsize_oracle = _FullSizeOracle()
+
+
+def pytest_collection_finish(session):
+    if any("test_500_iterations_against_the_oracle_at_full_size" in item.nodeid for item in session.items) and not session.config.option.collectonly:
+        _fullsize_oracle.start()
+
+
+@pytest.fixture(scope="session")
+def fullsize_oracle():
+    return _fullsize_oracle.result()

@@ -77,45 +77,40 @@ def test_sweep_is_affine_in_the_dual(problem):
     s.close()
 
 
-def test_500_iterations_against_the_oracle_at_full_size(problem):
-    from oracle.oracle import Oracle
-
-    p, (dh, ah) = problem
-    o = Oracle(p["network"], p["tree"], p["config"])
-    o.initialise(dh, ah)
-    oh = o.apg(2)
+def test_500_iterations_against_the_oracle_at_full_size(fullsize_oracle):
+    """The oracle's side -- factor step, affine terms, 2 and then 100 / 500 iterations on one host core, ~100 s -- has been running on
+    a background thread since the session started (tests/conftest.py: _FullSizeOracle); this test runs the GPU's side and compares."""
+    problem, snap = fullsize_oracle
     s = _solver(problem, False)
     for bid, nm in ((capi.BUF_UHAT, "uhat"), (capi.BUF_E, "e"), (capi.BUF_BETA, "beta"), (capi.BUF_XMAX, "xmax"), (capi.BUF_UMAX, "umax")):
-        assert relmax(s.get(bid), o.get(nm)) < 1e-12, nm
-    nv, nx, nu = o.nv, o.nx, o.nu
-    for node in (0, 5, 4000, o.nodes - 1):
-        assert relmax(s.getOperator(capi.OP_PHI, node), o.get("Phi").reshape(-1, nv * 2 * nx)[node]) < 1e-11
-        assert relmax(s.getOperator(capi.OP_F, node), o.get("Ftil").reshape(-1, nv * nu)[node]) < 1e-11
+        assert relmax(s.get(bid), snap["static"][nm]) < 1e-12, nm
+    for node, (phi, ftil) in snap["ops"].items():
+        assert relmax(s.getOperator(capi.OP_PHI, node), phi) < 1e-11
+        assert relmax(s.getOperator(capi.OP_F, node), ftil) < 1e-11
     h = s.algorithmApg(2)
     for bid, nm in ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_V, "v"), (capi.BUF_UPD_XI, "updXi"), (capi.BUF_UPD_PSI, "updPsi"),
                     (capi.BUF_DUAL_XI, "dualXi"), (capi.BUF_RES_PSI, "resPsi")):
-        assert relmax(s.get(bid), o.get(nm)) < 1e-9, nm
+        assert relmax(s.get(bid), snap[2][nm]) < 1e-9, nm
+    oh = snap["hist2"]
     assert np.abs(h - oh).max() <= 1e-9 * np.abs(oh).max()
     # ... and the reference's 500 iterations (SmpcController.cu:1500-1525), checked at 100 and at 500: north_star's bound is 1e-8
-    # relative on the iterates; device-resident batches on the GPU, the same counts on the CPU (~0.21 s per iteration)
-    o.apg_reset(); s.apgReset()
-    th, oh2, h2, done = [1.0, 1.0], [], [], 0
+    # relative on the iterates; device-resident batches on the GPU, the same counts on the CPU
+    s.apgReset()
+    h2, done = [], 0
     for total in (100, 500):
-        for _ in range(total - done):
-            th = o.apg_continue(1, th)
-            oh2.append(o.primal_infeasibility())
         h2.append(s.apgIterate(total - done)); done = total
+        o = snap[total]
         worst = {}
         for bid, nm in ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_V, "v"), (capi.BUF_UPD_XI, "updXi"), (capi.BUF_UPD_PSI, "updPsi"),
                         (capi.BUF_DUAL_XI, "dualXi")):
-            worst[nm] = relmax(s.get(bid), o.get(nm))
+            worst[nm] = relmax(s.get(bid), o[nm])
         # the residual Hx - z = Hx - proj(Hx + w / lambda) goes to zero with the iteration: its error is measured on the scale of
         # the projection's argument (an error of 1e-10 |w| in the dual is 1e-10 |w| / lambda in the residual)
-        hx_scale = max(np.abs(o.get("primalPsi")).max(), np.abs(o.get("accPsi")).max() / p_step(problem))
-        worst["resPsi"] = float(np.abs(s.get(capi.BUF_RES_PSI) - o.get("resPsi")).max() / hx_scale)
+        hx_scale = max(np.abs(o["primalPsi"]).max(), np.abs(o["accPsi"]).max() / p_step(problem))
+        worst["resPsi"] = float(np.abs(s.get(capi.BUF_RES_PSI) - o["resPsi"]).max() / hx_scale)
         print("full size, %d iterations, max relative difference to the oracle:" % total, {k: "%.1e" % v for k, v in worst.items()})
         assert max(worst.values()) < 1e-8, (total, worst)
-    oh2, h2 = np.array(oh2), np.concatenate(h2)
+    oh2, h2 = np.array(snap["hist"]), np.concatenate(h2)
     assert np.abs(h2 - oh2).max() <= 1e-8 * max(np.abs(oh2).max(), hx_scale)
     s.close()
 
