@@ -1164,7 +1164,7 @@ def main():
         entry = {"workload": w, "dtype": prec_w}
         try:
             beat("problem data (%s)" % w)
-            pw = problem if w == args.workload else synth.make_problem(w)
+            pw = synth.make_problem(w)      # (always fresh: the headline's control steps have advanced currentX / prevU of `problem` in place)
             cut_w = capi.default_cut_stage(pw["tree"]) if sharded else -1
             r = run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=min(args.repeats, 4), problem=pw, tree=pw["tree"],
                          precision=prec_w, workload=w, control_step=False, cut_stage=cut_w, fatal=False)
@@ -1181,8 +1181,7 @@ def main():
                 beat("CPU baseline (%s)%s" % (w, "" if rank == 0 else ": waiting for rank 0"), 1300.0)   # every rank: the others wait in the next collective
             if rank == 0 and not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, pw, prec_w, min(args.cpu_iterations, 8), sample_levels=1)
-            if pw is not problem:
-                del pw
+            del pw
         except AgreedFailure as e:   # every rank raised it together: reported, the run goes on
             entry["error"] = "AgreedFailure: %s" % e
         except Exception as e:   # a config that does not fit this device / host is reported, not fatal for the headline

@@ -1,6 +1,6 @@
 """Times the global-FBE / NAMA loops (rn_algorithm_fbe_nama) on a synthetic workload; prints one JSON line per run.
 
-usage: python tools/time_fbe_nama.py [workload] [iterations]     (default: barcelona493 30)
+usage: python tools/time_fbe_nama.py [workload] [iterations] [f64|f32]     (default: barcelona493 30 f64)
 Not a bench.py line (the headline metric is APG iterations/s); the numbers go into DESIGN.md.
 """
 import json
@@ -14,11 +14,12 @@ from rapidnet_amd import capi, synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "barcelona493"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+precision = sys.argv[3] if len(sys.argv) > 3 else "f64"
 p = synth.make_problem(name)
 dh, ah = synth.forecast_at(p["forecast"], 0)
 for structured in (False, True):
     for alg in ("proximalAlgorithm", "globalFbeAlgorithm", "namaAlgorithm"):
-        s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured)
+        s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision)
         s.initialiseSmpcController(dh, ah)
         if alg == "proximalAlgorithm":
             s.algorithmApg(5); s.synchronize()
@@ -31,6 +32,6 @@ for structured in (False, True):
             t = time.perf_counter(); h, v, tau = run(iters); dt = time.perf_counter() - t
             trials = [1 + {1.0: 0}.get(x, 0) for x in tau]
             extra = {"tau": [float(x) for x in tau[:12]], "value_first_last": [float(v[0]), float(v[-1])], "line_searches": s.fbeCounters()}
-        print(json.dumps({"workload": name, "structured": structured, "algorithm": alg, "iterations": iters,
+        print(json.dumps({"workload": name, "precision": precision, "structured": structured, "algorithm": alg, "iterations": iters,
                           "ms_per_iteration": 1e3 * dt / iters, "primal_inf_first_last": [float(h[0]), float(h[-1])], **extra}))
         s.close()
