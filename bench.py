@@ -302,7 +302,7 @@ def supervise(args):
     printed = [False]
     line_path = _line_file(world)
     flag_path = "/tmp/rapidnet_bench_%s" % _job_tag()       # + ".headline": rank 0 has a line; + ".alt": rank 0's decision on step 2
-    lock = threading.Lock()
+    lock = threading.RLock()      # (re-entrant: the SIGTERM handler runs on the main thread, possibly inside keep / emit)
 
     def _die_with_parent():                      # the worker gets SIGKILL if this process disappears without a word
         try:

@@ -2210,6 +2210,139 @@ __global__ void __launch_bounds__(REGG_THREADS, 1) k_gemm_vlv_reg(GemmArgs<T> gV
     }
 }
 
+// The same idea with EIGHT waves (two per SIMD, 256 registers each -- everything in arch registers: no copies out of the accumulation
+// file in front of the MFMAs; the partner wave of a SIMD covers a wave's epilogue, its barrier waits and the one-chain dependency of
+// the v product) and the next slab's input copied global -> LDS by global_load_lds_dwordx4 with PER-LANE source addresses (the LDS
+// image is lane-linear: position o of the padded slab [16][SB] takes its 16 bytes from row o / SB, column o % SB of the node-major
+// input, or from a page of zeros for the padding columns and the rows past the last node): no staging registers at all, three or four
+// pieces per wave and slab.  Wave w: RT's tile w (80 registers), [L; BL]'s tiles w and w + 8 (100).
+constexpr int REG8_WAVES = 8, REG8_THREADS = 64 * REG8_WAVES;
+template <typename T, int KSV, int KSL>
+__global__ void __launch_bounds__(REG8_THREADS, 2) k_gemm_vlv_reg8(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int nSlabs, const T *zeros) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+    T *sB0 = reinterpret_cast<T *>(gemm_smem);  // [2][16][SB] slabs of [s; kappa], double-buffered
+    T *sV = sB0 + (size_t)2 * 16 * SB;           // [16][SV] v of the slab, zero beyond gV.m
+    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tilesV = (gV.m + 15) / 16, tilesL = (gL.m + 15) / 16;     // <= 8, <= 16 (the host checks)
+    const bool hasV = wave < tilesV, hasL1 = wave + REG8_WAVES < tilesL;
+    T aV[1][KSV], aL[2][KSL];
+    {
+        const T *pV = gV.M + (size_t)(hasV ? wave : 0) * 16 + col + (size_t)kq * gV.mp;
+#pragma unroll
+        for (int s = 0; s < KSV; s++) aV[0][s] = pV[(size_t)(4 * s) * gV.mp];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int t = wave + REG8_WAVES * j;
+            const T *pL = gL.M + (size_t)(t < tilesL ? t : 0) * 16 + col + (size_t)kq * gL.mp;
+#pragma unroll
+            for (int s = 0; s < KSL; s++) aL[j][s] = pL[(size_t)(4 * s) * gL.mp];
+        }
+    }
+    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv): workgroup 0 owns the root's slab and takes it first
+        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 16 * SV; i += REG8_THREADS) sV[i] = (T)0;
+    // one slab's input into `dst` ([16][SB]) by LDS-DMA, issued by ONE wave; the caller waits (vmcnt(0)) before the barrier that publishes it
+    constexpr int VPL = 16 / (int)sizeof(T), PIECE = 64 * VPL;          // values per lane and per wave-instruction (1 KiB)
+    const int kst = gV.k, kz = (kst + 3) & ~3;                          // columns [kst, kz) must read as zeros, [kz, SB) are never read
+    // Every wave issues the pieces wave, wave + 8, ... (one 1 KiB piece = one wave-instruction); (row, column) of a lane's group in its
+    // first piece are computed once, the step from one of its pieces to the next is wave-uniform.
+    const int r0 = (wave * PIECE + lane * VPL) / SB, c0 = wave * PIECE + lane * VPL - r0 * SB;
+    const int dr = (REG8_WAVES * PIECE) / SB, dc = REG8_WAVES * PIECE - dr * SB;
+    auto slab_dma = [&](int slab, T *dst) {
+        const int node0 = slab * 16, total = 16 * SB;
+        int r = r0, c = c0;
+        for (int p0 = wave * PIECE; p0 < total; p0 += REG8_WAVES * PIECE) {
+            if (p0 + lane * VPL < total) {
+                // a lane's VPL values lie in one row (SB % VPL == 0); they are live when the whole group is inside [0, kst) of a live row
+                const bool rowOk = slab < nSlabs && node0 + r < gV.nodes;
+                const bool live = rowOk && c + VPL <= kst;
+                const bool part = rowOk && c < kst && !live;       // the group straddles kst: element-wise below
+                const T *src = live ? gV.in + (size_t)(node0 + r) * gV.ldin + c : zeros;
+                if (!part) __builtin_amdgcn_global_load_lds((ldsg_gptr *)src, (ldsg_lptr *)(dst + p0), 16, 0, 0);
+            }
+            r += dr; c += dc;
+            if (c >= SB) { c -= SB; r++; }
+        }
+        // (groups that straddle the last column -- k not a multiple of the lane's vector -- are written element by element by wave 0)
+        if (kst % VPL && wave == 0) {
+            for (int rr = lane; rr < 16; rr += 64) {
+                const int cc0 = kst - kst % VPL;
+                for (int cc = cc0; cc < cc0 + VPL && cc < SB; cc++)
+                    dst[rr * SB + cc] = (slab < nSlabs && node0 + rr < gV.nodes && cc < kst) ? gV.in[(size_t)(node0 + rr) * gV.ldin + cc] : (T)0;
+            }
+        }
+        (void)kz;
+    };
+    RN_KT(0);
+    // Slabs of a workgroup: with the root's step folded in (foldRoot = 1), workgroup 0 takes ONLY the root's slab -- the step costs it
+    // ~5 us before its first MFMA, a third slab behind it would be the launch's critical path -- and the others share the rest
+    const bool solo = foldRoot == 1 && gridDim.x > 1;
+    const int slabStep = solo ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const int slabEnd = (solo && blockIdx.x == 0) ? 1 : nSlabs;
+    slab_dma((int)blockIdx.x, sB0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    RN_KT(1);
+    int it = 0;
+    for (int slab = blockIdx.x; slab < slabEnd; slab += slabStep, it++) {
+        const T *sB = sB0 + (size_t)(it & 1) * 16 * SB;
+        const int node = slab * 16 + col;
+        const bool nodeOk = node < gV.nodes;
+        const int nodeC = nodeOk ? node : gV.nodes - 1;
+        slab_dma(slab + slabStep < slabEnd ? slab + slabStep : nSlabs, sB0 + (size_t)((it + 1) & 1) * 16 * SB);   // the next slab's input (3-4 pieces per wave), behind this slab's MFMAs
+        // ---- v = m1 - RT [s; kappa] / (2 p)
+        if (hasV) {
+            T auxv[4];
+            const T scale = (T)(-0.5) / gV.prob[nodeC];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = wave * 16 + Mfma16<T>::row(lane, reg);
+                auxv[reg] = gemm_aux<T, EPI_V>(gV, nodeC, gr < gV.m ? gr : gV.m - 1);
+            }
+            acc_t acc[1] = {acc_t{0, 0, 0, 0}};
+            regg_mfma<T, KSV, 1>(acc, aV, sB + (size_t)col * SB + kq);
+            if (it < 3) RN_KT(2 + 4 * it);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = wave * 16 + Mfma16<T>::row(lane, reg);
+                const T r = auxv[reg] + scale * acc[0][reg];
+                if (gr < gV.m) {
+                    if (gV.out && nodeOk) gV.out[(size_t)node * gV.ldout + gr] = r;
+                    sV[(size_t)col * SV + gr] = nodeOk ? r : (T)0;
+                }
+            }
+        }
+        regg_barrier();                          // v of the slab is complete in sV
+        if (it < 3) RN_KT(3 + 4 * it);
+        // ---- [L v ; B L v]
+        {
+            acc_t acc[2] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+            if (hasL1) regg_mfma<T, KSL, 2>(acc, aL, sV + (size_t)col * SV + kq);
+            else { acc_t a1[1] = {acc[0]}; const T (&aL0)[1][KSL] = reinterpret_cast<const T (&)[1][KSL]>(aL[0]); regg_mfma<T, KSL, 1>(a1, aL0, sV + (size_t)col * SV + kq); acc[0] = a1[0]; }
+            if (it < 3) RN_KT(4 + 4 * it);
+            // this wave's pieces of the next slab's input have landed (requested a slab-time ago; waited for HERE, in front of the result
+            // stores, so that the barrier below need not drain those)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (nodeOk) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = (wave + REG8_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
+                        if (wave + REG8_WAVES * j < tilesL && gr < gL.m) gL.out[(size_t)node * gL.ldout + gr] = acc[j][reg];
+                    }
+            }
+        }
+        regg_barrier();                          // the next slab's input is published; sV may be overwritten
+        if (it < 3) RN_KT(5 + 4 * it);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Root-to-leaf recursions of the forward sweep (SmpcController.cu:676-741 + solveChildNodesUpdate
 // Utilities.cu:142-155) and the diagonal Hx products (:744-747):

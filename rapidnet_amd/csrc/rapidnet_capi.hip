@@ -542,6 +542,7 @@ struct Ctx : CtxBase {
     // network -- RT: 97 x 160 (7 row tiles, 40 k-steps), [L; BL]: 177 x 97 (12 row tiles, 25 k-steps): BASELINE.json configs 1-3 -- and
     // was meant for launches with more slabs than CUs (each workgroup then walks 2-3 slabs with its tiles loaded once).
     int regVlv = -1;
+    T *d_zeroPage = nullptr;      // k_gemm_vlv_reg8: source of the padding columns of its LDS-DMA
     bool reg_want(int nSlabs) {
         if (regVlv < 0) {
             int force = -1;
@@ -555,12 +556,19 @@ struct Ctx : CtxBase {
             // average: the L2-fed kernel's 679 small workgroups balance themselves); the v product runs at 2/3 of the matrix pipe's rate with
             // two accumulation chains per wave (its tiles come out of the accumulation registers through v_accvgpr_read), the [Lv; BLv]
             // product at the full rate; and with ONE wave per SIMD nothing covers the epilogues and barriers (1.4 us per slab).
-            if (shape && force > 0 &&
-                (bytes <= 64 * 1024 || hipFuncSetAttribute((const void *)k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess))
-                regVlv = 1;
-            else (void)hipGetLastError();
+            // RAPIDNET_SLAB_REG: 1 = four waves with the whole register file each (k_gemm_vlv_reg); 2 = eight waves, arch registers only, the
+            // next slab's input by LDS-DMA (k_gemm_vlv_reg8): on a par with the default after three rounds of tuning (helpers 66.6-66.9
+            // against 66.2-66.5 us, profiles/r05_ab_slab_reg8.txt; per slab 6.4 us in-kernel where the matrix pipes need 4.5:
+            // profiles/r05_ktiming_slab_reg8.txt) -- not faster, so not the default
+            const void *fn = force == 2 ? (const void *)k_gemm_vlv_reg8<T, 40, 25> : (const void *)k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>;
+            if (shape && force > 0 && (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)) {
+                regVlv = force == 2 ? 2 : 1;
+                if (regVlv == 2 && !d_zeroPage) {
+                    if (dalloc(&d_zeroPage, (size_t)64) != RN_OK || hipMemset(d_zeroPage, 0, 64 * sizeof(T)) != hipSuccess) regVlv = 1;
+                }
+            } else (void)hipGetLastError();
         }
-        return regVlv == 1;
+        return regVlv >= 1;
     }
     // Slabs per workgroup of the LDS-staged products (0: the L2-fed kernels run).  They pay when a launch has more slabs than CUs --
     // there the shared operators' fragments, re-read from L2 per slab and wave, set the pace (kernels.hpp) -- and need one
@@ -1158,7 +1166,8 @@ struct Ctx : CtxBase {
                 int grid = std::min(nSlabs, numCUs);
                 if (const char *e = std::getenv("RAPIDNET_SLAB_REG_GRID")) { const int g = std::atoi(e); if (g > 0) grid = std::min(grid, g); }   // tests: several slabs per workgroup on a small tree
                 const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
-                hipLaunchKernelGGL((k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>), dim3(grid), dim3(REGG_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs);
+                if (regVlv == 2) hipLaunchKernelGGL((k_gemm_vlv_reg8<T, 40, 25>), dim3(grid), dim3(REG8_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs, (const T *)d_zeroPage);
+                else hipLaunchKernelGGL((k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>), dim3(grid), dim3(REGG_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs);
                 return;
             }
             // ... or the LDS-staged form (opt-in: loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)

@@ -61,9 +61,10 @@ def test_lds_staged_slab_kernels_are_bitwise_the_default(monkeypatch, name, stru
 synth.CONFIGS.setdefault("barcelona64", (1, 63, 114, 88, 17, 24, [8, 8]))   # the Barcelona network on 64 chains: 1 417 nodes = 89 slabs
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("name,structured,precision,grid", [("barcelona31", False, "f64", 0), ("barcelona31", True, "f64", 7), ("barcelona64", False, "f64", 7),
                                                             ("barcelona64", False, "f64", 32), ("barcelona64", False, "f32", 5)])
-def test_register_resident_slab_kernel_is_bitwise_the_default(monkeypatch, name, structured, precision, grid):
+def test_register_resident_slab_kernel_is_bitwise_the_default(monkeypatch, name, structured, precision, grid, variant):
     """k_gemm_vlv_reg (round 5: the operator tiles live in the waves' registers for the whole launch, persistent workgroups walk the
     slabs; the default on the 493-scenario tree) forced on small trees of the same network: RAPIDNET_SLAB_REG_GRID caps the grid so
     that a workgroup walks several slabs (89 slabs on 7 workgroups: 12 or 13 each, both halves of the double-buffered slab in use,
@@ -71,7 +72,7 @@ def test_register_resident_slab_kernel_is_bitwise_the_default(monkeypatch, name,
     p = synth.make_problem(name)
     monkeypatch.setenv("RAPIDNET_SLAB_REG", "0")
     h0, o0, _ = run(p, structured, precision)
-    monkeypatch.setenv("RAPIDNET_SLAB_REG", "1")
+    monkeypatch.setenv("RAPIDNET_SLAB_REG", variant)      # 1: four waves x the whole register file; 2: eight waves, LDS-DMA staging
     if grid:
         monkeypatch.setenv("RAPIDNET_SLAB_REG_GRID", str(grid))
     h1, o1, _ = run(p, structured, precision)

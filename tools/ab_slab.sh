@@ -10,7 +10,7 @@ timeout -k 10 300 python -m pytest tests/test_gpu_slab_kernels.py -x -q -k "regi
 tail -2 $O/ab_reg_tests.log
 : > $O/ab_reg.txt
 for r in $(seq 1 $R); do
-  for v in 0 1; do
+  for v in ${VARIANTS:-0 1}; do
     RAPIDNET_SLAB_REG=$v timeout -k 10 200 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-traffic --other-configs "" --profile-steps 40 --repeats 3 \
         --no-shard-ceiling --no-quasi-newton > $O/ab_reg_$v.json 2> $O/ab_reg_$v.err || { tail -5 $O/ab_reg_$v.err; exit 1; }
     python - $v $r $O/ab_reg_$v.json >> $O/ab_reg.txt <<'PY'
@@ -25,7 +25,7 @@ PY
     tail -1 $O/ab_reg.txt
   done
 done
-for v in 0 1; do
+for v in ${VARIANTS:-0 1}; do
   (cd /tmp && rm -rf /tmp/r05_ks$v && RAPIDNET_SLAB_REG=$v timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r05_ks$v -o ks -- python3 "$OLDPWD/bench.py" --steps 200 --warmup 20 \
       --no-cpu-baseline --no-traffic --other-configs "" --profile-steps 0 --repeats 0 --no-shard-ceiling --no-quasi-newton > /dev/null 2> "$OLDPWD/$O/ab_reg_ks$v.err") || { tail -5 $O/ab_reg_ks$v.err; exit 1; }
   cp $(find /tmp/r05_ks$v -name "*kernel_stats.csv" | head -1) $O/ab_reg_kernel_stats_$v.csv

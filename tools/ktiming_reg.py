@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps inside k_gemm_vlv_reg (a -DRN_KTIMING build, see kernels.hpp RN_KT): python tools/ktiming_reg.py"""
+"""Phase stamps inside k_gemm_vlv_reg / k_gemm_vlv_reg8 (a -DRN_KTIMING build, see kernels.hpp RN_KT): python tools/ktiming_reg.py [1|2]"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,7 @@ from rapidnet_amd import build  # noqa: E402
 
 build.build_hip(defines=["RN_KTIMING=1"], out=LIB)
 os.environ["RAPIDNET_LIB"] = LIB
-os.environ["RAPIDNET_SLAB_REG"] = "1"
+os.environ["RAPIDNET_SLAB_REG"] = sys.argv[1] if len(sys.argv) > 1 else "1"      # 1: k_gemm_vlv_reg, 2: k_gemm_vlv_reg8
 import numpy as np  # noqa: E402
 from rapidnet_amd import capi, synth  # noqa: E402
 

@@ -1,4 +1,4 @@
 #!/bin/bash
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/ab_slab.sh 3
+VARIANTS="${VARIANTS:-0 2}" bash tools/ab_slab.sh ${ROUNDS:-3}
