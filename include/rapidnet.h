@@ -226,6 +226,14 @@ int rn_get_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, double *hos
 int rn_set_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, const double *host);
 /* one node's operator block, reference layout (col-major, ld = nv) */
 int rn_get_operator(rn_ctx *ctx, int op_id, int node, double *host, size_t n);
+/* The raw device pointer of a buffer that the library keeps in the reference's own layout -- the counterpart of the reference's raw
+ * getters and protected device vectors for those arrays (Engine.cuh:108-318 getVecUhat / getVecBeta / getVecE / getPriceAlpha ...,
+ * SmpcController.cuh:336-462 devVecX / devVecU / devVecV): RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA, _XDIR, _UDIR, node-major
+ * [node][dim].  *precision = RN_F64 / RN_F32 (the element type is the context's), *n = element count.  The pointer stays valid until
+ * rn_destroy; its contents are those of the last call that has COMPLETED on the context's stream (rn_synchronize, or order your own
+ * work behind rn_stream).  x, u, v are stored by the last iteration of a batch and by every step-wise call.  Dual-shaped buffers
+ * (RN_BUF_XI ... RN_BUF_UMAX) and the operator blocks are kept in other layouts: RN_E_ARG, use rn_get. */
+int rn_device_pointer(rn_ctx *ctx, int buffer_id, void **devPtr, size_t *n, int *precision);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* per-kernel-class device time accumulated by hipEvents when profiling is on (costs a little; off by default).

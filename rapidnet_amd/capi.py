@@ -27,7 +27,7 @@ SYMBOLS = [
     "rn_apg_reset", "rn_apg_iterate", "rn_algorithm_apg", "rn_control_action", "rn_dual_extrapolation_step",
     "rn_solve_step", "rn_proximal_fun_g", "rn_compute_fixed_point_residual", "rn_dual_update",
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
-    "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
+    "rn_device_pointer", "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_comm_init_timeout", "rn_comm_check", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
@@ -149,6 +149,7 @@ def load():
     lib.rn_get_operator.argtypes = [vp, ip, ip, dp, C.c_size_t]
     lib.rn_get_range.argtypes = [vp, ip, C.c_size_t, C.c_size_t, dp]
     lib.rn_set_range.argtypes = [vp, ip, C.c_size_t, C.c_size_t, dp]
+    lib.rn_device_pointer.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     lib.rn_profile_enable.argtypes = [vp, ip]
     lib.rn_profile_reset.argtypes = [vp]
     lib.rn_profile_read.argtypes = [vp, dp, dp]
@@ -550,6 +551,13 @@ class Solver:
         self._check(self.lib.rn_measure_hbm_shape(self.h, int(shape), int(piece_bytes), int(stride_or_total or piece_bytes), int(n),
                                                   int(unroll), int(reps), C.addressof(r)))
         return r.value
+
+    def devicePointer(self, buffer_id):
+        """(raw device address, element count, 'f64' | 'f32') of a buffer kept in the reference's node-major layout (X, U, V, UHAT, E,
+        BETA, ALPHA, XDIR, UDIR): the counterpart of the reference's raw device getters; RapidNetError for the others (use get)."""
+        p, n, prec = C.c_void_p(), C.c_size_t(0), C.c_int(0)
+        self._check(self.lib.rn_device_pointer(self.h, int(buffer_id), C.byref(p), C.byref(n), C.byref(prec)))
+        return p.value, n.value, "f64" if prec.value == RN_F64 else "f32"
 
     def algorithmicBytes(self):
         a, b = C.c_double(0), C.c_double(0)

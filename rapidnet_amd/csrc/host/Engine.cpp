@@ -104,6 +104,21 @@ void Engine::setBuffer(int id, const real_t *host) { check(rn_set(ctx, id, host,
 void Engine::getBufferRange(int id, size_t first, size_t n, real_t *host) { check(rn_get_range(ctx, id, first, n, host), "rn_get_range"); }
 void Engine::setBufferRange(int id, size_t first, size_t n, const real_t *host) { check(rn_set_range(ctx, id, first, n, host), "rn_set_range"); }
 void Engine::getOperator(int op, uint_t node, real_t *host, size_t n) { check(rn_get_operator(ctx, op, node, host, n), "rn_get_operator"); }
+void *Engine::getDevicePointer(int bufferId, size_t *n) {
+    void *p = nullptr;
+    size_t cnt = 0;
+    int prec = 0;
+    check(rn_device_pointer(ctx, bufferId, &p, &cnt, &prec), "rn_device_pointer");
+    if (n) *n = cnt;
+    return p;
+}
+int Engine::getDevicePrecision() {
+    void *p = nullptr;
+    size_t cnt = 0;
+    int prec = 0;
+    check(rn_device_pointer(ctx, RN_BUF_UHAT, &p, &cnt, &prec), "rn_device_pointer");
+    return prec;
+}
 
 void Engine::calculateMatLandMatLhat() {
     const int ne = ptrMyNetwork->getNumMixNodes(), nu = ptrMyNetwork->getNumControls(), nd = ptrMyNetwork->getNumDemands();

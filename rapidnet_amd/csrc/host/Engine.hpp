@@ -2,8 +2,11 @@
 // The reference's Engine owns ~60 raw device arrays and hands out device pointers; here the device state lives behind
 // an opaque rn_ctx and the getters copy to the host on demand (node-major, the reference's layout):
 //   reference getter returning a device pointer        here
-//   getVecUhat() / getVecBeta() / getVecE() ...         getBuffer(RN_BUF_UHAT, host) ...
-//   getMatPhi() / getPtrMatPhi()[node] ...              getOperator(RN_OP_PHI, node, host) ...
+//   getVecUhat() / getVecBeta() / getVecE() ...         getBuffer(RN_BUF_UHAT, host) ...  -- or, for the arrays the library keeps in the
+//                                                       reference's own node-major layout, the raw device pointer under the
+//                                                       reference's name: getVecUhat(), getVecBeta(), getVecE(), getPriceAlpha()
+//                                                       (element type = the engine's precision: getDevicePrecision())
+//   getMatPhi() / getPtrMatPhi()[node] ...              getOperator(RN_OP_PHI, node, host) ...  (the blocks are stored interleaved: DESIGN.md section 4)
 #ifndef RAPIDNET_ENGINE_HPP_
 #define RAPIDNET_ENGINE_HPP_
 
@@ -59,6 +62,16 @@ public:
     void getBufferRange(int bufferId, size_t first, size_t n, real_t *host);         // elements [first, first + n) only
     void setBufferRange(int bufferId, size_t first, size_t n, const real_t *host);
     void getOperator(int opId, uint_t node, real_t *host, size_t n);
+    // Raw device pointers under the reference's names (Engine.cuh:108-318) for the arrays whose device layout IS the reference's:
+    // [node][dim], valid until the engine is destroyed, contents as of the last completed call (rn_synchronize / rn_stream).  The
+    // element type is double for RN_F64 engines (the default) and float for RN_F32 ones -- the reference's real_t is float, this
+    // host API's is double, so the pointers are untyped and getDevicePrecision() says which.
+    int getDevicePrecision();                           // RN_F64 or RN_F32
+    void *getDevicePointer(int bufferId, size_t *n = nullptr);      // RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA (others: std::logic_error)
+    void *getVecUhat() { return getDevicePointer(RN_BUF_UHAT); }   // Engine.cuh: getVecUhat
+    void *getVecBeta() { return getDevicePointer(RN_BUF_BETA); }   //             getVecBeta
+    void *getVecE() { return getDevicePointer(RN_BUF_E); }         //             getVecE
+    void *getPriceAlpha() { return getDevicePointer(RN_BUF_ALPHA); }   //         getPriceAlpha
     ~Engine();
 
 private:

@@ -141,6 +141,7 @@ struct CtxBase {
     virtual int get(int, double *, size_t) = 0;
     virtual int set(int, const double *, size_t) = 0;
     virtual int get_operator(int, int, double *, size_t) = 0;
+    virtual int device_pointer(int, void **, size_t *, int *) = 0;
     virtual int get_range(int, size_t, size_t, double *) = 0;
     virtual int set_range(int, size_t, size_t, const double *) = 0;
     virtual int profile_enable(int) = 0;
@@ -2034,6 +2035,15 @@ struct Ctx : CtxBase {
             default: *n = 0; return nullptr;
         }
     }
+    int device_pointer(int id, void **ptr, size_t *n, int *prec) override {
+        RN_CHECK(ptr && n && prec, RN_E_ARG, "rn_device_pointer: null output");
+        size_t cnt = 0;
+        T *p = plain(id, &cnt);
+        *ptr = nullptr; *n = 0; *prec = sizeof(T) == 8 ? RN_F64 : RN_F32;
+        RN_CHECK(p != nullptr && cnt > 0, RN_E_ARG, "rn_device_pointer: this buffer is not kept in the reference's layout on the device (or not allocated yet): use rn_get");
+        *ptr = p; *n = cnt;
+        return RN_OK;
+    }
     size_t buffer_size(int id) const override {
         T *b; int off, dim; size_t n;
         Ctx *self = const_cast<Ctx *>(this);
@@ -2409,6 +2419,7 @@ int rn_set(rn_ctx *ctx, int id, const double *h, size_t n) { RN_GUARD(ctx); retu
 int rn_get_range(rn_ctx *ctx, int id, size_t first, size_t n, double *h) { RN_GUARD(ctx); return ctx->impl->get_range(id, first, n, h); }
 int rn_set_range(rn_ctx *ctx, int id, size_t first, size_t n, const double *h) { RN_GUARD(ctx); return ctx->impl->set_range(id, first, n, h); }
 int rn_get_operator(rn_ctx *ctx, int op, int node, double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->get_operator(op, node, h, n); }
+int rn_device_pointer(rn_ctx *ctx, int id, void **p, size_t *n, int *prec) { RN_GUARD(ctx); return ctx->impl->device_pointer(id, p, n, prec); }
 int rn_profile_enable(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->profile_enable(on); }
 int rn_profile_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->profile_reset(); }
 int rn_profile_read(rn_ctx *ctx, double ms[4], long n[4]) { RN_GUARD(ctx); return ctx->impl->profile_read(ms, n); }

@@ -276,6 +276,19 @@ static void testEngine(const string &dir) {   // Testing::testEngineTesting
         eng.getBuffer(q.id, v.data());
         CHECK(v.size() == j[q.key].Size() && closeAbs(v.data(), j[q.key].arr.data(), v.size(), 1e-2, q.key));   // Testing.cu:62
     }
+    {   // the reference's raw getters (Engine.cuh: getVecUhat, getVecBeta, getVecE, getPriceAlpha): device pointers of arrays kept in the
+        // reference's node-major layout; an RN_F64 engine stores doubles
+        CHECK(eng.getDevicePrecision() == RN_F64);
+        size_t n = 0;
+        void *dev = eng.getDevicePointer(RN_BUF_UHAT, &n);
+        CHECK(dev != nullptr && dev == eng.getVecUhat() && n == eng.getBufferSize(RN_BUF_UHAT));
+        CHECK(eng.getVecBeta() != nullptr && eng.getVecE() != nullptr && eng.getPriceAlpha() != nullptr);
+        // (what a device-to-host copy from these pointers returns is checked through the C-ABI in tests/test_gpu_device_pointer.py:
+        //  this driver does not link the HIP runtime itself)
+        bool threw = false;
+        try { eng.getDevicePointer(RN_BUF_XI); } catch (const std::exception &) { threw = true; }    // dual-shaped: kept interleaved, no raw pointer
+        CHECK(threw);
+    }
     struct { int id; const char *key; uint_t dim; } path[] = {{RN_BUF_XMIN, "xmin", nx}, {RN_BUF_XMAX, "xmax", nx}, {RN_BUF_XS, "xs", nx},
                                                               {RN_BUF_UMIN, "umin", nu}, {RN_BUF_UMAX, "umax", nu}};
     for (auto &q : path) {   // compareDeviceScenarioArray: along one scenario (1-based node ids in "scenarioNodes")
