@@ -375,6 +375,12 @@ int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64 /* 64 bytes out */);
 int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 bytes, rank order */, int nranks);
 int rn_set_exchange_transport(rn_ctx *ctx, int transport);
+/* Overlapped exchange (opt-in; transport 0 only; measured on one GPU it LOSES 27-29 us per iteration to the two cross-stream
+ * dependencies it needs, more than the 12 us of products it can hide: DESIGN.md section 6).  Of one iteration's shared-operator products
+ * (SmpcController.cu:604-611, :692-736) only the crown's depend on the exchanged children sums; with 1 the per-iteration all-reduce
+ * runs on a stream of its own while the solver's stream multiplies the chain region's nodes, and only the crown's slabs -- and the
+ * forward walk behind them -- wait for it.  Same launches on the same data in the same order per node: identical iterates. */
+int rn_set_exchange_overlap(rn_ctx *ctx, int on);
 
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red

@@ -197,6 +197,7 @@ struct CtxBase {
     virtual int peer_inbox_connect_local(CtxBase **, int) = 0;
     virtual unsigned long long *peer_inbox_ptr() = 0;
     virtual int set_exchange_transport(int) = 0;
+    virtual int set_exchange_overlap(int) = 0;
     virtual int fbe_counters(long *) = 0;
 };
 
@@ -374,7 +375,8 @@ struct Ctx : CtxBase {
     int fullNodes = 0;
     bool has_comm() const { return comm != nullptr || arHook != nullptr; }
     // sum all-reduce, in place, on the solver's stream: the library's RCCL communicator, or the installed stand-in
-    int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */) {
+    int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */, hipStream_t on = nullptr) {
+        hipStream_t stream = on ? on : this->stream;      // (the overlapped exchange issues the per-iteration collective on a stream of its own)
         if (arHook) {
             hipEvent_t ev = prof_begin(4);
             const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, op, (void *)stream);
@@ -405,6 +407,9 @@ struct Ctx : CtxBase {
         for (void *p : ipcOpened) (void)hipIpcCloseMemHandle(p);
         if (d_inbox) (void)hipFree(d_inbox);
         for (void *p : allocs) (void)hipFree(p);
+        if (evCommFork) (void)hipEventDestroy(evCommFork);
+        if (evCommJoin) (void)hipEventDestroy(evCommJoin);
+        if (commStream) { (void)hipStreamSynchronize(commStream); (void)hipStreamDestroy(commStream); }
         if (evFork) (void)hipEventDestroy(evFork);
         if (evJoin) (void)hipEventDestroy(evJoin);
         if (stream2) (void)hipStreamDestroy(stream2);
@@ -1151,19 +1156,25 @@ struct Ctx : CtxBase {
         return nw;
     }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
-    void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
+    // [n0, n1): the nodes this launch covers (n1 < 0: all of them; n0 a multiple of 16) -- the overlapped exchange runs the products of the
+    // chain region beside the collective and the crown's slabs behind it.  A sub-range is the same kernel on shifted node-major pointers.
+    void launch_v_lv(const SweepArgs<T> &a, int foldRoot, int n0 = 0, int n1 = -1) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
+        if (n1 < 0) n1 = d.nodes;
+        const bool whole = n0 == 0 && n1 == d.nodes;
+        const int nSub = n1 - n0;
 #if RN_GEMM_SLAB
-        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk, nv + nx, a.v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk + (size_t)n0 * (nv + nx), nv + nx, a.v + (size_t)n0 * nv, nv, a.my + (size_t)n0 * 2 * nv, 2 * nv,
+                       d_prob + n0, nSub, a.my2, a.splitFirst - n0};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
-        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
+        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v + (size_t)n0 * nv, nv, a.lvb + (size_t)n0 * (nu + nx), nu + nx, nullptr, 0, d_prob + n0, nSub};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (lds <= 64 * 1024) {
-            const int nSlabs = (d.nodes + 15) / 16;
+            const int nSlabs = (nSub + 15) / 16;
             // more slabs than CUs, Barcelona-shaped operators: the register-resident persistent form (every wave keeps its operator tiles in
             // registers for the whole launch; kernels.hpp, k_gemm_vlv_reg)
-            if (foldRoot != 2 && reg_want(nSlabs)) {
+            if (whole && foldRoot != 2 && reg_want(nSlabs)) {
                 int grid = std::min(nSlabs, numCUs);
                 if (const char *e = std::getenv("RAPIDNET_SLAB_REG_GRID")) { const int g = std::atoi(e); if (g > 0) grid = std::min(grid, g); }   // tests: several slabs per workgroup on a small tree
                 const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
@@ -1172,7 +1183,7 @@ struct Ctx : CtxBase {
                 return;
             }
             // ... or the LDS-staged form (opt-in: loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)
-            if (foldRoot != 2) {
+            if (whole && foldRoot != 2) {
                 const int lct = lds_ct_vlv();
                 if (lct >= 2) {
                     const LdsImage<T> imV = lds_image(d_imgRT, nv, nv + nx), imL = lds_image(d_imgLBL, nu + nx, nv);
@@ -1184,7 +1195,7 @@ struct Ctx : CtxBase {
                 }
             }
             // ... or one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
-            const int ct = wide_ct(nSlabs, lds);
+            const int ct = whole ? wide_ct(nSlabs, lds) : 0;
             if (ct >= 2 && foldRoot != 2) {
                 const int grid = (nSlabs + ct - 1) / ct, threads = 64 * wide_waves();
                 if (ct == 2) hipLaunchKernelGGL((k_gemm_vlv_wide<T, 2>), dim3(grid), dim3(threads), lds * 2, stream, gV, gL, SB, SV, a, foldRoot);
@@ -1210,6 +1221,7 @@ struct Ctx : CtxBase {
             return;
         }
 #endif
+        (void)whole; (void)nSub;
         launch_gemm<EPI_V>(d_RTp, nv, nv + nx, a.sk, nv + nx, a.v, nv, a.my, 2 * nv);
         launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, a.v, nv, a.lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
@@ -1329,6 +1341,14 @@ struct Ctx : CtxBase {
             if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
             if (oneShot) return RN_OK;                       // the payload has gone to the peers' inboxes straight from the kernel
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
+            if (overlapNow) {   // on its own stream, behind the launch that made the payload; joined in front of the crown's slabs below
+                RN_HIP(hipEventRecord(evCommFork, stream));
+                RN_HIP(hipStreamWaitEvent(commStream, evCommFork, 0));
+                if (int rc = all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)", 0, commStream)) return rc;
+                RN_HIP(hipEventRecord(evCommJoin, commStream));
+                joinPending = true;
+                return RN_OK;
+            }
             return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
         };
         // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
@@ -1336,6 +1356,11 @@ struct Ctx : CtxBase {
         // 2: sharded with a two-stage crown whose stage 1 is the exchange stage -- its (presummed) step is folded as well
         int foldRoot = (RN_FOLD_ROOT && phase == 0 && cs >= 2 && !(a.cutSums && cutStage == 1) && v_lv_is_slab()) ? 1 : 0;
         if (foldRoot && a.cutSums && cs == 2 && cutStage == 2) foldRoot = 2;
+        // overlapped exchange: the sharded two-stage crown (what the Barcelona shards run), a real or stand-in communicator, not while every
+        // interval is being bracketed by profiling events on the one stream; the chain region's slabs start behind the crown's
+        const int crownEnd = (h_stageCum[cs] + 15) / 16 * 16;
+        overlapNow = overlapExchange && commStream && foldRoot == 2 && has_comm() && !oneShot && phase == 0 && !prof && !hessianInput && crownEnd < d.nodes;
+        joinPending = false;
         {
             const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
             const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
@@ -1351,7 +1376,12 @@ struct Ctx : CtxBase {
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
-        launch_v_lv(a, foldRoot);
+        if (joinPending) {
+            launch_v_lv(a, 0, crownEnd, d.nodes);                 // the chain region: beside the collective
+            RN_HIP(hipStreamWaitEvent(stream, evCommJoin, 0));
+            launch_v_lv(a, 2, 0, crownEnd);                       // the crown's steps and slabs: behind it
+            joinPending = false;
+        } else launch_v_lv(a, foldRoot);
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
         // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch.
         // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
@@ -1684,6 +1714,27 @@ struct Ctx : CtxBase {
     std::vector<void *> ipcOpened;
     bool peerReady = false, inBatch = false;
     int transport = 0;            // 0: the cut payload is all-reduced by the collective; 1: one-shot peer writes (inside rn_apg_iterate batches)
+    // Overlapped exchange (rn_set_exchange_overlap; OPT-IN and, as measured on one GPU, a loss: the two cross-stream dependencies and the
+    // extra launch cost 27-29 us per iteration -- 0.1339 -> 0.1608 ms on a 1/8 shard with a one-rank communicator,
+    // profiles/r05_exchange_overlap_one_gpu.txt -- where the products it can hide behind the collective take 12 us): the v / Lv products of the chain region
+    // do not depend on the exchange -- only the crown's steps and, through them, the forward walk do (SmpcController.cu:604-611 are
+    // per-node products; the children sums of :644-672 enter at the cut parents) -- so the per-iteration collective runs on a stream of
+    // its own while the solver's stream multiplies the chain region's slabs, and only the crown's two slabs wait for it.
+    int overlapExchange = 0;
+    bool overlapNow = false, joinPending = false;      // state of the sweep being enqueued
+    hipStream_t commStream = nullptr;
+    hipEvent_t evCommFork = nullptr, evCommJoin = nullptr;
+    int set_exchange_overlap(int on) override {
+        RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_exchange_overlap: 0 or 1");
+        if (on && !commStream) {
+            RN_HIP(hipSetDevice(device));
+            RN_HIP(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking));
+            RN_HIP(hipEventCreateWithFlags(&evCommFork, hipEventDisableTiming));
+            RN_HIP(hipEventCreateWithFlags(&evCommJoin, hipEventDisableTiming));
+        }
+        overlapExchange = on;
+        return RN_OK;
+    }
     unsigned int peerSeq = 0;     // sequence number of the last one-shot exchange (the same on every rank: they issue the same exchanges)
     unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }
     int peer_inbox_create(void *handle64) override {
@@ -2538,6 +2589,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
     return RN_OK;
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
+int rn_set_exchange_overlap(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_exchange_overlap(on); }
 int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
