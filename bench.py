@@ -559,7 +559,7 @@ def shard_ceiling(problem, device, steps, unsharded_ms, profile_steps=40):
     n_it = max(int(steps), 100)
     rows = []
     for W in (2, 4, 8):
-        row = {"world": W}
+        row, s = {"world": W}, None
         try:
             part = capi.partition_tree(problem["tree"], 0, W, cut)
             s = capi.Solver(problem["network"], part["tree"], problem["config"], precision="f64", device=device)
@@ -598,9 +598,11 @@ def shard_ceiling(problem, device, steps, unsharded_ms, profile_steps=40):
             row["one_shot"] = timed("oneshot")
             best = min(row["rccl_one_rank"]["ms_per_step"], row["one_shot"]["ms_per_step"])
             row["exchange_budget_us_for_3p5x"] = 1e3 * (unsharded_ms / 3.5 - best) if W == 8 else None
-            s.close()
         except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
             row["error"] = "%s: %s" % (type(e).__name__, e)
+        finally:
+            if s is not None:
+                s.close()
         rows.append(row)
     return {"what": "rank 0's shard of a W-rank partition of the bench workload through the whole sharded path on ONE GPU (one-rank RCCL communicator; "
                     "one-shot: the rank's own inbox): per-rank time without the wire and the wait for peers => ceiling of the W-GPU speed-up",
@@ -619,6 +621,7 @@ def quasi_newton(problem, device, iterations=40):
     for structured in (False, True):
         for alg, key in (("globalFbeAlgorithm", "global_fbe"), ("namaAlgorithm", "nama")):
             name = "%s_%s" % (key, "structured" if structured else "dense")
+            s = None
             try:
                 s = capi.Solver(problem["network"], problem["tree"], problem["config"], precision="f64", device=device, structured=structured)
                 s.initialiseSmpcController(dh, ah)
@@ -633,9 +636,11 @@ def quasi_newton(problem, device, iterations=40):
                 out[name] = {"ms_per_iteration": 1e3 * dt / iterations, "tau_first": [float(x) for x in tau[:8]], "tau_mean": float(np.mean(tau)),
                              "value_first_last": [float(v[0]), float(v[-1])], "primal_inf_first_last": [float(h[0]), float(h[-1])],
                              "counters": c if isinstance(c, dict) else [int(x) for x in c]}
-                s.close()
             except Exception as e:   # noqa: BLE001
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                if s is not None:
+                    s.close()
     return out
 
 
