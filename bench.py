@@ -1108,6 +1108,17 @@ def main():
             struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=0)
         except Exception as e:   # noqa: BLE001
             struct_error = "%s: %s" % (type(e).__name__, e)
+    # opt-in variant of the dense path (round 5): the forward walk and the dual update in one launch (RAPIDNET_FUSE_DOWN_DUAL=1), timed beside
+    # the headline on the same workload; the headline itself stays the default launch sequence, whose dual-update kernel has a roofline of its own
+    fused, fused_error = None, None
+    if dense is not None and not sharded and not args.dense_only and not args.traffic_probe and args.workload == "barcelona493":
+        os.environ["RAPIDNET_FUSE_DOWN_DUAL"] = "1"
+        try:
+            fused = run_mode(False, args.steps, args.warmup, 0, repeats=min(args.repeats, 4), control_step=False)
+        except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
+            fused_error = "%s: %s" % (type(e).__name__, e)
+        finally:
+            os.environ.pop("RAPIDNET_FUSE_DOWN_DUAL", None)
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
@@ -1157,6 +1168,12 @@ def main():
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if struct_error:
             out["structured_mode"] = {"error": struct_error}
+        if fused is not None:
+            out["fused_walk_dual"] = {"value": fused["value"], "ms_per_step": fused["ms_per_step"], "timing_spread": fused["spread"], "batch_counters": fused["batch_counters"],
+                                      "what": "RAPIDNET_FUSE_DOWN_DUAL=1: k_down_chain + k_dual_stage as one launch (k_down_chain_dual, Hx kept in LDS), identical iterates; opt-in -- the "
+                                              "default keeps the dual update a kernel of its own (north_star's roofline target names it)"}
+        elif fused_error:
+            out["fused_walk_dual"] = {"error": fused_error}
         if head.get("per_rank"):
             out["per_rank"] = head["per_rank"]
         if args.worker:   # under a supervisor (N > 1): the headline is on record from here on -- a first, partial line; the supervisor keeps

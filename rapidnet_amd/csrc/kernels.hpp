@@ -3014,6 +3014,273 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The forward walk AND the dual update of the nodes it has just walked, in one launch (round 5, opt-in: RAPIDNET_FUSE_DOWN_DUAL).
+// k_down_chain produces Hx of a chain's nodes (and of the crown nodes it writes); the fused dual update of exactly those elements needs
+// nothing else from the sweep, so the same workgroup can do it: phase A is k_down_chain with Hx kept in LDS ([rows][ny]; global memory
+// only when the primal iterates are stored), phase B walks the rows' 16-byte vectors like a k_dual_stage tile (dual_elem: the same
+// arithmetic element by element).  One dependent launch and the 42 MB round trip of Hx less per iteration.  The arg-max keeps the
+// reference's tie rule by comparing indices on equal magnitudes (a thread does not meet its elements in ascending order here).
+template <typename T, bool MATERIALIZE>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *shx = reinterpret_cast<T *>(smem_raw);      // [L + top][ny]: rows 0 .. L-1 the chain's nodes (stage top + r), rows L + dd the crown nodes this workgroup writes
+    __shared__ Partial sh_p[CHAIN_THREADS / 64];
+    __shared__ int sh_rowNode[CROWN_MAX_DEPTH];     // crown rows: node (or -1)
+    const bool crownWriter = (int)blockIdx.x >= a.K;
+    const int s = crownWriter ? 0 : (int)blockIdx.x;
+    const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
+    const int top = a.chainStage, L = a.N - top;
+    const int ntop = a.tr.stageCum[top] + s;
+    const size_t nodeTop = (size_t)ntop;
+    const T sp = a.tr.sqrtp[ntop];
+    const T *__restrict__ lvb = a.lvb;
+    const T *__restrict__ uhat = a.uhat;
+    const T *__restrict__ eb = a.eb;
+    const T *__restrict__ dyAll = a.tr.dy;
+    const int *__restrict__ cum = a.tr.stageCum;
+    int anc[CROWN_MAX_DEPTH];
+    bool writer[CROWN_MAX_DEPTH];
+    {
+        int n = ntop;
+        bool first = true;
+#pragma unroll
+        for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) {
+            if (dd < top) {
+                const int p = a.tr.parent[n];
+                first = first && (a.tr.childStart[p] == n);
+                anc[dd] = p; writer[dd] = first && foldCrown == 1 && !crownWriter;
+                n = p;
+            } else { anc[dd] = 0; writer[dd] = false; }
+        }
+    }
+    if (threadIdx.x < CROWN_MAX_DEPTH) {
+        int nd = -1;
+#pragma unroll
+        for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) if ((int)threadIdx.x == dd && writer[dd]) nd = anc[dd];
+        sh_rowNode[threadIdx.x] = nd;
+    }
+    // ---- phase A: the walk (k_down_chain, foldCrown 1 / 2), Hx into LDS
+    auto put = [&](int row, size_t node, int c, T val) {
+        shx[(size_t)row * ny + c] = val;
+        if (a.writePrimal) a.hx[node * ny + c] = val;
+    };
+    for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
+        if (t < nu) {
+            T run = a.prevU[t] - a.prevUhat[t];
+            T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
+#pragma unroll
+            for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uh[dd] = uhat[(size_t)anc[dd] * nu + t]; }
+#pragma unroll
+            for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                if (dd < top) {
+                    const int k = top - 1 - dd;
+                    const T uv = uh[dd] + run + lv[dd];
+                    run = uv - uh[dd];
+                    if (writer[dd]) {
+                        const T spc = a.tr.sqrtp[anc[dd]];
+                        if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
+                        put(L + dd, (size_t)anc[dd], 2 * nx + t, spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv);
+                    }
+                }
+            for (int k = top; k < a.N; k += CHAIN_PF) {
+                T dv[CHAIN_PF], uh2[CHAIN_PF], d0[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    dv[j] = lvb[node * w + t];
+                    uh2[j] = uhat[node * nu + t];
+                    d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k + j < a.N) {
+                        const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
+                        run += dv[j];
+                        const T uv = uh2[j] + run;
+                        if (a.writePrimal) a.u[node * nu + t] = uv;
+                        put(k + j - top, node, 2 * nx + t, sp * d0[j] * uv);
+                    }
+                }
+            }
+        } else {
+            const int j0 = t - nu;
+            T bw = a.bw0[j0], xr = a.curX[j0];
+            T lv[CROWN_MAX_DEPTH], ev0[CROWN_MAX_DEPTH];
+#pragma unroll
+            for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; ev0[dd] = eb[(size_t)anc[dd] * nx + j0]; }
+#pragma unroll
+            for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                if (dd < top) {
+                    const int k = top - 1 - dd;
+                    bw = bw + lv[dd];
+                    xr = xr + ev0[dd] + bw;
+                    if (writer[dd]) {
+                        const T spc = a.tr.sqrtp[anc[dd]];
+                        a.bw[(size_t)anc[dd] * nx + j0] = bw;
+                        if (a.writePrimal) a.x[(size_t)anc[dd] * nx + j0] = xr;
+                        put(L + dd, (size_t)anc[dd], j0, spc * dyAll[(size_t)k * ny + j0] * xr);
+                        put(L + dd, (size_t)anc[dd], nx + j0, spc * dyAll[(size_t)k * ny + nx + j0] * xr);
+                    }
+                }
+            for (int k = top; k < a.N; k += CHAIN_PF) {
+                T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    dv[j] = lvb[node * w + nu + j0];
+                    ev[j] = eb[node * nx + j0];
+                    d0[j] = dyAll[(size_t)kk * ny + j0];
+                    d1[j] = dyAll[(size_t)kk * ny + nx + j0];
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    if (k + j < a.N) {
+                        const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
+                        bw += dv[j];
+                        xr += ev[j] + bw;
+                        if (a.writePrimal) a.x[node * nx + j0] = xr;
+                        put(k + j - top, node, j0, sp * d0[j] * xr);
+                        put(k + j - top, node, nx + j0, sp * d1[j] * xr);
+                    }
+                }
+            }
+        }
+    }
+    int cwNode = -1, cwStage = 0;
+    if (crownWriter) {      // sharded runs (foldCrown = 2): this workgroup writes crown node j (root -> j walk), row 0
+        const int j = (int)blockIdx.x - a.K;
+        cwNode = j; cwStage = a.tr.stageOf[j];
+        const int kj = cwStage;
+        int pth[CROWN_MAX_DEPTH];
+        {
+            int n = j;
+#pragma unroll
+            for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) { pth[dd] = n; if (dd < kj) n = a.tr.parent[n]; }
+        }
+        const T spj = a.tr.sqrtp[j];
+        for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
+            if (t < nu) {
+                T run = a.prevU[t] - a.prevUhat[t];
+                T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = uhat[(size_t)pth[dd] * nu + t]; }
+                T uv = 0;
+#pragma unroll
+                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                    if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
+                if (a.writePrimal) a.u[(size_t)j * nu + t] = uv;
+                put(0, (size_t)j, 2 * nx + t, spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv);
+            } else {
+                const int j0 = t - nu;
+                T bw = a.bw0[j0], xr = a.curX[j0];
+                T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = eb[(size_t)pth[dd] * nx + j0]; }
+#pragma unroll
+                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                    if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
+                a.bw[(size_t)j * nx + j0] = bw;
+                if (a.writePrimal) a.x[(size_t)j * nx + j0] = xr;
+                put(0, (size_t)j, j0, spj * dyAll[(size_t)kj * ny + j0] * xr);
+                put(0, (size_t)j, nx + j0, spj * dyAll[(size_t)kj * ny + nx + j0] * xr);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: the dual update of the rows' elements (dual_slot_use's arithmetic; LAZY = 0)
+    const int vpn = ny / VN;
+    const int nRows = crownWriter ? 1 : L + top;
+    const T ln = (T)lnNext;
+    DualAcc<T> r;
+    constexpr int U = 3;
+    for (int v0 = threadIdx.x; v0 < nRows * vpn; v0 += U * CHAIN_THREADS) {
+        VT hxv[U], wv[U], ypv[U], dyv[U], blov[U], bhiv[U];
+        T spv[U];
+        long long ivv[U];
+        int cv[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int v = v0 + u * CHAIN_THREADS;
+            const bool in = v < nRows * vpn;
+            const int row = in ? v / vpn : 0, j = in ? v - row * vpn : 0;
+            int node, stage;
+            T spn;
+            if (crownWriter) { node = cwNode; stage = cwStage; spn = a.tr.sqrtp[cwNode]; }
+            else if (row < L) { node = (int)nodeTop + row * a.K; stage = top + row; spn = sp; }
+            else { node = sh_rowNode[row - L]; stage = top - 1 - (row - L); spn = node >= 0 ? a.tr.sqrtp[node] : (T)0; }
+            on[u] = in && node >= 0;
+            const int nd = on[u] ? node : 0;
+            cv[u] = j * VN;
+            ivv[u] = (long long)nd * vpn + j;
+            spv[u] = spn;
+            hxv[u] = *reinterpret_cast<const VT *>(shx + (size_t)row * ny + cv[u]);
+            wv[u] = reinterpret_cast<const VT *>(da.w)[ivv[u]];
+            ypv[u] = reinterpret_cast<const VT *>(da.yprev)[ivv[u]];
+            dyv[u] = *reinterpret_cast<const VT *>(da.dy + (size_t)(on[u] ? stage : 0) * ny + cv[u]);
+            blov[u] = *reinterpret_cast<const VT *>(da.blo + cv[u]);
+            bhiv[u] = *reinterpret_cast<const VT *>(da.bhi + cv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!on[u]) continue;
+            VT yn, wn, z, res;
+            const long long i0 = ivv[u] * VN;
+            const bool counted = da.countCrown || i0 >= da.crownElems;
+#pragma unroll
+            for (int e = 0; e < VN; e++) {
+                const int c = cv[u] + e;
+                const bool isBox = c < da.nx, isXi = c < 2 * da.nx;
+                const T k = spv[u] * dyv[u][e];
+                const T lo = k * blov[u][e];
+                const T hi = (isXi && !isBox) ? bhiv[u][e] : k * bhiv[u][e];
+                const DualOut<T> o = dual_elem<T, false>(hxv[u][e], wv[u][e], lo, hi, ypv[u][e], da.lambda, da.invLambda, ln, (T)0);
+                yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
+                const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
+                r.d2x += isBox ? dd : 0.0;
+                r.d2s += (isXi && !isBox) ? dd : 0.0;
+                const double rv = (double)o.res;
+                const unsigned int ie = (unsigned int)i0 + (unsigned int)e;
+                const bool upX = isXi && (r.idxXi == 0xffffffffu || fabs(rv) > fabs(r.valXi) || (fabs(rv) == fabs(r.valXi) && ie < r.idxXi));
+                const bool upP = !isXi && (r.idxPsi == 0xffffffffu || fabs(rv) > fabs(r.valPsi) || (fabs(rv) == fabs(r.valPsi) && ie < r.idxPsi));
+                r.valXi = upX ? rv : r.valXi; r.idxXi = upX ? ie : r.idxXi;
+                r.valPsi = upP ? rv : r.valPsi; r.idxPsi = upP ? ie : r.idxPsi;
+            }
+            reinterpret_cast<VT *>(da.ynew)[ivv[u]] = yn;
+            reinterpret_cast<VT *>(da.wnext)[ivv[u]] = wn;
+            if (MATERIALIZE) { reinterpret_cast<VT *>(da.z)[ivv[u]] = z; reinterpret_cast<VT *>(da.res)[ivv[u]] = res; }
+        }
+    }
+    double valXi = r.valXi, valPsi = r.valPsi;
+    long long idxXi = r.idxXi == 0xffffffffu ? 0x7fffffffffffffffLL : (long long)r.idxXi;
+    long long idxPsi = r.idxPsi == 0xffffffffu ? 0x7fffffffffffffffLL : (long long)r.idxPsi;
+    double absXi = r.idxXi == 0xffffffffu ? -1.0 : fabs(valXi), absPsi = r.idxPsi == 0xffffffffu ? -1.0 : fabs(valPsi);
+    const double d2x = wave_sum_f64(r.d2x), d2s = wave_sum_f64(r.d2s);
+    wave_argmax(absXi, valXi, idxXi);
+    wave_argmax(absPsi, valPsi, idxPsi);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh_p[wave] = Partial{d2x, d2s, absXi, valXi, absPsi, valPsi, idxXi, idxPsi};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Partial p = sh_p[0];
+        for (int k = 1; k < CHAIN_THREADS / 64; k++) {
+            p.d2x += sh_p[k].d2x; p.d2s += sh_p[k].d2s;
+            better(p.absXi, p.valXi, p.idxXi, sh_p[k].absXi, sh_p[k].valXi, sh_p[k].idxXi);
+            better(p.absPsi, p.valPsi, p.idxPsi, sh_p[k].absPsi, sh_p[k].valPsi, sh_p[k].idxPsi);
+        }
+        da.partials[blockIdx.x] = p;
+    }
+}
+
 // one workgroup: fold the block partials; decide whether the soft-constraint branch trips
 // (dist > gamma/lambda, SmpcController.cu:793, :811)
 __global__ void __launch_bounds__(ELT_THREADS) k_decide(const Partial *partials, int nblocks, IterState *st, double thrX,

@@ -1392,7 +1392,14 @@ struct Ctx : CtxBase {
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
         }
         // sharded (foldCrown = 2): one more workgroup per replicated crown node, which writes that node while the chains are walked
-        hipLaunchKernelGGL(k_down_chain<T>, dim3(a.K + (foldCrown == 2 ? h_stageCum[cs] : 0)), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
+        const int downGrid = a.K + (foldCrown == 2 ? h_stageCum[cs] : 0);
+        const size_t fuseLds = (size_t)d.N * ny * sizeof(T);      // Hx of the chain's N - cs nodes and of up to cs crown nodes
+        if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024) {
+            if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
+            else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
+            fuseDone = true; mainPartials = downGrid;
+        } else
+        hipLaunchKernelGGL(k_down_chain<T>, dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
@@ -1584,11 +1591,14 @@ struct Ctx : CtxBase {
             // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
             // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
             lazyIn = lazy && k > 0;
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; carryTail = false; pendingFin = false; return fail_batch(rc); }
+            fuseReq = !lazy && fuse_want(); fuseDone = false;
+            if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; carryTail = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
             const bool storesW = !lazy || k == n - 1;
-            launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
+            if (!fuseDone) launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
             prof_end(e2);
             lazyIn = false;
             // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
@@ -1663,11 +1673,14 @@ struct Ctx : CtxBase {
             // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
             // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
             lazyIn = lazy && k > 0;
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; pendingFin = false; return fail_batch(rc); }
+            fuseReq = !lazy && fuse_want(); fuseDone = false;
+            if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
             const bool storesW = !lazy || k == n - 1;
-            launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
+            if (!fuseDone) launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
             prof_end(e2);
             lazyIn = false;
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
@@ -1722,6 +1735,16 @@ struct Ctx : CtxBase {
     // its own while the solver's stream multiplies the chain region's slabs, and only the crown's two slabs wait for it.
     int overlapExchange = 0;
     bool overlapNow = false, joinPending = false;      // state of the sweep being enqueued
+    // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual; opt-in: RAPIDNET_FUSE_DOWN_DUAL=1):
+    // the optimistic batches ask for it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened
+    bool fuseReq = false, fuseDone = false, fuseMat = false;
+    DualArgs<T> fuseArgs{};
+    double fuseLn = 0.0;
+    int fuseEnv = -1;      // $RAPIDNET_FUSE_DOWN_DUAL, read when the context runs its first batch
+    bool fuse_want() {
+        if (fuseEnv < 0) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseEnv = e ? (std::atoi(e) != 0) : 0; }
+        return fuseEnv != 0 && dualU != 0 && !prof;
+    }
     hipStream_t commStream = nullptr;
     hipEvent_t evCommFork = nullptr, evCommJoin = nullptr;
     int set_exchange_overlap(int on) override {

@@ -1,0 +1,66 @@
+"""k_down_chain_dual (round 5, RAPIDNET_FUSE_DOWN_DUAL=1): the forward walk and the fused dual update of the nodes it has just walked in
+ONE launch, Hx kept in LDS in between.  Element by element it is dual_elem, the arithmetic of k_dual_stage: iterates, histories and
+batch counters must be the unfused path's bit for bit -- single GPU (the first descendant chain of a crown node writes it) and
+sharded (crown nodes written by workgroups of their own), dense and structured, fp64 and fp32, incl. a batch whose soft-constraint
+thresholds trip and which is replayed through the exact path."""
+import numpy as np
+import pytest
+
+from rapidnet_amd import capi, synth
+from test_gpu_sharded_batched import VECS, Ranks, dims_of
+
+pytestmark = pytest.mark.gpu
+BUFS = (capi.BUF_X, capi.BUF_U, capi.BUF_V, capi.BUF_XI, capi.BUF_PSI, capi.BUF_UPD_XI, capi.BUF_UPD_PSI, capi.BUF_ACC_XI, capi.BUF_ACC_PSI,
+        capi.BUF_PRIMAL_XI, capi.BUF_PRIMAL_PSI, capi.BUF_DUAL_XI, capi.BUF_DUAL_PSI, capi.BUF_RES_XI, capi.BUF_RES_PSI)
+
+
+def run(p, structured, precision, batches=(20, 17, 3)):
+    s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision)
+    s.initialiseSmpcController(*synth.forecast_at(p["forecast"], 0))
+    s.apgReset()
+    hist = np.concatenate([s.apgIterate(n) for n in batches])      # batches of >= 16 take the optimistic (fusable) path, the last one the exact path
+    out = {b: s.get(b) for b in BUFS}
+    c = s.counters()
+    s.close()
+    return hist, out, c
+
+
+@pytest.mark.parametrize("name,structured,precision,kw", [("medium", False, "f64", {}), ("medium", True, "f64", {}), ("ragged", False, "f64", {}), ("small", False, "f64", {}),
+                                                          ("barcelona31", False, "f64", {}), ("medium", False, "f32", {}), ("widecrown", False, "f64", {}),
+                                                          ("barcelona31_infeasible", False, "f64", {"penalty_x": 20.0, "penalty_xs": 5.0})])
+def test_fused_walk_and_dual_update_is_bitwise_the_two_launches(monkeypatch, name, structured, precision, kw):
+    p = synth.make_problem(name, **kw)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "0")
+    h0, o0, c0 = run(p, structured, precision)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "1")
+    h1, o1, c1 = run(p, structured, precision)
+    assert c0 == c1, (c0, c1)
+    assert np.array_equal(h0, h1)
+    for b in BUFS:
+        assert np.array_equal(o0[b], o1[b]), b
+
+
+@pytest.mark.parametrize("name,world,structured,kw", [("medium", 2, False, {}), ("medium", 4, True, {}), ("ragged", 3, False, {}),
+                                                      ("medium", 3, False, {"penalty_x": 20.0, "penalty_xs": 5.0})])
+def test_fused_walk_and_dual_update_sharded(monkeypatch, name, world, structured, kw):
+    p = synth.make_problem(name, **kw)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    out = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", fused)
+        rk = Ranks(p, world, 0, structured)
+        try:
+            def solve(s):
+                s.initialiseSmpcController(dh, ah)
+                s.apgReset()
+                return s.counters(), np.concatenate([s.apgIterate(20), s.apgIterate(5)])
+
+            res = rk.run(solve)
+            d = dims_of(rk.shards[0])
+            out.append((res[0][0], res[0][1], [rk.gathered(bid, d[dm]) for bid, _, dm in VECS]))
+        finally:
+            rk.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)
