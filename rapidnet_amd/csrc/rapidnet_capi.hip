@@ -570,7 +570,7 @@ struct Ctx : CtxBase {
             if (shape && force > 0 && (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)) {
                 regVlv = force == 2 ? 2 : 1;
                 if (regVlv == 2 && !d_zeroPage) {
-                    if (dalloc(&d_zeroPage, (size_t)64) != RN_OK || hipMemset(d_zeroPage, 0, 64 * sizeof(T)) != hipSuccess) regVlv = 1;
+                    if (dalloc(&d_zeroPage, (size_t)64) != RN_OK || hipMemset(d_zeroPage, 0, 64 * sizeof(T)) != hipSuccess) regVlv = 0;      // (no zero page: the default kernel runs)
                 }
             } else (void)hipGetLastError();
         }
