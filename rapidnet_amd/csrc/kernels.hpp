@@ -3040,7 +3040,6 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
     const T *__restrict__ uhat = a.uhat;
     const T *__restrict__ eb = a.eb;
     const T *__restrict__ dyAll = a.tr.dy;
-    const int *__restrict__ cum = a.tr.stageCum;
     int anc[CROWN_MAX_DEPTH];
     bool writer[CROWN_MAX_DEPTH];
     {
