@@ -770,7 +770,7 @@ def main():
             rccl_library = "unavailable: %s" % e
 
     def run_mode(structured, steps, warmup, profile_steps, repeats=0, problem=problem, tree=tree, precision=precision, workload=args.workload,
-                 control_step=True, cut_stage=cut_stage, fatal=True, alt=False):
+                 control_step=True, cut_stage=cut_stage, fatal=True, alt=False, fused_ab=False):
         if sharded:
             import torch
         def make_local():
@@ -928,6 +928,31 @@ def main():
             spread = {"regions": len(allr), "steps_per_region": steps, "ms_per_step_median": 1e3 * float(np.median(allr)) / steps,
                       "ms_per_step_min": 1e3 * allr[0] / steps, "ms_per_step_max": 1e3 * allr[-1] / steps,
                       "value_median": steps / float(np.median(allr)), "note": "region 1 is the contract's timed region (`value`); all regions max over ranks"}
+        # opt-in variant in the SAME context (same buffers: two contexts of one process differ by up to 5 % through the placement of their
+        # buffers alone): the forward walk and the dual update in one launch (rn_set_fused_walk_dual), `repeats` regions, then off again
+        fused = None
+        if fused_ab and not sharded and not structured and rep:
+            try:
+                s.setFusedWalkDual(1)
+                iterate(40)
+                frep = []
+                for _ in range(len(rep)):
+                    barrier()
+                    t0 = time.perf_counter()
+                    iterate(steps)
+                    barrier()
+                    frep.append(time.perf_counter() - t0)
+                s.setFusedWalkDual(0)
+                iterate(40)
+                s.synchronize()
+                fm, um = float(np.median(frep)), float(np.median(rep))
+                fused = {"value": steps / fm, "ms_per_step": 1e3 * fm / steps, "ms_per_step_min": 1e3 * min(frep) / steps, "ms_per_step_max": 1e3 * max(frep) / steps, "regions": len(frep),
+                         "same_context_two_launches": {"ms_per_step": 1e3 * um / steps, "regions": len(rep)}, "speedup": um / fm,
+                         "what": "rn_set_fused_walk_dual(ctx, 1): k_down_chain + k_dual_stage as one launch (k_down_chain_dual, Hx kept in LDS), identical iterates, timed in "
+                                 "the headline's own context right behind its regions; opt-in -- the default keeps the dual update a kernel of its own (north_star's "
+                                 "roofline target names it)"}
+            except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
+                fused = {"error": "%s: %s" % (type(e).__name__, e)}
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
         ctrl_ms = None
         if not sharded and control_step:
@@ -1081,7 +1106,7 @@ def main():
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
-               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res}
+               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res, "fused_walk_dual": fused}
         s.close()
         return res
 
@@ -1099,7 +1124,8 @@ def main():
         dist.barrier()
         return
     # headline: the reference's storage model (dense per-node blocks); the structured mode is reported beside it on 1 GPU
-    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
+    dense = None if args.structured else run_mode(False, args.steps, args.warmup, args.profile_steps, repeats=args.repeats,
+                                                  fused_ab=not (args.dense_only or args.traffic_probe) and args.workload == "barcelona493")
     struct, struct_error = None, None
     if args.structured:
         struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
@@ -1108,17 +1134,6 @@ def main():
             struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=0)
         except Exception as e:   # noqa: BLE001
             struct_error = "%s: %s" % (type(e).__name__, e)
-    # opt-in variant of the dense path (round 5): the forward walk and the dual update in one launch (RAPIDNET_FUSE_DOWN_DUAL=1), timed beside
-    # the headline on the same workload; the headline itself stays the default launch sequence, whose dual-update kernel has a roofline of its own
-    fused, fused_error = None, None
-    if dense is not None and not sharded and not args.dense_only and not args.traffic_probe and args.workload == "barcelona493":
-        os.environ["RAPIDNET_FUSE_DOWN_DUAL"] = "1"
-        try:
-            fused = run_mode(False, args.steps, args.warmup, 0, repeats=min(args.repeats, 4), control_step=False)
-        except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
-            fused_error = "%s: %s" % (type(e).__name__, e)
-        finally:
-            os.environ.pop("RAPIDNET_FUSE_DOWN_DUAL", None)
     head = struct if args.structured else dense
     dt = args.steps / head["value"]
     roofline, classes = head["roofline"], head["kernel_classes"]
@@ -1168,12 +1183,8 @@ def main():
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
         if struct_error:
             out["structured_mode"] = {"error": struct_error}
-        if fused is not None:
-            out["fused_walk_dual"] = {"value": fused["value"], "ms_per_step": fused["ms_per_step"], "timing_spread": fused["spread"], "batch_counters": fused["batch_counters"],
-                                      "what": "RAPIDNET_FUSE_DOWN_DUAL=1: k_down_chain + k_dual_stage as one launch (k_down_chain_dual, Hx kept in LDS), identical iterates; opt-in -- the "
-                                              "default keeps the dual update a kernel of its own (north_star's roofline target names it)"}
-        elif fused_error:
-            out["fused_walk_dual"] = {"error": fused_error}
+        if dense is not None and dense.get("fused_walk_dual"):
+            out["fused_walk_dual"] = dense["fused_walk_dual"]
         if head.get("per_rank"):
             out["per_rank"] = head["per_rank"]
         if args.worker:   # under a supervisor (N > 1): the headline is on record from here on -- a first, partial line; the supervisor keeps

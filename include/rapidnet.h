@@ -381,6 +381,11 @@ int rn_set_exchange_transport(rn_ctx *ctx, int transport);
  * runs on a stream of its own while the solver's stream multiplies the chain region's nodes, and only the crown's slabs -- and the
  * forward walk behind them -- wait for it.  Same launches on the same data in the same order per node: identical iterates. */
 int rn_set_exchange_overlap(rn_ctx *ctx, int on);
+/* The forward walk and the fused dual update of the nodes it has just walked in ONE launch (k_down_chain_dual: Hx stays in LDS between
+ * the two; SmpcController.cu:676-747 + :759-864 per node) inside batches of >= 16 iterations; identical iterates.  Opt-in (default:
+ * $RAPIDNET_FUSE_DOWN_DUAL, else off): 0.9 % faster per iteration on the 493-scenario tree, slower on small shards, and the default
+ * keeps the dual update a kernel of its own (the one the roofline target names). */
+int rn_set_fused_walk_dual(rn_ctx *ctx, int on);
 
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red

@@ -36,7 +36,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport", "rn_set_exchange_overlap",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual",
 ]
 
 
@@ -206,6 +206,7 @@ def load():
     lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
     lib.rn_set_exchange_transport.argtypes = [vp, ip]
     lib.rn_set_exchange_overlap.argtypes = [vp, ip]
+    lib.rn_set_fused_walk_dual.argtypes = [vp, ip]
     lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
     _LIB = lib
     return lib
@@ -528,6 +529,10 @@ class Solver:
     def setExchangeTransport(self, transport):
         """0: the cut payload is all-reduced by the communicator (default); 1: one-shot peer writes (needs connected inboxes)"""
         self._check(self.lib.rn_set_exchange_transport(self.h, int(transport)))
+
+    def setFusedWalkDual(self, on):
+        """1: forward walk + dual update in one launch inside batches of >= 16 iterations (identical iterates; opt-in)"""
+        self._check(self.lib.rn_set_fused_walk_dual(self.h, int(bool(on))))
 
     def setExchangeOverlap(self, on):
         """1: the per-iteration all-reduce on a stream of its own, beside the chain region's shared-operator products (identical iterates)"""

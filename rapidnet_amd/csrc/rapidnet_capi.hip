@@ -198,6 +198,7 @@ struct CtxBase {
     virtual unsigned long long *peer_inbox_ptr() = 0;
     virtual int set_exchange_transport(int) = 0;
     virtual int set_exchange_overlap(int) = 0;
+    virtual int set_fused_walk_dual(int) = 0;
     virtual int fbe_counters(long *) = 0;
 };
 
@@ -1740,7 +1741,8 @@ struct Ctx : CtxBase {
     bool fuseReq = false, fuseDone = false, fuseMat = false;
     DualArgs<T> fuseArgs{};
     double fuseLn = 0.0;
-    int fuseEnv = -1;      // $RAPIDNET_FUSE_DOWN_DUAL, read when the context runs its first batch
+    int fuseEnv = -1;      // rn_set_fused_walk_dual, or $RAPIDNET_FUSE_DOWN_DUAL read when the context runs its first batch
+    int set_fused_walk_dual(int on) override { RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_fused_walk_dual: 0 or 1"); fuseEnv = on; return RN_OK; }
     bool fuse_want() {
         if (fuseEnv < 0) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseEnv = e ? (std::atoi(e) != 0) : 0; }
         return fuseEnv != 0 && dualU != 0 && !prof;
@@ -2613,6 +2615,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
 int rn_set_exchange_overlap(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_exchange_overlap(on); }
+int rn_set_fused_walk_dual(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_fused_walk_dual(on); }
 int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }

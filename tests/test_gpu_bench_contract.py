@@ -64,7 +64,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert sc["shards"][0]["local_nodes"] in (5452, 5430) and sc["shards"][2]["local_nodes"] in (1382, 1360)
     assert sc["shards"][2]["rccl_one_rank"]["speedup_before_wire"] > 3.5 and sc["shards"][2]["exchange_budget_us_for_3p5x"] > 0
     fw = d["fused_walk_dual"]      # the opt-in one-launch form of the forward walk + dual update, timed beside the headline
-    assert "error" not in fw and 0.9 * d["value"] < fw["value"] < 1.1 * d["value"], fw
+    assert "error" not in fw and 0.9 * d["value"] < fw["value"] < 1.1 * d["value"] and fw["speedup"] > 0.97, fw      # (same context: comparable to a fraction of a percent)
     qn = d["quasi_newton"]
     for k in ("global_fbe_dense", "nama_dense", "global_fbe_structured", "nama_structured"):
         assert "error" not in qn[k], qn[k]

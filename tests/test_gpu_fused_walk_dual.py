@@ -1,4 +1,4 @@
-"""k_down_chain_dual (round 5, RAPIDNET_FUSE_DOWN_DUAL=1): the forward walk and the fused dual update of the nodes it has just walked in
+"""k_down_chain_dual (round 5, rn_set_fused_walk_dual / RAPIDNET_FUSE_DOWN_DUAL=1): the forward walk and the fused dual update of the nodes it has just walked in
 ONE launch, Hx kept in LDS in between.  Element by element it is dual_elem, the arithmetic of k_dual_stage: iterates, histories and
 batch counters must be the unfused path's bit for bit -- single GPU (the first descendant chain of a crown node writes it) and
 sharded (crown nodes written by workgroups of their own), dense and structured, fp64 and fp32, incl. a batch whose soft-constraint
@@ -64,3 +64,25 @@ def test_fused_walk_and_dual_update_sharded(monkeypatch, name, world, structured
     assert np.array_equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         assert np.array_equal(a, b)
+
+
+def test_the_switch_can_be_flipped_between_batches():
+    """rn_set_fused_walk_dual on a live context: batches with and without the fusion alternate and the iterates are those of a context
+    that never fused (what bench.py's same-context A/B relies on)."""
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    ref = capi.Solver(p["network"], p["tree"], p["config"])
+    ref.initialiseSmpcController(dh, ah)
+    ref.apgReset()
+    h0 = np.concatenate([ref.apgIterate(20) for _ in range(4)])
+    s = capi.Solver(p["network"], p["tree"], p["config"])
+    s.initialiseSmpcController(dh, ah)
+    s.apgReset()
+    h1 = []
+    for on in (1, 0, 1, 0):
+        s.setFusedWalkDual(on)
+        h1.append(s.apgIterate(20))
+    assert np.array_equal(h0, np.concatenate(h1))
+    for b in BUFS:
+        assert np.array_equal(ref.get(b), s.get(b)), b
+    ref.close(); s.close()
