@@ -129,6 +129,57 @@ def timeout_case():
     os._exit(0)      # the half-finished group is not torn down
 
 
+def latecomer_case():
+    """Three ranks; rank 2 starts its batch 0.6 s late, the readers' time-out is 0.4 s.  Ranks 0 and 1 give up on rank 2's packets of
+    the FIRST exchange (and carry on with incomplete sums); rank 2 then finds everybody's packets where they belong, catches up and
+    never times out itself.  The batch is nevertheless invalid everywhere -- ranks 0 and 1 pushed sums derived from incomplete ones --
+    so every rank must return RN_E_COMM: the flag rides in the per-batch MAX all-reduce (round 5; before, rank 2 returned RN_OK)."""
+    import time
+
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    world = 3
+    group = capi.local_group_create(world)
+    shards = []
+    for r in range(world):
+        s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=world)
+        s.joinLocalGroup(group, r)
+        s.peerInboxCreate()
+        shards.append(s)
+    capi.peer_inbox_connect_local(shards)
+    for s in shards:
+        s.setExchangeTransport(1)
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        s.synchronize()
+    res = [None] * world
+
+    def work(i):
+        if i == 2:
+            time.sleep(0.6)
+        try:
+            shards[i].apgIterate(20, history=False)
+            res[i] = "ok"
+        except capi.RapidNetError as e:
+            res[i] = str(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(r is not None and r != "ok" for r in res), res                     # EVERY rank failed the batch, the one that saw all packets too
+    assert all("did not arrive" in r for r in res), res                           # ... with the one-shot time-out's message (RN_E_COMM)
+    for s in shards:                                                              # and refuses to go on until it is reset
+        try:
+            s.apgIterate(1, history=False)
+            raise AssertionError("a poisoned context iterated")
+        except capi.RapidNetError:
+            pass
+    print("oneshot latecomer ok: %s" % [r[:60] for r in res], flush=True)
+    os._exit(0)
+
+
 def ipc(name, cut):
     import ctypes as C
 
@@ -192,6 +243,8 @@ if __name__ == "__main__":
         inprocess(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), "structured" in sys.argv[5:], "f32" if "f32" in sys.argv[5:] else "f64", kw)
     elif mode == "timeout":
         timeout_case()
+    elif mode == "latecomer":
+        latecomer_case()
     elif mode == "ipc":
         ipc(sys.argv[2], int(sys.argv[3]))
     else:

@@ -42,6 +42,11 @@ def test_one_shot_exchange_gives_up_instead_of_hanging():
     assert "oneshot timeout ok" in out, out
 
 
+def test_a_time_out_on_some_ranks_fails_the_batch_on_every_rank():
+    out = run(("latecomer",), env_extra={"RAPIDNET_ONESHOT_TIMEOUT_MS": "400", "RAPIDNET_GROUP_TIMEOUT_S": "30"})
+    assert "oneshot latecomer ok" in out, out
+
+
 @pytest.mark.parametrize("name,cut", [("medium", 0), ("ragged", 1)])
 def test_one_shot_exchange_between_two_processes(name, cut):
     """hipIpcMemHandle_t inboxes between two processes sharing the box's one GPU"""
