@@ -258,6 +258,35 @@ def test_nama_pair_of_hessian_sweeps_is_bitwise_the_two_sweeps(name, precision, 
         assert np.array_equal(x, y)
 
 
+def test_nama_on_a_cut_context_without_a_communicator_takes_the_two_sweeps():
+    """A one-rank context with a cut stage set and no communicator (what the FBE entry points explicitly allow) keeps ONE buffer for
+    the cut parents' sums: the pair of Hessian sweeps -- whose two helper chains run side by side on two streams -- would both write
+    and read it (round 4's advisor finding).  Such a context takes the two sweeps one after the other and its loop is the plain
+    context's: same accepted steps, same values, same iterates, twice in a row."""
+    from rapidnet_amd import partition
+
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    cut = partition.default_cut_stage(p["tree"])
+    runs = []
+    for kind in ("plain", "cut", "cut"):
+        s = capi.Solver(p["network"], p["tree"], p["config"])
+        if kind == "cut":
+            s.commInit(0, 1, None)
+            s.setCutStage(cut, partition.cut_children_moments(p["tree"], cut))
+        s.initialiseSmpcController(dh, ah)
+        s.setAlgorithm("namaAlgorithm", 5)
+        h, v, t = s.algorithmNama(10)
+        runs.append((h, v, t, s.get(capi.BUF_X), s.get(capi.BUF_U), s.fbeCounters()))
+        s.close()
+    plain, cut1, cut2 = runs
+    assert plain[5]["sweep_pairs"] >= 8 and cut1[5]["sweep_pairs"] == 0, (plain[5], cut1[5])
+    for a, b in zip(cut1[:5], cut2[:5]):
+        assert np.array_equal(a, b)                      # deterministic
+    assert np.array_equal(plain[2], cut1[2])             # the same accepted steps
+    assert relmax(cut1[1], plain[1]) < 1e-12 and relmax(cut1[3], plain[3]) < 1e-10 and relmax(cut1[4], plain[4]) < 1e-10
+
+
 @pytest.mark.parametrize("alg", ALGS)
 def test_steps_match_oracle(alg):
     """every step of one iteration, each fed by the previous one, compared after each call"""
