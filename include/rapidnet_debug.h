@@ -38,6 +38,11 @@ int rn_debug_local_group_destroy(void *group);
  * handle needed -- contexts in rank order */
 int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks);
 
+/* one-shot exchange: sets the sequence number of the context's LAST exchange (the next one carries seq + 1; every rank must be given the
+ * same value) -- lets a test walk the 32-bit tag across its wrap, where two values are skipped so that the parity which selects the
+ * inbox buffer keeps alternating */
+int rn_debug_peer_seq(rn_ctx *ctx, unsigned int seq);
+
 /* test of the guard-mode detector itself (rn_guard_check): overwrites `nbytes` (1 .. 256) right behind the payload of the context's
  * first buffer */
 int rn_debug_guard_poke(rn_ctx *ctx, int nbytes);

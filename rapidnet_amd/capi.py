@@ -36,7 +36,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual",
 ]
 
 
@@ -204,6 +204,7 @@ def load():
     lib.rn_peer_inbox_create.argtypes = [vp, dp]
     lib.rn_peer_inbox_connect.argtypes = [vp, dp, ip]
     lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
+    lib.rn_debug_peer_seq.argtypes = [vp, C.c_uint]
     lib.rn_set_exchange_transport.argtypes = [vp, ip]
     lib.rn_set_exchange_overlap.argtypes = [vp, ip]
     lib.rn_set_fused_walk_dual.argtypes = [vp, ip]
@@ -525,6 +526,9 @@ class Solver:
         blob = b"".join(bytes(h) for h in handles)
         buf = C.create_string_buffer(blob, len(blob))
         self._check(self.lib.rn_peer_inbox_connect(self.h, C.cast(buf, C.c_void_p), len(handles)))
+
+    def debugPeerSeq(self, seq):
+        self._check(self.lib.rn_debug_peer_seq(self.h, int(seq) & 0xFFFFFFFF))
 
     def setExchangeTransport(self, transport):
         """0: the cut payload is all-reduced by the communicator (default); 1: one-shot peer writes (needs connected inboxes)"""

@@ -199,6 +199,7 @@ struct CtxBase {
     virtual int set_exchange_transport(int) = 0;
     virtual int set_exchange_overlap(int) = 0;
     virtual int set_fused_walk_dual(int) = 0;
+    virtual int debug_peer_seq(unsigned int) = 0;
     virtual int fbe_counters(long *) = 0;
 };
 
@@ -1819,6 +1820,11 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         return peer_table_install();
     }
+    int debug_peer_seq(unsigned int seq) override {      // test hook: the next exchange gets sequence number seq + 1 (all ranks alike)
+        RN_CHECK(peerReady, RN_E_STATE, "rn_debug_peer_seq: connect the inboxes first");
+        peerSeq = seq;
+        return RN_OK;
+    }
     int set_exchange_transport(int t) override {
         RN_CHECK(t == 0 || t == 1, RN_E_ARG, "rn_set_exchange_transport: 0 (collective) or 1 (one-shot peer writes)");
         RN_CHECK(t == 0 || peerReady, RN_E_STATE, "rn_set_exchange_transport: connect the peers' inboxes first (rn_peer_inbox_connect)");
@@ -2603,6 +2609,7 @@ int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank) { RN_GUARD(ctx
 int rn_debug_local_group_destroy(void *group) { if (!group) return RN_E_ARG; delete static_cast<rn::LocalGroup *>(group); return RN_OK; }
 int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes) { RN_GUARD(ctx); return ctx->impl->inject_allocation(bytes); }
 int rn_debug_guard_poke(rn_ctx *ctx, int nbytes) { RN_GUARD(ctx); return ctx->impl->guard_poke(nbytes); }
+int rn_debug_peer_seq(rn_ctx *ctx, unsigned int seq) { RN_GUARD(ctx); return ctx->impl->debug_peer_seq(seq); }
 int rn_guard_report(long out[2]) { if (!out) return RN_E_ARG; out[0] = rn::g_guardContexts.load(); out[1] = rn::g_guardBadBytes.load(); return RN_OK; }
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64) { RN_GUARD(ctx); return ctx->impl->peer_inbox_create(ipcHandle64); }
 int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles, int nranks) { RN_GUARD(ctx); return ctx->impl->peer_inbox_connect(ipcHandles, nranks); }

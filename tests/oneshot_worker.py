@@ -53,6 +53,8 @@ def inprocess(name, world, cut, structured, precision, kw):
             capi.peer_inbox_connect_local(shards)
             for s in shards:
                 s.setExchangeTransport(1)
+                if "wrap" in sys.argv[5:]:
+                    s.debugPeerSeq(0xFFFFFFF0)      # the 44 exchanges of this run walk the 32-bit sequence tag across its wrap (... ffffffff, 2, 3 ...)
         out, errs = [None] * world, []
 
         def work(i):

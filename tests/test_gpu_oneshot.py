@@ -29,7 +29,7 @@ def run(args, env_extra=None, timeout=600, launcher=None):
 
 
 @pytest.mark.parametrize("args", [("medium", 2, 0), ("medium", 4, 1), ("medium", 3, 2, "structured"), ("ragged", 3, 1), ("small", 2, 3),
-                                  ("medium", 2, 0, "f32"), ("medium", 4, 0, "trip")])
+                                  ("medium", 2, 0, "f32"), ("medium", 4, 0, "trip"), ("medium", 3, 0, "wrap")])
 def test_one_shot_exchange_in_process(args):
     out = run(("inprocess",) + args)
     assert "oneshot inprocess ok" in out, out
