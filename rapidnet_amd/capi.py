@@ -36,7 +36,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual", "rn_set_sweep_form",
 ]
 
 
@@ -208,6 +208,7 @@ def load():
     lib.rn_set_exchange_transport.argtypes = [vp, ip]
     lib.rn_set_exchange_overlap.argtypes = [vp, ip]
     lib.rn_set_fused_walk_dual.argtypes = [vp, ip]
+    lib.rn_set_sweep_form.argtypes = [vp, ip, C.POINTER(C.c_int)]
     lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
     _LIB = lib
     return lib
@@ -537,6 +538,12 @@ class Solver:
     def setFusedWalkDual(self, on):
         """1: forward walk + dual update in one launch inside batches of >= 16 iterations (identical iterates; opt-in)"""
         self._check(self.lib.rn_set_fused_walk_dual(self.h, int(bool(on))))
+
+    def setSweepForm(self, form):
+        """0: the six-launch helper path everywhere; 1 (default): the chain-fused form where the context qualifies.  Returns 1 if sweeps will be chain-fused."""
+        act = C.c_int(0)
+        self._check(self.lib.rn_set_sweep_form(self.h, int(form), C.byref(act)))
+        return act.value
 
     def setExchangeOverlap(self, on):
         """1: the per-iteration all-reduce on a stream of its own, beside the chain region's shared-operator products (identical iterates)"""

@@ -476,6 +476,10 @@ __device__ __forceinline__ T extrap_elem(T y1, T y0, T ln) {
     return fma_rn(-ln, y0, a);
 }
 
+// chain-fused sweep (chain_kernels.hpp): the primal value behind an entry of Hx from the chain-local partial p and the offsets of the
+// chain's parent in the crown -- the ONE expression every consumer uses (k_dual_stage OFFS, k_hx_finish), roundings spelled out
+template <typename T>
+__device__ __forceinline__ T cf_primal(T p, T cnt, T off1, T off0) { return p + fma_rn(cnt, off1, off0); }
 template <typename T> struct Slot;
 template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
 template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4; };
@@ -2618,6 +2622,9 @@ struct DualArgs {
     // partials of the main pass; this launch writes its own partials to `partials`.
     int decideHere, itHost, nMain;
     const Partial *mainPartials;
+    // k_dual_stage OFFS (chain-fused sweep): hx holds the partial primal P of the chain nodes; Hx = sqrt(p_i) d (P + off0 + cnt off1) with the
+    // offset rows of the chain's parent (chainPar[chain] = its position in stage c* - 1), cnt = stage - c* + 1
+    const T *off0, *off1; const int *chainPar;
 };
 
 
@@ -2868,8 +2875,9 @@ struct DualStageShape {
 // one 16-byte vector of the tile with everything its update needs (all seven loads are independent)
 template <typename T>
 struct DualSlot {
-    typename VecOf<T>::type hx, w, yp, blo, bhi, dy;
-    T sp;
+    typename VecOf<T>::type hx, w, yp, blo, bhi, dy, o0, o1;
+    T sp, cnt;        // (o0, o1, cnt: OFFS only)
+    bool offs;
     int c;            // column of the vector's first element
     long long iv;     // global vector index
     bool on;
@@ -2879,7 +2887,7 @@ struct DualAcc {      // per-thread running reductions; arg-max keeps the signed
     double d2x = 0, d2s = 0, valXi = 0, valPsi = 0;   // the 32-bit element index of its first occurrence (strict >, ascending walk)
     unsigned int idxXi = 0xffffffffu, idxPsi = 0xffffffffu;
 };
-template <typename T>
+template <typename T, bool OFFS = false>
 __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T> &a, const DualStageShape &g, int trip, int jbase, int cnt,
                                                int nodeFirst, int stageU, bool crownBlock) {
     typedef typename VecOf<T>::type VT;
@@ -2893,6 +2901,9 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
     s.iv = (long long)nodeFirst * g.vpn + J;
     int stage = stageU;
     if (crownBlock) stage = a.stageOf[node];
+    s.offs = OFFS && !crownBlock;
+    int ppos = 0;
+    if (OFFS && !crownBlock) ppos = a.chainPar[q];      // (a regular stage holds the K chains in order: q is the chain) requested first: the offset rows wait for it
     s.hx = reinterpret_cast<const VT *>(a.hx)[s.iv]; s.w = reinterpret_cast<const VT *>(a.w)[s.iv];
     s.yp = reinterpret_cast<const VT *>(a.yprev)[s.iv];
 #if RN_DUAL_ABL & 1
@@ -2903,13 +2914,18 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
     s.blo = *reinterpret_cast<const VT *>(a.blo + s.c);
     s.bhi = *reinterpret_cast<const VT *>(a.bhi + s.c);
 #endif
+    if (OFFS && !crownBlock) {
+        s.cnt = (T)(stageU - g.cs + 1);
+        s.o0 = *reinterpret_cast<const VT *>(a.off0 + (size_t)ppos * a.ny + s.c);
+        s.o1 = *reinterpret_cast<const VT *>(a.off1 + (size_t)ppos * a.ny + s.c);
+    }
 }
 // LAZY = 0: w is read, y+ and w_next are stored.  Device-resident batches of more than one iteration keep the accelerated dual
 // out of memory between their iterations -- the next sweep and the next dual update derive it from the two iterates (4 streams
 // instead of 5, and 21 MB of dirty lines less in front of the streaming kernel): LAZY = 3 (first iteration): w is read, w_next not
 // stored; LAZY = 1 (inner iterations): w derived, w_next not stored; LAZY = 2 (last iteration): w derived, and both w_t (wview)
 // and w_next stored, so that the state a caller can observe is what it always was.
-template <typename T, bool MATERIALIZE, int LAZY>
+template <typename T, bool MATERIALIZE, int LAZY, bool OFFS = false>
 __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualArgs<T> &a, T ln, DualAcc<T> &r) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
@@ -2925,7 +2941,8 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
         const T lo = k * s.blo[e];
         const T hi = (isXi && !isBox) ? s.bhi[e] : k * s.bhi[e];
         wcur[e] = (LAZY == 1 || LAZY == 2) ? extrap_elem(s.yp[e], s.w[e], a.lnCur) : s.w[e];
-        const DualOut<T> o = dual_elem<T, false>(s.hx[e], wcur[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
+        const T hxv = (OFFS && s.offs) ? k * cf_primal<T>(s.hx[e], s.cnt, s.o1[e], s.o0[e]) : s.hx[e];
+        const DualOut<T> o = dual_elem<T, false>(hxv, wcur[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
         yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
 #if !(RN_DUAL_ABL & 2)
         const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
@@ -2954,7 +2971,7 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
 }
 // PIPE = 1: one vector at a time;  PIPE = 2: double-buffered -- the loads of trip t+1 are requested before trip t is consumed, so
 // a wave always has a trip in flight (the kernel lives on memory-level parallelism: its VALU phase is a gap in the streams)
-template <typename T, bool MATERIALIZE, int PIPE, int LAZY>
+template <typename T, bool MATERIALIZE, int PIPE, int LAZY, bool OFFS = false>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualStageShape g) {
     __shared__ Partial sh_p[ELT_THREADS / 64];
     const T ln = (T)g.lnNext;
@@ -2975,18 +2992,18 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
     if (PIPE == 1) {
         for (int t = 0; t < g.trips; t++) {
             DualSlot<T> s;
-            dual_slot_load<T>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY>(s, a, ln, r);
+            dual_slot_load<T, OFFS>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(s, a, ln, r);
         }
     } else {
         DualSlot<T> sA, sB;
-        dual_slot_load<T>(sA, a, g, 0, jbase, cnt, nodeFirst, stageU, crownBlock);
+        dual_slot_load<T, OFFS>(sA, a, g, 0, jbase, cnt, nodeFirst, stageU, crownBlock);
         for (int t = 0; t < g.trips; t += 2) {
             const bool hasB = t + 1 < g.trips;
-            if (hasB) dual_slot_load<T>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY>(sA, a, ln, r);
-            if (t + 2 < g.trips) dual_slot_load<T>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
-            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY>(sB, a, ln, r);
+            if (hasB) dual_slot_load<T, OFFS>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(sA, a, ln, r);
+            if (t + 2 < g.trips) dual_slot_load<T, OFFS>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
+            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(sB, a, ln, r);
         }
     }
 #if RN_DUAL_ABL & 2

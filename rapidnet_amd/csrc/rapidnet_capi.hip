@@ -24,6 +24,7 @@
 #include "../../include/rapidnet.h"
 #include "../../include/rapidnet_debug.h"
 #include "fbe_kernels.hpp"
+#include "chain_kernels.hpp"
 #include "partition.hpp"
 
 #ifndef RN_FIXUP_BLOCKS
@@ -199,6 +200,7 @@ struct CtxBase {
     virtual int set_exchange_transport(int) = 0;
     virtual int set_exchange_overlap(int) = 0;
     virtual int set_fused_walk_dual(int) = 0;
+    virtual int set_sweep_form(int, int *) = 0;
     virtual int debug_peer_seq(unsigned int) = 0;
     virtual int fbe_counters(long *) = 0;
 };
@@ -335,6 +337,15 @@ struct Ctx : CtxBase {
                                  // soft bounds would otherwise pay checkpoint + replay on every batch of every control step)
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
+    // chain-fused form of the sweep's helper path (chain_kernels.hpp): 1 = used wherever it applies (single-GPU contexts, plain sweeps, trees whose
+    // crown fits one workgroup), 0 = the six-launch form everywhere (rn_set_sweep_form; RAPIDNET_CHAIN_FUSED=0)
+    int sweepForm = 1;
+    int cfState = -1;            // -1: not looked at yet, 0: the tree / the dimensions do not qualify, 1: buffers and launch shapes are ready
+    int cfCT = 1, cfSB = 0, cfSV = 0, cfSO = 0, cfParents = 0;
+    size_t cfLdsChain = 0, cfLdsCrown = 0;
+    T *d_cfCut = nullptr, *d_cfOff0 = nullptr, *d_cfOff1 = nullptr;
+    int *d_chainPar = nullptr;
+    bool hxPending = false;      // d_hx holds the partial primal P of the chain nodes (the next dual update adds the crown's offsets, or cf_finish does)
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
     T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
     T *d_tmp = nullptr;  // nodes*max(2nx,nu) staging for reference-layout get/set
@@ -738,6 +749,7 @@ struct Ctx : CtxBase {
         const long long want = (ntot() + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
         eltBlocks = (int)std::max<long long>(1, std::min<long long>(ELT_MAX_BLOCKS, want));
         dual_stage_setup();
+        (void)cf_ready();      // the chain-fused sweep's small buffers: here, so that no control step allocates (the leak check of controlAction)
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         return apg_reset();
     }
@@ -1227,6 +1239,71 @@ struct Ctx : CtxBase {
         launch_gemm<EPI_V>(d_RTp, nv, nv + nx, a.sk, nv + nx, a.v, nv, a.my, 2 * nv);
         launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, a.v, nv, a.lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
     }
+    // ---- chain-fused form (chain_kernels.hpp) -----------------------------------------------------------
+    // does the tree qualify, and if so: launch shapes, LDS limits, the children-sum / offset buffers and the chain -> parent table (once)
+    bool cf_ready() {
+        if (cfState >= 0) return cfState == 1;
+        cfState = 0;
+        if (const char *e = std::getenv("RAPIDNET_CHAIN_FUSED")) { if (std::atoi(e) == 0) return false; }
+#if RN_GEMM_SLAB
+        const int nx = d.nx, nu = d.nu, nv = d.nv, cs = chainStage;
+        if (cs < 1 || cs > CROWN_MAX_DEPTH) return false;                 // a tree that is one chain from the root has no crown to hand offsets down
+        const int nCrown = h_stageCum[cs], Lc = d.N - cs;
+        if (nCrown > 32 || Lc < 1 || Lc > CF_MAX_LC) return false;        // crown: at most two 16-column tiles in ONE workgroup; chain: two tiles
+        if (nv + nx > CF_THREADS || nu + nx > CF_THREADS) return false;   // a thread per component of the running sums
+        const int SB = slab_stride(pad4(nv + nx)), SV = slab_stride(pad4(nv)), SO = slab_stride(nu + nx);
+        const int CT = nCrown <= 16 ? 1 : 2;
+        const size_t ldsChain = (size_t)Lc * (std::max(SB, SO) + SV) * sizeof(T), ldsCrown = (size_t)CT * 16 * (SB + SV + SO) * sizeof(T);
+        if (ldsChain > 160 * 1024 || ldsCrown > 160 * 1024) return false;
+        if (SV + SO < nv + 2 * nx || SB + SV < nu + 2 * nx) return false; // k_crown_small keeps (rho, kappa, q) / (du, bw, x) of a node in those rows
+        // (the attribute belongs to the function, not to this context: always the device's whole LDS)
+        const void *fnCrown = CT == 1 ? (const void *)k_crown_small<T, 1> : (const void *)k_crown_small<T, 2>;
+        if ((ldsChain > 64 * 1024 && hipFuncSetAttribute((const void *)k_chain_sweep<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) ||
+            (ldsCrown > 64 * 1024 && hipFuncSetAttribute(fnCrown, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const int nP = h_stageCum[cs] - h_stageCum[cs - 1], K = h_stageCum[cs + 1] - h_stageCum[cs];
+        if (dalloc(&d_cfCut, (size_t)nP * (nv + 2 * nx) + 2) || dalloc(&d_cfOff0, (size_t)nP * ny) || dalloc(&d_cfOff1, (size_t)nP * ny) || dalloc(&d_chainPar, (size_t)K)) return false;
+        std::vector<int> par(K);
+        for (int c = 0; c < K; c++) par[c] = h_parent[h_stageCum[cs] + c] - h_stageCum[cs - 1];
+        if (hipMemcpy(d_chainPar, par.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
+        cfCT = CT; cfSB = SB; cfSV = SV; cfSO = SO; cfParents = nP; cfLdsChain = ldsChain; cfLdsCrown = ldsCrown;
+        cfState = 1;
+#endif
+        return cfState == 1;
+    }
+    // P -> Hx in place (and x, u of the chain nodes when the primal iterates are stored): every consumer of Hx other than k_dual_stage OFFS
+    void cf_finish(bool writePrimal) {
+        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
+        FinishArgs<T> f{d_hx, d_cfOff0, d_cfOff1, d_chainPar, d_sqrtp, d_dy, d_x, d_u, d.nx, d.nu, ny, cs, K, h_stageCum[cs], d.N, writePrimal ? 1 : 0};
+        const long long total = (long long)(d.N - cs) * K * ny;
+        const int blocks = (int)std::min<long long>((total + ELT_THREADS - 1) / ELT_THREADS, (long long)numCUs * 16);
+        hipLaunchKernelGGL(k_hx_finish<T>, dim3(blocks), dim3(ELT_THREADS), 0, stream, f);
+        hxPending = false;
+    }
+    // the helper path of a plain single-GPU sweep in the chain-fused form: chain workgroups, the cut parents' children sums (+ the previous
+    // iteration's bookkeeping workgroup), the crown workgroup; allowPending: the caller's next launch is a dual update that adds the offsets itself
+    int cf_helpers(const SweepArgs<T> &a0, bool allowPending) {
+        const int nx = d.nx, nu = d.nu, nv = d.nv, cs = chainStage;
+        SweepArgs<T> a = a0;
+        a.cutSums = d_cfCut; a.cutStage = cs; a.distTail = nullptr;
+        ChainArgs<T> c{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), cfSB, cfSV, cfSO, d.N - cs, a.hx};
+        hipLaunchKernelGGL(k_chain_sweep<T>, dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
+        FinArgs fin{};
+        const bool ride = pendingFin;      // single-GPU optimistic bookkeeping of the previous iteration's dual update (as in k_up_chain)
+        if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
+        hipLaunchKernelGGL((k_cut_partial_sums<T, false>), dim3(cfParents + (ride ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cfCut, cfParents, fin);
+        CrownArgs<T> cr{};
+        cr.gV = GemmArgs<T>{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), nullptr, nv + nx, a.writePrimal ? a.v : nullptr, nv, a.my, 2 * nv, d_prob, h_stageCum[cs], nullptr, 0};
+        cr.gL = GemmArgs<T>{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), nullptr, nv, nullptr, nu + nx, nullptr, 0, d_prob, h_stageCum[cs], nullptr, 0};
+        cr.SB = cfSB; cr.SV = cfSV; cr.SO = cfSO; cr.nCrown = h_stageCum[cs]; cr.off0 = d_cfOff0; cr.off1 = d_cfOff1;
+        if (cfCT == 1) hipLaunchKernelGGL((k_crown_small<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
+        else hipLaunchKernelGGL((k_crown_small<T, 2>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
+        hxPending = true;
+        if (!allowPending || a.writePrimal) cf_finish(a.writePrimal != 0);
+        return RN_OK;
+    }
     // crown handling of the forward sweep: 0 = crown launches of their own; 1 = every chain workgroup walks its crown path and
     // the first descendant chain of a crown node writes it; 2 (sharded) = crown nodes dealt round-robin to the workgroups
     int fold_crown_mode(int cs, bool sharded) const {
@@ -1253,7 +1330,7 @@ struct Ctx : CtxBase {
     // ONE pass over the operator blocks (k_stream_gemv NR = 2); the vector recursions and shared-operator products then run once per
     // right-hand side.  The first sweep's results go to the pair buffers (d_xdirB, d_udirB, d_hxDirB), the second's where a Hessian
     // sweep always leaves them (d_xdir, d_udir, d_hxDir).  Bitwise the results of two launch_sweep calls.
-    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true, const T *hessianInput2 = nullptr) {
+    int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true, const T *hessianInput2 = nullptr, bool allowPending = false) {
         SweepArgs<T> a = sweep_args();
         a.writePrimal = primalOut ? 1 : 0;
         if (hessianInput) {
@@ -1301,6 +1378,13 @@ struct Ctx : CtxBase {
         static const int gatherHere = [] { const char *e = std::getenv("RAPIDNET_ONESHOT_GATHER"); return e ? std::atoi(e) : 1; }();
         auto helpers = [&](SweepArgs<T> &a) -> int {
         e1 = prof_begin(1);
+        // the chain-fused form: plain sweeps of a single-GPU context whose crown fits one workgroup (chain_kernels.hpp)
+        if (sweepForm == 1 && phase == 0 && !hessianInput && !a.cutSums && !fuseReq && cf_ready()) {
+            const int rc = cf_helpers(a, allowPending);
+            prof_end(e1);
+            RN_HIP(hipGetLastError());
+            return rc;
+        }
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
         // sharded, cut right above the chains, few local chains per cut parent: one launch does the chain walks AND the cut
         // parents' local children sums (k_up_chain_cut)
@@ -1470,6 +1554,7 @@ struct Ctx : CtxBase {
     // w_t and w_next stored (always the materialising last iteration of a batch); 3 = w read, w_next not stored
     void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false, int lazy = 0) {
         if (flat || dualU == 0) {
+            if (hxPending) cf_finish(false);
             if (materialize) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             mainPartials = eltBlocks;
@@ -1478,6 +1563,15 @@ struct Ctx : CtxBase {
         mainPartials = dualBlocks;
         DualStageShape g = dshape;
         g.lnNext = h_lam[h_it + 1];   // ensure_tables(h_it + n) has run: the table covers every iteration of the batch
+        if (hxPending && lazy == 0 && !materialize) {    // chain-fused sweep: Hx is formed here from the partial primal and the crown's offsets
+            DualArgs<T> b = a;
+            b.off0 = d_cfOff0; b.off1 = d_cfOff1; b.chainPar = d_chainPar;
+            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, b, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, b, g);
+            hxPending = false;
+            return;
+        }
+        if (hxPending) cf_finish(false);
 #define RN_LAUNCH_DSTAGE(MAT, PIPE, LAZY) hipLaunchKernelGGL((k_dual_stage<T, MAT, PIPE, LAZY>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g)
 #define RN_LAUNCH_DSTAGE_P(PIPE)                                                                                          \
         switch (lazy) {                                                                                                \
@@ -1677,7 +1771,7 @@ struct Ctx : CtxBase {
             lazyIn = lazy && k > 0;
             fuseReq = !lazy && fuse_want(); fuseDone = false;
             if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { lazyIn = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
             fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
@@ -1823,6 +1917,15 @@ struct Ctx : CtxBase {
     int debug_peer_seq(unsigned int seq) override {      // test hook: the next exchange gets sequence number seq + 1 (all ranks alike)
         RN_CHECK(peerReady, RN_E_STATE, "rn_debug_peer_seq: connect the inboxes first");
         peerSeq = seq;
+        return RN_OK;
+    }
+    int set_sweep_form(int form, int *active) override {
+        RN_CHECK(form == 0 || form == 1, RN_E_ARG, "rn_set_sweep_form: 0 (six-launch form) or 1 (chain-fused where it applies)");
+        RN_HIP(hipSetDevice(device));
+        RN_HIP(hipStreamSynchronize(stream));
+        if (hxPending) cf_finish(false);
+        sweepForm = form;
+        if (active) *active = (sweepForm == 1 && cutStage <= 0 && cf_ready()) ? 1 : 0;
         return RN_OK;
     }
     int set_exchange_transport(int t) override {
@@ -2623,6 +2726,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
 int rn_set_exchange_overlap(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_exchange_overlap(on); }
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_fused_walk_dual(on); }
+int rn_set_sweep_form(rn_ctx *ctx, int form, int *active) { RN_GUARD(ctx); return ctx->impl->set_sweep_form(form, active); }
 int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }
