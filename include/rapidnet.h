@@ -387,13 +387,15 @@ int rn_set_exchange_overlap(rn_ctx *ctx, int on);
  * keeps the dual update a kernel of its own (the one the roofline target names). */
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on);
 /* Form of the sweep's helper path behind the streaming launch (SmpcController.cu:587-747: the vector recursions and the products with
- * the shared matrices).  1 (default): CHAIN-FUSED wherever it applies -- single-GPU contexts, plain sweeps, trees whose crown (the stages
- * above the K parallel chains) has at most 32 nodes and whose chains have at most 32: one workgroup per chain does the leaf-to-top sums,
- * both MFMA products and the local top-to-leaf sums of ITS chain in LDS, one workgroup does the crown, and the dual update adds the crown's
- * offsets (csrc/chain_kernels.hpp; four helper launches instead of five and 44 MB less through global memory per iteration on the
- * 493-scenario tree).  0: the six-launch form everywhere (up_chain | up_crown | gemm_vlv | down_chain).  The two forms associate the
- * sums along a chain differently: iterates agree to rounding, not bitwise.  Returns the form sweeps will use in `*active` (may be NULL):
- * 1 only if the context qualifies. */
+ * the shared matrices).  0 (default): the six-launch form (up_chain | up_crown | gemm_vlv | down_chain).  1: CHAIN-FUSED wherever it
+ * applies -- single-GPU contexts, plain sweeps, trees whose crown (the stages above the K parallel chains) has at most 32 nodes and whose
+ * chains have at most 32: one workgroup per chain (or pair of chains) does the leaf-to-top sums, both MFMA products and the local
+ * top-to-leaf sums of ITS chain in LDS, one workgroup does the crown, and the dual update adds the crown's offsets
+ * (csrc/chain_kernels.hpp: four helper launches instead of five, 44 MB less through global memory per iteration on the 493-scenario
+ * tree).  Opt-in because it is SLOWER on this part: the chain launch is 22 us shorter than the three it replaces, the crown -- a few nodes in
+ * one workgroup behind the children sums -- 33 us longer (DESIGN.md section 3 has the in-kernel phase times).  The two forms associate
+ * the sums along a chain differently: iterates agree to rounding, not bitwise.  `*active` (may be NULL) returns the form sweeps will
+ * use: 1 only if the context qualifies.  $RAPIDNET_CHAIN_FUSED=1 makes 1 the default of new contexts. */
 int rn_set_sweep_form(rn_ctx *ctx, int form, int *active);
 
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).

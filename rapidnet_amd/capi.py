@@ -540,7 +540,7 @@ class Solver:
         self._check(self.lib.rn_set_fused_walk_dual(self.h, int(bool(on))))
 
     def setSweepForm(self, form):
-        """0: the six-launch helper path everywhere; 1 (default): the chain-fused form where the context qualifies.  Returns 1 if sweeps will be chain-fused."""
+        """0 (default): the six-launch helper path everywhere; 1: the chain-fused form where the context qualifies (opt-in: measured slower).  Returns 1 if sweeps will be chain-fused."""
         act = C.c_int(0)
         self._check(self.lib.rn_set_sweep_form(self.h, int(form), C.byref(act)))
         return act.value

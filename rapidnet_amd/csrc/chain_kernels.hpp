@@ -120,6 +120,16 @@ __global__ void __launch_bounds__(CF_THREADS, 4) k_chain_sweep(SweepArgs<T> a, C
         const int t = tid;
         if (t < nv) {
             T rho = 0;
+            // the second partial m2 of the chain's last stages (k_stream_gemv's split last round lies within the last STREAM_SPLIT_STAGES stages; zero
+            // where a node was not split) -- as in k_up_chain: requested up front, no branch inside the batches of loads
+            T mx[STREAM_SPLIT_STAGES];
+#pragma unroll
+            for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
+                const int kk = Lc - 1 - j >= 0 ? Lc - 1 - j : 0;
+                const size_t node = nodeTop + (size_t)kk * K;
+                const bool has = Lc - 1 - j >= 0 && node >= (size_t)a.splitFirst;
+                mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
+            }
             for (int k0 = Lc - 1; k0 >= 0; k0 -= CF_PF) {
                 T b[CF_PF], m[CF_PF];
 #pragma unroll
@@ -127,9 +137,11 @@ __global__ void __launch_bounds__(CF_THREADS, 4) k_chain_sweep(SweepArgs<T> a, C
                     const int kk = k0 - j >= 0 ? k0 - j : 0;
                     const size_t node = nodeTop + (size_t)kk * K;
                     b[j] = a.beta[node * nv + t];
-                    T mv = a.my[node * 2 * nv + nv + t];
-                    if (node >= (size_t)a.splitFirst) mv += a.my2[(node - (size_t)a.splitFirst) * 2 * nv + nv + t];   // k_stream_gemv's split last round: (first half) + (second half)
-                    m[j] = mv;
+                    m[j] = a.my[node * 2 * nv + nv + t];
+                }
+                if (k0 == Lc - 1) {
+#pragma unroll
+                    for (int j = 0; j < STREAM_SPLIT_STAGES && j < CF_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }
 #pragma unroll
                 for (int j = 0; j < CF_PF; j++) {
@@ -191,10 +203,18 @@ __global__ void __launch_bounds__(CF_THREADS, 4) k_chain_sweep(SweepArgs<T> a, C
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const int gr = t * 16 + Mfma16<T>::row(lane, reg), grc = gr < c.mV ? gr : c.mV - 1;
-                    T mv = a.my[CF_NODE(ct) * 2 * nv + grc];
-                    if (CF_NODE(ct) >= (size_t)a.splitFirst) mv += a.my2[(CF_NODE(ct) - (size_t)a.splitFirst) * 2 * nv + grc];
-                    acc[ct][reg] = mv;
+                    acc[ct][reg] = a.my[CF_NODE(ct) * 2 * nv + grc];
                 }
+            if (a.splitFirst < a.nodes) {          // (uniform) the second partial m1 of the nodes of k_stream_gemv's split last round
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = t * 16 + Mfma16<T>::row(lane, reg), grc = gr < c.mV ? gr : c.mV - 1;
+                        const bool has = CF_NODE(ct) >= (size_t)a.splitFirst;
+                        acc[ct][reg] += has ? a.my2[(CF_NODE(ct) - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + grc] : (T)0;
+                    }
+            }
             cf_mfma<T, CF_KU>(acc, c.MV + (size_t)t * 16 + col + (size_t)kq * c.mpV, (size_t)4 * c.mpV, sB + colN[0] * SB + kq, sB + colN[1] * SB + kq, G);
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
@@ -393,6 +413,566 @@ __global__ void __launch_bounds__(CF_THREADS) k_crown_small(SweepArgs<T> a, Crow
             c.off1[(size_t)pos * ny + r] = o1;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// REGISTER-RESIDENT forms of the two kernels above, for operators of at most CFR_KSV / CFR_KSL k-steps (the Barcelona shapes: exactly 40
+// and 28) and at most 8 / 16 row tiles.  Measured with the forms above on the 493-scenario tree: k_chain_sweep 41 us, k_crown_small 35 us --
+// every group of four k-steps of a wave's MFMA loop waits for its A fragments' round trip to L2 (~1 us with so few waves in flight), ten
+// and seven times per product.  Here a wave requests ALL A fragments of its row tile with one batch of loads -- the v product's at the very
+// start of the kernel, so that they arrive during the running sums, the second product's when the first one's registers are free, in front
+// of its epilogue and the barrier -- and the MFMA loops read only registers and LDS.  One workgroup per CU (up to 256 registers per lane).
+// k_chain_sweep_reg<T, CPW>: CPW = 2 chains per workgroup when there are more chains than CUs (44 columns = three 16-column tiles: 92 % of
+// the MFMA columns live instead of 69 %, every A fragment used for two chains, ONE round of workgroups on the 493-scenario tree), 1 otherwise.
+constexpr int CFR_KSV = 40, CFR_KSL = 28;
+// RN_KTIMING builds (tools/ktiming_cf.py): phase stamps (100 MHz wall clock) of workgroups 0, 1, 2 and the last one, read back by rn_debug_ktiming:
+// rows 0-3 = k_chain_sweep_reg, row 4 = k_crown_small_reg (kernels.hpp keeps rows 0-3 for the slab kernels: one kind of launch per measurement)
+#ifdef RN_KTIMING
+#define CF_KT(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x == gridDim.x - 1 ? 3 : (int)blockIdx.x; if (b_ < 4) g_ktiming[b_ * 16 + (slot)] = wall_clock64(); } } while (0)
+#define CR_KT(slot) do { if (threadIdx.x == 0) g_ktiming[4 * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define CF_KT(slot) do { } while (0)
+#define CR_KT(slot) do { } while (0)
+#endif
+template <typename T, int KS>
+__device__ __forceinline__ void cfr_load_a(T (&A)[KS], const T *p, size_t step, int ks) {
+#pragma unroll
+    for (int s = 0; s < KS; s++) A[s] = p[(size_t)(s < ks ? s : ks - 1) * step];
+}
+// acc[c] += A (16 x 4 G, registers) * B_c (LDS), G groups of four k-steps; the B fragments of group g + 1 are requested in front of the MFMAs of group g
+template <typename T, int KS, int CT>
+__device__ __forceinline__ void cfr_mfma(typename Mfma16<T>::acc_t (&acc)[CT], const T (&A)[KS], const T *const (&Bp)[CT], int G) {
+    static_assert(KS % 4 == 0, "whole groups of four k-steps");
+    T b[2][4][CT];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < CT; c++) b[0][i][c] = Bp[c][i * 4];
+#pragma unroll
+    for (int g = 0; g < KS / 4; g++) {
+        if (g < G) {
+            if (g + 1 < G) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int c = 0; c < CT; c++) b[(g + 1) & 1][i][c] = Bp[c][((g + 1) * 4 + i) * 4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int c = 0; c < CT; c++) acc[c] = Mfma16<T>::run(A[g * 4 + i], b[g & 1][i][c], acc[c]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < G) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int c = 0; c < CT; c++) asm volatile("" ::"v"(b[(g + 1) & 1][i][c]));
+            }
+        }
+    }
+}
+constexpr int CFR_PF = 24;            // stages per batch of loads of the running sums in the register-resident kernel (256 registers: one batch for N - c* <= 24)
+template <typename T, int CPW>
+__global__ void __launch_bounds__(CF_THREADS, 2) k_chain_sweep_reg(SweepArgs<T> a, ChainArgs<T> c) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    constexpr int CT = CPW == 1 ? 2 : 3;     // 16-column tiles: Lc <= 32 (CPW = 1), 2 Lc <= 48 (CPW = 2; the host checks)
+    constexpr int NW = CF_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+    const int Lc = c.Lc, SB = c.SB, SV = c.SV, SO = c.SO;
+    const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny;
+    const int top = a.chainStage, K = a.K;
+    const int chain0 = (int)blockIdx.x * CPW;
+    const int nCh = K - chain0 < CPW ? K - chain0 : CPW;          // chains of this workgroup (the last one of an odd K: one)
+    const int R = nCh * Lc;                                          // live columns
+    T *sB = reinterpret_cast<T *>(cf_smem);                          // [CPW Lc][SB]; second product on: [CPW Lc][SO]
+    T *sV = sB + (size_t)CPW * Lc * (SB > SO ? SB : SO);             // [CPW Lc][SV]
+    T *sO = sB;
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (32-bit node and element indices: the host checks nodes * max(2 nv, ny) < 2^31)
+    const int node00 = a.tr.stageCum[top] + chain0;                  // column r = (chain ci, stage k): node00 + ci + k K,  ci = r / Lc, k = r % Lc
+    const int tilesV = (c.mV + 15) / 16, tilesL = (c.mL + 15) / 16;  // <= NW, <= 2 NW (the host checks)
+    const int ksV = c.kpV / 4, ksL = c.kpL / 4;                      // <= CFR_KSV, <= CFR_KSL
+    CF_KT(0);
+    // ---- the A fragments of the v product's row tile and the product's initial values m1_i: requested first, they arrive during phase A
+    T aV[CFR_KSV];
+    cfr_load_a<T, CFR_KSV>(aV, c.MV + (size_t)(wave < tilesV ? wave : 0) * 16 + col + (size_t)kq * c.mpV, (size_t)4 * c.mpV, ksV);
+    int colN[CT]; bool live[CT]; int nodeC[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int cn = ct * 16 + col;
+        live[ct] = cn < R;
+        colN[ct] = live[ct] ? cn : R - 1;
+        const int ci = colN[ct] / Lc;
+        nodeC[ct] = node00 + ci + (colN[ct] - ci * Lc) * K;
+    }
+    acc_t accV[CT];
+    {
+        const int t = wave < tilesV ? wave : 0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int gr = t * 16 + Mfma16<T>::row(lane, reg), grc = gr < c.mV ? gr : c.mV - 1;
+                accV[ct][reg] = a.my[nodeC[ct] * 2 * nv + grc];
+            }
+        if (a.splitFirst < a.nodes) {              // (uniform) the second partial m1 of the nodes of k_stream_gemv's split last round
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = t * 16 + Mfma16<T>::row(lane, reg), grc = gr < c.mV ? gr : c.mV - 1;
+                    const bool has = nodeC[ct] >= a.splitFirst;
+                    accV[ct][reg] += has ? a.my2[(nodeC[ct] - (has ? a.splitFirst : 0)) * 2 * nv + grc] : (T)0;
+                }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    CF_KT(1);
+    // ---- phase A: running sums leaf -> top, a thread per (chain, component)
+    {
+        const int per = nv + nx;
+        const int ci = tid / per, t = tid - ci * per;
+        if (ci < nCh) {
+            const int nodeTop = node00 + ci;
+            const T scale = (T)(-0.5) / a.tr.prob[nodeTop];          // p_i is the same along a chain: -1 / (2 p_i) goes onto the columns [s; kappa]
+            T *sBc = sB + ci * Lc * SB;
+            if (t < nv) {
+                T rho = 0;
+                T mx[STREAM_SPLIT_STAGES];           // the second partial m2 of the last stages (see k_chain_sweep)
+#pragma unroll
+                for (int j = 0; j < STREAM_SPLIT_STAGES; j++) {
+                    const int kk = Lc - 1 - j >= 0 ? Lc - 1 - j : 0;
+                    const int node = nodeTop + kk * K;
+                    const bool has = Lc - 1 - j >= 0 && node >= a.splitFirst;
+                    mx[j] = has ? a.my2[(node - (has ? a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
+                }
+                for (int k0 = Lc - 1; k0 >= 0; k0 -= CFR_PF) {
+                    T b[CFR_PF], m[CFR_PF];
+#pragma unroll
+                    for (int j = 0; j < CFR_PF; j++) {
+                        const int kk = k0 - j >= 0 ? k0 - j : 0;
+                        const int node = nodeTop + kk * K;
+                        b[j] = a.beta[node * nv + t];
+                        m[j] = a.my[node * 2 * nv + nv + t];
+                    }
+                    if (k0 == Lc - 1) {
+#pragma unroll
+                        for (int j = 0; j < STREAM_SPLIT_STAGES && j < CFR_PF; j++) m[j] += mx[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CFR_PF; j++) {
+                        if (k0 - j >= 0) {
+                            const T sv = b[j] + rho;
+                            rho = sv + m[j];
+                            sBc[(k0 - j) * SB + t] = scale * (a.structured ? rho : sv);
+                        }
+                    }
+                }
+                a.rkq[nodeTop * (nv + 2 * nx) + t] = rho;
+            } else {
+                const int j0 = t - nv;
+                T kap = 0, q = 0;
+                for (int k0 = Lc - 1; k0 >= 0; k0 -= CFR_PF) {
+                    T av[CFR_PF];
+#pragma unroll
+                    for (int j = 0; j < CFR_PF; j++) {
+                        const int kk = k0 - j >= 0 ? k0 - j : 0;
+                        av[j] = a.qa[(nodeTop + kk * K) * nx + j0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CFR_PF; j++) {
+                        if (k0 - j >= 0) {
+                            kap += q;
+                            sBc[(k0 - j) * SB + nv + j0] = scale * kap;
+                            q += av[j];
+                        }
+                    }
+                }
+                a.rkq[nodeTop * (nv + 2 * nx) + nv + j0] = kap;
+                a.rkq[nodeTop * (nv + 2 * nx) + nv + nx + j0] = q;
+            }
+        }
+        // zero where the products read what nobody writes: the K padding of the two B operands, k in [nv + nx, kpV) and [nv, kpL) (the operators'
+        // columns there are zero, but 0 * garbage is not 0); the columns beyond are never read
+        const int padB = c.kpV - per, padV = c.kpL - nv;
+        for (int i = tid; i < R * padB; i += CF_THREADS) sB[(i / padB) * SB + per + i % padB] = (T)0;
+        for (int i = tid; i < R * padV; i += CF_THREADS) sV[(i / padV) * SV + nv + i % padV] = (T)0;
+    }
+    CF_KT(2);
+    __syncthreads();
+    CF_KT(3);
+    // ---- phase B: v = m1 + RT (scaled [s; kappa])
+    T aL[2][CFR_KSL];
+    {
+        const int t = wave;
+        const T *Bp[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) Bp[ct] = sB + colN[ct] * SB + kq;
+        if (t < tilesV) cfr_mfma<T, CFR_KSV, CT>(accV, aV, Bp, ksV / 4);
+        CF_KT(4);
+        // the second product's A fragments (row tiles wave, wave + 8): their round trip overlaps the epilogue and the barrier
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int tl = wave + NW * j;
+            cfr_load_a<T, CFR_KSL>(aL[j], c.ML + (size_t)(tl < tilesL ? tl : 0) * 16 + col + (size_t)kq * c.mpL, (size_t)4 * c.mpL, ksL);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < tilesV) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                    if (live[ct] && gr < c.mV) {
+                        sV[colN[ct] * SV + gr] = accV[ct][reg];
+                        if (a.writePrimal) a.v[nodeC[ct] * nv + gr] = accV[ct][reg];
+                    }
+                }
+        }
+    }
+    CF_KT(5);
+    __syncthreads();
+    CF_KT(6);
+    // ---- phase C: [L v ; B L v] into LDS (over the [s; kappa] columns: last read in front of the barrier above)
+    {
+        const T *Bp[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) Bp[ct] = sV + colN[ct] * SV + kq;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int t = wave + NW * j;
+            if (t < tilesL) {
+                acc_t acc[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) acc[ct] = acc_t{0, 0, 0, 0};
+                cfr_mfma<T, CFR_KSL, CT>(acc, aL[j], Bp, ksL / 4);
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                        if (live[ct] && gr < c.mL) sO[colN[ct] * SO + gr] = acc[ct][reg];
+                    }
+            }
+        }
+    }
+    CF_KT(7);
+    // ---- phase D: prefix sums top -> leaf, a thread per (chain, component); the constants are requested in front of the barrier
+    {
+        const int w = nu + nx;
+        const int ci = tid / w, tc0 = tid - ci * w;
+        const bool on = ci < nCh;
+        const int tc = on ? tc0 : 0, cic = on ? ci : 0;
+        const bool isU = tc < nu;
+        const int j0 = isU ? 0 : tc - nu;
+        const int nodeTop = node00 + cic;
+        const T *sOc = sO + cic * Lc * SO;
+        T run = 0, xr = 0;
+        for (int k0 = 0; k0 < Lc; k0 += CFR_PF) {
+            T cst[CFR_PF];
+#pragma unroll
+            for (int j = 0; j < CFR_PF; j++) {
+                const int kk = k0 + j < Lc ? k0 + j : Lc - 1;
+                const int node = nodeTop + kk * K;
+                cst[j] = isU ? a.uhat[node * nu + tc] : a.eb[node * nx + j0];
+            }
+            if (k0 == 0) { __syncthreads(); CF_KT(8); }
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < CFR_PF; j++) {
+                    if (k0 + j < Lc) {
+                        const int o = (nodeTop + (k0 + j) * K) * ny;
+                        run += sOc[(k0 + j) * SO + tc];
+                        if (isU) c.p[o + 2 * nx + tc] = cst[j] + run;
+                        else {
+                            xr += cst[j] + run;
+                            c.p[o + j0] = xr;
+                            c.p[o + nx + j0] = xr;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    CF_KT(9);
+}
+// the crown workgroup with register-resident A fragments (see above): k_crown_small's steps with every dependent round trip to global memory
+// taken out of the workgroup's critical path that can be -- the first measurement of a single-workgroup crown was 35 us, of which the MFMAs
+// are 6: the rest were ~20 strided loops whose trips each waited for their own loads.  Here the inputs of the leaf-to-root step of the stage
+// above the chains are requested in batches of CRN_UB items per thread, and the constants of the root-to-leaf pass (uhat / eb, the scaling
+// of Hx, the parent) of all of a thread's items in ONE batch behind the second product.
+constexpr int CRN_UB = 6, CRN_DB = 7;
+template <typename T, int CT>
+__global__ void __launch_bounds__(CF_THREADS, 2) k_crown_small_reg(SweepArgs<T> a, CrownArgs<T> c) {
+    typedef typename Mfma16<T>::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+    const int SB = c.SB, SV = c.SV, SO = c.SO, nC = c.nCrown;
+    T *sB = reinterpret_cast<T *>(cf_smem);        // [CT * 16][SB]
+    T *sV = sB + (size_t)CT * 16 * SB;             // [CT * 16][SV]
+    T *sO = sV + (size_t)CT * 16 * SV;             // [CT * 16][SO]
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = CF_THREADS / 64;
+    const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, w3 = nv + 2 * nx, per = nv + nx;
+    const int cs = a.cutStage;
+    const GemmArgs<T> &gV = c.gV, &gL = c.gL;
+    const int tilesV = (gV.m + 15) / 16, tilesL = (gL.m + 15) / 16, ksV = gV.kp / 4, ksL = gL.kp / 4;
+    CR_KT(0);
+    T aV[CFR_KSV];
+    cfr_load_a<T, CFR_KSV>(aV, gV.M + (size_t)(wave < tilesV ? wave : 0) * 16 + col + (size_t)kq * gV.mp, (size_t)4 * gV.mp, ksV);
+    // the products' epilogue operands (m1_i, 1 / p_i)
+    int nodeC[CT]; bool live[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) { const int n = ct * 16 + col; live[ct] = n < nC; nodeC[ct] = live[ct] ? n : nC - 1; }
+    T auxv[CT][4], scale[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        scale[ct] = (T)(-0.5) / gV.prob[nodeC[ct]];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int gr = (wave < tilesV ? wave : 0) * 16 + Mfma16<T>::row(lane, reg);
+            auxv[ct][reg] = gV.aux[(size_t)nodeC[ct] * gV.ldaux + (gr < gV.m ? gr : gV.m - 1)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    CR_KT(1);
+    T *rk = sV;
+    const int RS = SV + SO;
+    // ---- leaf-to-root: stage c* - 1 from the children sums (batches of CRN_UB items per thread: loads first) ...
+    {
+        const int s0 = a.tr.stageCum[cs - 1], n1 = a.tr.stageCum[cs] - s0, total = n1 * per;
+        for (int i0 = tid; i0 < total; i0 += CF_THREADS * CRN_UB) {
+            T c0[CRN_UB], c1[CRN_UB], b0[CRN_UB], b1[CRN_UB];
+#pragma unroll
+            for (int u = 0; u < CRN_UB; u++) {
+                const int i = i0 + u * CF_THREADS;
+                const bool on = i < total;
+                const int pos = on ? i / per : 0, t = on ? i - pos * per : 0, node = s0 + pos;
+                if (t < nv) {
+                    c0[u] = a.cutSums[(size_t)pos * w3 + t]; c1[u] = 0;
+                    b0[u] = a.beta[(size_t)node * nv + t]; b1[u] = a.my[(size_t)node * 2 * nv + nv + t];
+                } else {
+                    const int j0 = t - nv;
+                    c0[u] = a.cutSums[(size_t)pos * w3 + nv + j0]; c1[u] = a.cutSums[(size_t)pos * w3 + nv + nx + j0];
+                    b0[u] = a.qa[(size_t)node * nx + j0]; b1[u] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CRN_UB; u++) {
+                const int i = i0 + u * CF_THREADS;
+                if (i < total) {
+                    const int pos = i / per, t = i - pos * per, node = s0 + pos;
+                    if (t < nv) {
+                        const T sv = b0[u] + c0[u];
+                        const T rho = sv + b1[u];
+                        sB[node * SB + t] = a.structured ? rho : sv;
+                        rk[node * RS + t] = rho;
+                    } else {
+                        const int j0 = t - nv;
+                        const T kap = c0[u] + c1[u];
+                        sB[node * SB + nv + j0] = kap;
+                        rk[node * RS + nv + j0] = kap;
+                        rk[node * RS + nv + nx + j0] = c1[u] + b0[u];
+                    }
+                }
+            }
+        }
+    }
+    CR_KT(2);
+    // ... the stages above it from their children (ascending order); a thread's first item has its own terms requested in front of the barrier
+    for (int k = cs - 2; k >= 0; k--) {
+        const int s0 = a.tr.stageCum[k], nk = a.tr.stageCum[k + 1] - s0, total = nk * per;
+        T own0 = 0, own1 = 0;
+        int ch0 = 0, nc = 0;
+        if (tid < total) {
+            const int node = s0 + tid / per, t = tid % per;
+            ch0 = a.tr.childStart[node]; nc = a.tr.childCount[node];
+            own0 = t < nv ? a.beta[(size_t)node * nv + t] : a.qa[(size_t)node * nx + (t - nv)];
+            own1 = t < nv ? a.my[(size_t)node * 2 * nv + nv + t] : (T)0;
+        }
+        __syncthreads();
+        for (int i = tid; i < total; i += CF_THREADS) {
+            const int node = s0 + i / per, t = i % per;
+            if (i != tid) {
+                ch0 = a.tr.childStart[node]; nc = a.tr.childCount[node];
+                own0 = t < nv ? a.beta[(size_t)node * nv + t] : a.qa[(size_t)node * nx + (t - nv)];
+                own1 = t < nv ? a.my[(size_t)node * 2 * nv + nv + t] : (T)0;
+            }
+            if (t < nv) {
+                T sum = 0;
+                for (int ch = 0; ch < nc; ch++) sum += rk[(ch0 + ch) * RS + t];
+                const T sv = own0 + sum;
+                const T rho = sv + own1;
+                sB[node * SB + t] = a.structured ? rho : sv;
+                rk[node * RS + t] = rho;
+            } else {
+                const int j0 = t - nv;
+                T kap = 0, q = 0;
+                for (int ch = 0; ch < nc; ch++) { const T qc = rk[(ch0 + ch) * RS + nv + nx + j0]; kap += rk[(ch0 + ch) * RS + nv + j0] + qc; q += qc; }
+                sB[node * SB + nv + j0] = kap;
+                rk[node * RS + nv + j0] = kap;
+                rk[node * RS + nv + nx + j0] = q + own0;
+            }
+        }
+    }
+    __syncthreads();
+    CR_KT(3);
+    {   // zero where the products read what nobody writes: the K padding of the B operands' live columns (rk, which lay over sV, is dead)
+        const int padB = gV.kp - per, padV = gL.kp - nv;
+        for (int i = tid; i < nC * padB; i += CF_THREADS) sB[(i / padB) * SB + per + i % padB] = (T)0;
+        for (int i = tid; i < nC * padV; i += CF_THREADS) sV[(i / padV) * SV + nv + i % padV] = (T)0;
+    }
+    __syncthreads();
+    CR_KT(4);
+    // ---- the two products (wide_product's epilogues: v = m1 - acc / (2 p), then [L v; B L v])
+    T aL[2][CFR_KSL];
+    {
+        acc_t acc[CT];
+        const int t = wave;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[ct] = acc_t{0, 0, 0, 0};
+        const T *Bp[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) Bp[ct] = sB + nodeC[ct] * SB + kq;
+        if (t < tilesV) cfr_mfma<T, CFR_KSV, CT>(acc, aV, Bp, ksV / 4);
+        CR_KT(5);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int tl = wave + NW * j;
+            cfr_load_a<T, CFR_KSL>(aL[j], gL.M + (size_t)(tl < tilesL ? tl : 0) * 16 + col + (size_t)kq * gL.mp, (size_t)4 * gL.mp, ksL);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < tilesV) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                    const T r = auxv[ct][reg] + scale[ct] * acc[ct][reg];
+                    if (gr < gV.m && live[ct]) {
+                        if (gV.out) gV.out[(size_t)nodeC[ct] * gV.ldout + gr] = r;
+                        sV[nodeC[ct] * SV + gr] = r;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    CR_KT(6);
+    {
+        const T *Bp[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) Bp[ct] = sV + nodeC[ct] * SV + kq;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int t = wave + NW * j;
+            if (t < tilesL) {
+                acc_t acc[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) acc[ct] = acc_t{0, 0, 0, 0};
+                cfr_mfma<T, CFR_KSL, CT>(acc, aL[j], Bp, ksL / 4);
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                        if (gr < gL.m && live[ct]) sO[nodeC[ct] * SO + gr] = acc[ct][reg];
+                    }
+            }
+        }
+    }
+    CR_KT(7);
+    // the root-to-leaf pass: item i = (crown node, component of [u | x]); a thread's items tid, tid + 512, ...; the first CRN_DB of them have their
+    // constants requested here, behind the second product's MFMAs (its registers are free) and in front of the barrier
+    const int wd = nu + nx, nItems = nC * wd;
+    T dCst[CRN_DB], dF0[CRN_DB], dF1[CRN_DB];
+    int dNode[CRN_DB], dPar[CRN_DB], dStage[CRN_DB];
+#pragma unroll
+    for (int u = 0; u < CRN_DB; u++) {
+        const int i = tid + u * CF_THREADS;
+        const bool on = i < nItems;
+        const int node = on ? i / wd : 0, t = on ? i - node * wd : 0;
+        const int k = a.tr.stageOf[node];
+        const T *dy = a.tr.dy + (size_t)k * ny;
+        const T sp = a.tr.sqrtp[node];
+        dNode[u] = on ? node : -1; dPar[u] = a.tr.parent[node]; dStage[u] = k;
+        if (t < nu) { dCst[u] = a.uhat[(size_t)node * nu + t]; dF0[u] = sp * dy[2 * nx + t]; dF1[u] = (T)0; }
+        else { const int j0 = t - nu; dCst[u] = a.eb[(size_t)node * nx + j0]; dF0[u] = sp * dy[j0]; dF1[u] = sp * dy[nx + j0]; }
+    }
+    CR_KT(8);
+    __syncthreads();
+    CR_KT(9);
+    // ---- root-to-leaf over the crown, stage by stage; du, bw, x of the crown nodes in LDS ([node][nu + 2 nx] over sB and sV, both dead by now)
+    T *dn = sB;
+    const int DS = SB + SV;
+    for (int k = 0; k < cs; k++) {
+#pragma unroll
+        for (int u = 0; u < CRN_DB; u++) {
+            if (dNode[u] >= 0 && dStage[u] == k) {
+                const int node = dNode[u], par = dPar[u], t = tid + u * CF_THREADS - node * wd;
+                if (t < nu) {
+                    const T wanc = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : dn[par * DS + t];
+                    const T uv = dCst[u] + wanc + sO[node * SO + t];
+                    dn[node * DS + t] = uv - dCst[u];
+                    a.u[(size_t)node * nu + t] = uv;
+                    a.hx[(size_t)node * ny + 2 * nx + t] = dF0[u] * uv;
+                } else {
+                    const int j0 = t - nu;
+                    const T bw = (par < 0 ? a.bw0[j0] : dn[par * DS + nu + j0]) + sO[node * SO + nu + j0];
+                    const T xv = (par < 0 ? a.curX[j0] : dn[par * DS + nu + nx + j0]) + dCst[u] + bw;
+                    dn[node * DS + nu + j0] = bw;
+                    dn[node * DS + nu + nx + j0] = xv;
+                    a.bw[(size_t)node * nx + j0] = bw;
+                    a.x[(size_t)node * nx + j0] = xv;
+                    a.hx[(size_t)node * ny + j0] = dF0[u] * xv;
+                    a.hx[(size_t)node * ny + nx + j0] = dF1[u] * xv;
+                }
+            }
+        }
+        // (crowns with more than CRN_DB * 512 items: the rest with their loads where they are used)
+        for (int i = tid + CRN_DB * CF_THREADS; i < nItems; i += CF_THREADS) {
+            const int node = i / wd, t = i - node * wd;
+            if (a.tr.stageOf[node] != k) continue;
+            const int par = a.tr.parent[node];
+            const T sp = a.tr.sqrtp[node];
+            const T *dy = a.tr.dy + (size_t)k * ny;
+            if (t < nu) {
+                const T wanc = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : dn[par * DS + t];
+                const T uh = a.uhat[(size_t)node * nu + t];
+                const T uv = uh + wanc + sO[node * SO + t];
+                dn[node * DS + t] = uv - uh;
+                a.u[(size_t)node * nu + t] = uv;
+                a.hx[(size_t)node * ny + 2 * nx + t] = sp * dy[2 * nx + t] * uv;
+            } else {
+                const int j0 = t - nu;
+                const T bw = (par < 0 ? a.bw0[j0] : dn[par * DS + nu + j0]) + sO[node * SO + nu + j0];
+                const T xv = (par < 0 ? a.curX[j0] : dn[par * DS + nu + nx + j0]) + a.eb[(size_t)node * nx + j0] + bw;
+                dn[node * DS + nu + j0] = bw;
+                dn[node * DS + nu + nx + j0] = xv;
+                a.bw[(size_t)node * nx + j0] = bw;
+                a.x[(size_t)node * nx + j0] = xv;
+                a.hx[(size_t)node * ny + j0] = sp * dy[j0] * xv;
+                a.hx[(size_t)node * ny + nx + j0] = sp * dy[nx + j0] * xv;
+            }
+        }
+        __syncthreads();
+    }
+    CR_KT(10);
+    {
+        const int s0 = a.tr.stageCum[cs - 1], n1 = a.tr.stageCum[cs] - s0;
+        for (int i = tid; i < n1 * ny; i += CF_THREADS) {
+            const int pos = i / ny, r = i - pos * ny, node = s0 + pos;
+            T o0, o1;
+            if (r < 2 * nx) { const int j0 = r < nx ? r : r - nx; o0 = dn[node * DS + nu + nx + j0]; o1 = dn[node * DS + nu + j0]; }
+            else { o0 = dn[node * DS + (r - 2 * nx)]; o1 = (T)0; }
+            c.off0[(size_t)pos * ny + r] = o0;
+            c.off1[(size_t)pos * ny + r] = o1;
+        }
+    }
+    CR_KT(11);
 }
 
 // ------------------------------------------------------------------------------------------------------

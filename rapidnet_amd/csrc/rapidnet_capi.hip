@@ -337,11 +337,13 @@ struct Ctx : CtxBase {
                                  // soft bounds would otherwise pay checkpoint + replay on every batch of every control step)
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
-    // chain-fused form of the sweep's helper path (chain_kernels.hpp): 1 = used wherever it applies (single-GPU contexts, plain sweeps, trees whose
-    // crown fits one workgroup), 0 = the six-launch form everywhere (rn_set_sweep_form; RAPIDNET_CHAIN_FUSED=0)
-    int sweepForm = 1;
+    // chain-fused form of the sweep's helper path (chain_kernels.hpp; opt-in: measured slower): 1 = used wherever it applies
+    // (single-GPU contexts, plain sweeps, trees whose crown fits one workgroup), 0 (default) = the six-launch form everywhere
+    // (rn_set_sweep_form; RAPIDNET_CHAIN_FUSED=1 makes 1 the default of new contexts, for runs of whole test files in that form)
+    int sweepForm = 0;
     int cfState = -1;            // -1: not looked at yet, 0: the tree / the dimensions do not qualify, 1: buffers and launch shapes are ready
     int cfCT = 1, cfSB = 0, cfSV = 0, cfSO = 0, cfParents = 0;
+    int cfReg = 0, cfCPW = 1;    // register-resident forms of the two kernels (operators of at most 40 / 28 k-steps); chains per workgroup
     size_t cfLdsChain = 0, cfLdsCrown = 0;
     T *d_cfCut = nullptr, *d_cfOff0 = nullptr, *d_cfOff1 = nullptr;
     int *d_chainPar = nullptr;
@@ -749,7 +751,8 @@ struct Ctx : CtxBase {
         const long long want = (ntot() + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
         eltBlocks = (int)std::max<long long>(1, std::min<long long>(ELT_MAX_BLOCKS, want));
         dual_stage_setup();
-        (void)cf_ready();      // the chain-fused sweep's small buffers: here, so that no control step allocates (the leak check of controlAction)
+        if (const char *e = std::getenv("RAPIDNET_CHAIN_FUSED")) sweepForm = std::atoi(e) != 0 ? 1 : 0;
+        if (sweepForm == 1) (void)cf_ready();      // the chain-fused sweep's small buffers: here, so that no control step allocates (the leak check of controlAction)
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         return apg_reset();
     }
@@ -1244,7 +1247,6 @@ struct Ctx : CtxBase {
     bool cf_ready() {
         if (cfState >= 0) return cfState == 1;
         cfState = 0;
-        if (const char *e = std::getenv("RAPIDNET_CHAIN_FUSED")) { if (std::atoi(e) == 0) return false; }
 #if RN_GEMM_SLAB
         const int nx = d.nx, nu = d.nu, nv = d.nv, cs = chainStage;
         if (cs < 1 || cs > CROWN_MAX_DEPTH) return false;                 // a tree that is one chain from the root has no crown to hand offsets down
@@ -1264,6 +1266,23 @@ struct Ctx : CtxBase {
             return false;
         }
         const int nP = h_stageCum[cs] - h_stageCum[cs - 1], K = h_stageCum[cs + 1] - h_stageCum[cs];
+        // the register-resident forms: every wave holds the A fragments of its row tiles (RAPIDNET_CF_REG=0: the forms that stream them from L2)
+        cfReg = (pad4(nv + nx) / 4 <= CFR_KSV && pad4(nv) / 4 <= CFR_KSL && (nv + 15) / 16 <= CF_THREADS / 64 && (nu + nx + 15) / 16 <= 2 * (CF_THREADS / 64)) ? 1 : 0;
+        if ((long long)d.nodes * std::max(std::max(2 * nv, ny), nv + 2 * nx) >= (1ll << 31)) cfReg = 0;     // k_chain_sweep_reg indexes with 32-bit integers
+        if (const char *e = std::getenv("RAPIDNET_CF_REG")) { if (std::atoi(e) == 0) cfReg = 0; }
+        cfCPW = 1;
+        if (cfReg) {
+            // two chains per workgroup when one round of one-chain workgroups would not hold them (one workgroup per CU: 256 registers per lane)
+            if (K > numCUs && 2 * Lc <= 48 && 2 * (nv + nx) <= CF_THREADS && 2 * (nu + nx) <= CF_THREADS && 2 * ldsChain <= 160 * 1024) cfCPW = 2;
+            if (const char *e = std::getenv("RAPIDNET_CF_CPW")) { const int v = std::atoi(e); if (v == 1) cfCPW = 1; }    // tuning runs
+            const void *fnChain = cfCPW == 2 ? (const void *)k_chain_sweep_reg<T, 2> : (const void *)k_chain_sweep_reg<T, 1>;
+            const void *fnCrownR = CT == 1 ? (const void *)k_crown_small_reg<T, 1> : (const void *)k_crown_small_reg<T, 2>;
+            if ((cfCPW * ldsChain > 64 * 1024 && hipFuncSetAttribute(fnChain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) ||
+                (ldsCrown > 64 * 1024 && hipFuncSetAttribute(fnCrownR, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
+                (void)hipGetLastError();
+                cfReg = 0; cfCPW = 1;
+            }
+        }
         if (dalloc(&d_cfCut, (size_t)nP * (nv + 2 * nx) + 2) || dalloc(&d_cfOff0, (size_t)nP * ny) || dalloc(&d_cfOff1, (size_t)nP * ny) || dalloc(&d_chainPar, (size_t)K)) return false;
         std::vector<int> par(K);
         for (int c = 0; c < K; c++) par[c] = h_parent[h_stageCum[cs] + c] - h_stageCum[cs - 1];
@@ -1289,7 +1308,9 @@ struct Ctx : CtxBase {
         SweepArgs<T> a = a0;
         a.cutSums = d_cfCut; a.cutStage = cs; a.distTail = nullptr;
         ChainArgs<T> c{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), cfSB, cfSV, cfSO, d.N - cs, a.hx};
-        hipLaunchKernelGGL(k_chain_sweep<T>, dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
+        if (cfReg && cfCPW == 2) hipLaunchKernelGGL((k_chain_sweep_reg<T, 2>), dim3((a.K + 1) / 2), dim3(CF_THREADS), 2 * cfLdsChain, stream, a, c);
+        else if (cfReg) hipLaunchKernelGGL((k_chain_sweep_reg<T, 1>), dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
+        else hipLaunchKernelGGL(k_chain_sweep<T>, dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
         FinArgs fin{};
         const bool ride = pendingFin;      // single-GPU optimistic bookkeeping of the previous iteration's dual update (as in k_up_chain)
         if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
@@ -1298,7 +1319,9 @@ struct Ctx : CtxBase {
         cr.gV = GemmArgs<T>{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), nullptr, nv + nx, a.writePrimal ? a.v : nullptr, nv, a.my, 2 * nv, d_prob, h_stageCum[cs], nullptr, 0};
         cr.gL = GemmArgs<T>{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), nullptr, nv, nullptr, nu + nx, nullptr, 0, d_prob, h_stageCum[cs], nullptr, 0};
         cr.SB = cfSB; cr.SV = cfSV; cr.SO = cfSO; cr.nCrown = h_stageCum[cs]; cr.off0 = d_cfOff0; cr.off1 = d_cfOff1;
-        if (cfCT == 1) hipLaunchKernelGGL((k_crown_small<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
+        if (cfReg && cfCT == 1) hipLaunchKernelGGL((k_crown_small_reg<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
+        else if (cfReg) hipLaunchKernelGGL((k_crown_small_reg<T, 2>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
+        else if (cfCT == 1) hipLaunchKernelGGL((k_crown_small<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
         else hipLaunchKernelGGL((k_crown_small<T, 2>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
         hxPending = true;
         if (!allowPending || a.writePrimal) cf_finish(a.writePrimal != 0);

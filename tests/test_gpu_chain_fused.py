@@ -60,6 +60,16 @@ def test_chain_fused_sweep_matches_the_six_launch_form_and_the_oracle(name, stru
     assert out[1][2] == out[0][2]
 
 
+@pytest.mark.parametrize("name,structured,precision,env", [("medium", False, "f64", {"RAPIDNET_CF_REG": "0"}), ("small2", False, "f64", {"RAPIDNET_CF_REG": "0"}),
+                                                           ("barcelona31", False, "f64", {"RAPIDNET_CF_REG": "0"}), ("barcelona31", True, "f32", {"RAPIDNET_CF_REG": "0"})])
+def test_the_kernels_that_stream_their_operator_fragments_from_l2(monkeypatch, name, structured, precision, env):
+    """operators of at most 40 / 28 k-steps take the register-resident kernels (k_chain_sweep_reg, k_crown_small_reg); larger ones ("tall" above)
+    and RAPIDNET_CF_REG=0 the ones whose MFMA loops stream the A fragments from L2 (k_chain_sweep, k_crown_small)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_chain_fused_sweep_matches_the_six_launch_form_and_the_oracle(name, structured, precision)
+
+
 def test_shapes_outside_the_conditions_take_the_six_launch_form():
     # one chain from the root (no crown), also with N = 1; a crown of 127 nodes; more components per node than a workgroup has threads
     for name in ("toy", "horizon1", "deep", "widecrown"):
