@@ -1863,7 +1863,8 @@ struct Ctx : CtxBase {
     int set_fused_walk_dual(int on) override { RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_fused_walk_dual: 0 or 1"); fuseEnv = on; return RN_OK; }
     bool fuse_want() {
         if (fuseEnv < 0) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseEnv = e ? (std::atoi(e) != 0) : 0; }
-        return fuseEnv != 0 && dualU != 0 && !prof;
+        // (a context whose sweeps are chain-fused has no forward walk to fuse the dual update with: that form takes precedence)
+        return fuseEnv != 0 && dualU != 0 && !prof && !(sweepForm == 1 && cutStage <= 0 && cf_ready());
     }
     hipStream_t commStream = nullptr;
     hipEvent_t evCommFork = nullptr, evCommJoin = nullptr;
