@@ -17,7 +17,7 @@ for step in "$@"; do
     guard)   # whole test files under the buffer guard (RAPIDNET_GUARD=1: red zones + NaN poison) in one process, the round's kernels among them
              timeout -k 10 1000 python tools/guard_suite.py -m gpu tests/test_gpu_slab_kernels.py tests/test_gpu_sharded_batched.py tests/test_gpu_fbe_nama.py tests/test_gpu_lazy_dual.py \
                  tests/test_gpu_random_shapes.py tests/test_gpu_parity.py tests/test_golden_synthetic.py tests/test_gpu_closed_loop.py tests/test_reference_barcelona30.py \
-                 tests/test_nonuniform_trees.py tests/test_gpu_fullsize.py tests/test_gpu_oneshot.py tests/test_gpu_comm_timeout.py tests/test_gpu_device_pointer.py tests/test_gpu_fused_walk_dual.py > $O/guard_suite.log 2>&1; rc=$?
+                 tests/test_nonuniform_trees.py tests/test_gpu_fullsize.py tests/test_gpu_oneshot.py tests/test_gpu_comm_timeout.py tests/test_gpu_device_pointer.py tests/test_gpu_fused_walk_dual.py tests/test_gpu_chain_fused.py > $O/guard_suite.log 2>&1; rc=$?
              tail -4 $O/guard_suite.log; [ $rc -eq 0 ] || exit $rc ;;
     sq)      RAPIDNET_SLAB_LDS=0 bash tools/collect_sq.sh l2 || exit 1 ;;
     probes)  timeout -k 10 120 tools/probes/probe_chain_layout 2>&1 | tee $O/chain_layout_probe.txt
