@@ -931,7 +931,7 @@ def main():
         # opt-in variant in the SAME context (same buffers: two contexts of one process differ by up to 5 % through the placement of their
         # buffers alone): the forward walk and the dual update in one launch (rn_set_fused_walk_dual), `repeats` regions, then off again
         fused = None
-        if fused_ab and not sharded and not structured and rep:
+        if fused_ab and not sharded and rep:
             try:
                 s.setFusedWalkDual(1)
                 iterate(40)
@@ -953,6 +953,32 @@ def main():
                                  "roofline target names it)"}
             except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
                 fused = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the other opt-in form of the helper path, same context, same protocol: one workgroup per chain (pair of chains) + one for the crown
+        # (rn_set_sweep_form; csrc/chain_kernels.hpp) -- iterates agree with the six-launch form to rounding, so the context's state simply carries on
+        chain_fused = None
+        if fused_ab and not sharded and not structured and rep and hasattr(s, "setSweepForm"):
+            try:
+                if s.setSweepForm(1) == 1:
+                    iterate(40)
+                    crep = []
+                    for _ in range(len(rep)):
+                        barrier()
+                        t0 = time.perf_counter()
+                        iterate(steps)
+                        barrier()
+                        crep.append(time.perf_counter() - t0)
+                    cm, um = float(np.median(crep)), float(np.median(rep))
+                    chain_fused = {"value": steps / cm, "ms_per_step": 1e3 * cm / steps, "ms_per_step_min": 1e3 * min(crep) / steps, "ms_per_step_max": 1e3 * max(crep) / steps,
+                                   "regions": len(crep), "same_context_six_launches": {"ms_per_step": 1e3 * um / steps, "regions": len(rep)}, "speedup": um / cm,
+                                   "what": "rn_set_sweep_form(ctx, 1): k_chain_sweep_reg + k_cut_partial_sums + k_crown_small_reg, the crown's offsets added inside k_dual_stage "
+                                           "(4 helper launches instead of 5; iterates within 1e-11 of the six-launch form); timed in the headline's own context; opt-in because it is slower"}
+                else:
+                    chain_fused = {"error": "the context does not qualify (crown of more than 32 nodes, chains of more than 32, or one chain from the root)"}
+                s.setSweepForm(0)
+                iterate(40)
+                s.synchronize()
+            except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
+                chain_fused = {"error": "%s: %s" % (type(e).__name__, e)}
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
         ctrl_ms = None
         if not sharded and control_step:
@@ -1106,7 +1132,7 @@ def main():
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
-               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res, "fused_walk_dual": fused}
+               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res, "fused_walk_dual": fused, "chain_fused_sweep": chain_fused}
         s.close()
         return res
 
@@ -1131,7 +1157,9 @@ def main():
         struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=args.repeats)
     elif not sharded and not args.dense_only:
         try:      # the opt-in mode rides along: a failure there is reported in the line, it does not take the headline with it
-            struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=0)
+            # (the headline workload: with the repeat regions and the same-context A/B of the fused walk + dual update, as in the dense run)
+            sab = not args.traffic_probe and args.workload == "barcelona493"
+            struct = run_mode(True, args.steps, args.warmup, args.profile_steps, repeats=args.repeats if sab else 0, fused_ab=sab)
         except Exception as e:   # noqa: BLE001
             struct_error = "%s: %s" % (type(e).__name__, e)
     head = struct if args.structured else dense
@@ -1181,10 +1209,16 @@ def main():
             out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",
                                                                "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
             out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
+            if struct.get("spread"):
+                out["structured_mode"]["timing_spread"] = struct["spread"]
+            if struct.get("fused_walk_dual"):      # rn_set_fused_walk_dual in the structured context (same-context A/B, as for the dense headline)
+                out["structured_mode"]["fused_walk_dual"] = {k: v for k, v in struct["fused_walk_dual"].items() if k != "what"}
         if struct_error:
             out["structured_mode"] = {"error": struct_error}
         if dense is not None and dense.get("fused_walk_dual"):
             out["fused_walk_dual"] = dense["fused_walk_dual"]
+        if dense is not None and dense.get("chain_fused_sweep"):
+            out["chain_fused_sweep"] = dense["chain_fused_sweep"]
         if head.get("per_rank"):
             out["per_rank"] = head["per_rank"]
         if args.worker:   # under a supervisor (N > 1): the headline is on record from here on -- a first, partial line; the supervisor keeps
