@@ -1631,12 +1631,8 @@ struct Ctx : CtxBase {
         a.regen = RN_DUAL_REGEN; a.stageOf = d_stageOf; a.sqrtp = d_sqrtp; a.dy = d_dy; a.blo = d_blo; a.bhi = d_bhi;
         return a;
     }
+    int lamUploaded = 0;   // leading entries of h_lam that are on the device (0 after every restart of the theta recursion)
     int ensure_tables(int upto) {  // lambda table and history capacity for iterations [0, upto]
-        while ((int)h_lam.size() <= upto + 1) {   // theta recursion, SmpcController.cu:1513-1520
-            h_lam.push_back(theta1 * (1.0 / theta0 - 1.0));
-            theta0 = theta1;
-            theta1 = 0.5 * (std::sqrt(std::pow(theta1, 4) + 4 * std::pow(theta1, 2)) - std::pow(theta1, 2));
-        }
         if (upto + 2 > lamCap) {
             const int cap = std::max(1024, 2 * (upto + 2));
             double *nl = nullptr, *nh = nullptr, *np = nullptr;
@@ -1650,10 +1646,19 @@ struct Ctx : CtxBase {
                 RN_HIP(hipMemcpy(np, d_histParts, (size_t)4 * histCap * sizeof(double), hipMemcpyDeviceToDevice));
             }
             d_lam = nl; d_hist = nh; d_histParts = np; lamCap = cap; histCap = cap;   // old arrays are freed with the context
+            lamUploaded = 0;
         }
-        // (re)upload the table prefix that may have grown
-        RN_HIP(hipMemcpyAsync(d_lam, h_lam.data(), std::min((size_t)lamCap, h_lam.size()) * sizeof(double), hipMemcpyHostToDevice, stream));
-        RN_HIP(hipStreamSynchronize(stream));   // h_lam may be re-allocated by the next call
+        // the theta recursion (SmpcController.cu:1513-1520) is a fixed sequence: the table is filled up to the device array's capacity at once
+        // and uploaded ONCE per restart, so that a batch in steady state starts without a copy and a host sync of its own
+        while ((int)h_lam.size() < lamCap) {
+            h_lam.push_back(theta1 * (1.0 / theta0 - 1.0));
+            theta0 = theta1;
+            theta1 = 0.5 * (std::sqrt(std::pow(theta1, 4) + 4 * std::pow(theta1, 2)) - std::pow(theta1, 2));
+        }
+        if (lamUploaded >= upto + 2) return RN_OK;
+        RN_HIP(hipMemcpyAsync(d_lam, h_lam.data(), (size_t)lamCap * sizeof(double), hipMemcpyHostToDevice, stream));
+        RN_HIP(hipStreamSynchronize(stream));   // (pageable source)
+        lamUploaded = lamCap;
         return RN_OK;
     }
     int apg_reset() override {
@@ -1668,7 +1673,7 @@ struct Ctx : CtxBase {
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
         poisoned = false; lazyIn = false; carryTail = false; pendingFin = false;
-        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
+        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
     // warm start: keep the duals of the previous control step, restart the momentum (theta = {1,1} => w_0 = y+)
@@ -1676,7 +1681,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipMemcpyAsync(p_xi, p_upd, (size_t)ntot() * sizeof(T), hipMemcpyDeviceToDevice, stream));   // y := y+
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
-        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear();
+        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         acc_ready = false;   // the first iteration re-derives w_0 = (1 + 0) y+ - 0 y
         return ensure_tables(0);
     }
