@@ -1273,7 +1273,10 @@ struct GemmArgs {
     const T *prob;
     int nodes;
     // EPI_V: the nodes >= auxSplit have a second partial m1 in aux2[(i - auxSplit) * ldaux] (k_stream_gemv's split last round)
-    const T *aux2; int auxSplit;
+    const T *aux2; int auxSplit;    // the same operator in MFMA FRAGMENT ORDER (nullptr: not used): [16-row tile][pair of k-steps][lane][2] -- lane (row = lane & 15, kq = lane >> 4)
+    // of tile t finds its A operands of the k-steps 2p and 2p + 1 side by side at ((t * kp / 8 + p) * 64 + lane) * 2, so a wave requests ONE contiguous
+    // 16-byte-per-lane kilobyte (fp32: 512 bytes) where the column-major copy takes two requests of four 128-byte lines each
+    const T *Mf;
 };
 // the auxiliary operand of node i, row r (EPI_V: m1, both partials of a split node added; EPI_Z: e)
 template <typename T, int EPI>
@@ -1435,11 +1438,22 @@ __device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, 
 // operators are stored with K padded by zero columns to a whole number of groups (host: pad_k), the LDS slab is zero beyond
 // k, and the prefetches past the last group re-read the last group (a scalar min on the group index, no branch).
 // Same order of accumulation over k as every earlier version of these kernels.
-template <typename T, int TG, int CT, int KU>
+// FRAG: Ap[j] points at the tile's data in the operator's fragment-ordered copy (GemmArgs::Mf: this lane's pair of k-steps 2p, 2p + 1 at
+// Ap[j] + p * 128): one 16-byte request per pair instead of two strided 8-byte ones; aStep is not used.  Same operands, same order of MFMAs.
+template <typename T, int TG, int CT, int KU, bool FRAG = false>
 __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[TG][CT], const T *(&Ap)[TG], size_t aStep, const T *Bp,
                                                int bTile, int G) {
+    typedef T frag2 __attribute__((ext_vector_type(2)));
+    static_assert(KU % 2 == 0, "pairs of k-steps");
     T a0[KU][TG], a1[KU][TG], a2[KU][TG], b0[KU][CT], b1[KU][CT], b2[KU][CT];   // three rotating sets: no register copies of in-flight loads
 #define RN_LOAD_A(dst, g_)                                                                                             \
+    if (FRAG) {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < KU; i += 2)                                                              \
+            _Pragma("unroll") for (int j = 0; j < TG; j++) {                                                           \
+                const frag2 v_ = reinterpret_cast<const frag2 *>(Ap[j])[((size_t)(g_) * (KU / 2) + i / 2) * 64];         \
+                dst[i][j] = v_[0]; dst[i + 1][j] = v_[1];                                                              \
+            }                                                                                                          \
+    } else                                                                                                             \
     _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                     \
         _Pragma("unroll") for (int j = 0; j < TG; j++) dst[i][j] = Ap[j][((size_t)(g_) * KU + i) * aStep];
 #define RN_LOAD_B(dst, g_)                                                                                             \
@@ -1486,7 +1500,7 @@ __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[
 // leaves the latency hiding to the three workgroups that share a CU when there are more slabs than CUs.
 template <typename T, int TG, int KU, bool PIPE>
 __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], const T *M, int mp, int t0, int ts, int tiles, int ksteps,
-                                          const T *sB, int SB, int lane) {
+                                          const T *sB, int SB, int lane, const T *Mf = nullptr) {
     typedef typename Mfma16<T>::acc_t acc_t;
     const int col = lane & 15, kq = lane >> 4;
     const T *Ap[TG];
@@ -1496,9 +1510,11 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
 #pragma unroll
         for (int j = 0; j < TG; j++) {
             const int t = t0 + ts * j;
-            Ap[j] = M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
+            Ap[j] = Mf ? Mf + ((size_t)(t < tiles ? t : t0) * (ksteps / 2) * 64 + lane) * 2 : M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
             a2[j][0] = acc_t{0, 0, 0, 0};
         }
+        if (Mf) slab_mfma_pipe<T, TG, 1, KU, true>(a2, Ap, 0, Bp, 0, ksteps / KU);
+        else
         slab_mfma_pipe<T, TG, 1, KU>(a2, Ap, (size_t)4 * mp, Bp, 0, ksteps / KU);
 #pragma unroll
         for (int j = 0; j < TG; j++) acc[j] = a2[j][0];
@@ -1509,6 +1525,31 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
         const int t = t0 + ts * j;
         Ap[j] = M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
         acc[j] = acc_t{0, 0, 0, 0};
+    }
+    if (Mf != nullptr) {                          // A operands from the fragment-ordered copy: one 16-byte request per lane and pair of k-steps
+        typedef T frag2 __attribute__((ext_vector_type(2)));
+        static_assert(KU % 2 == 0, "pairs of k-steps");
+        const frag2 *Af[TG];
+#pragma unroll
+        for (int j = 0; j < TG; j++) {
+            const int t = t0 + ts * j;
+            Af[j] = reinterpret_cast<const frag2 *>(Mf) + (size_t)(t < tiles ? t : t0) * (ksteps / 2) * 64 + lane;
+        }
+        for (int ks = 0; ks < ksteps; ks += KU) {
+            T av[KU][TG], bv[KU];
+#pragma unroll
+            for (int i = 0; i < KU; i += 2) {
+#pragma unroll
+                for (int j = 0; j < TG; j++) { const frag2 v = Af[j][(size_t)((ks + i) / 2) * 64]; av[i][j] = v[0]; av[i + 1][j] = v[1]; }
+                bv[i] = Bp[(ks + i) * 4];
+                bv[i + 1] = Bp[(ks + i + 1) * 4];
+            }
+#pragma unroll
+            for (int i = 0; i < KU; i++)
+#pragma unroll
+                for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+        }
+        return;
     }
     for (int ks = 0; ks < ksteps; ks += KU) {     // ksteps is a whole number of groups (K padded by the host)
         T av[KU][TG], bv[KU];
@@ -1576,7 +1617,7 @@ __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int
     RN_KT(EPI == EPI_V ? 6 : 10);
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
     RN_KT(EPI == EPI_V ? 7 : 11);
-    slab_mfma<T, TG, KU, PIPE>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane);
+    slab_mfma<T, TG, KU, PIPE>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane, g.Mf);
     RN_KT(EPI == EPI_V ? 8 : 12);
     slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
     RN_KT(EPI == EPI_V ? 9 : 13);
@@ -1759,13 +1800,15 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 #define RN_WIDE_LD 18     // slab rows x 64-element chunks a wave requests at once (48 rows x 3 chunks over 8 waves: one round trip)
 #endif
 template <typename T, int CT, int KU>
-__device__ __forceinline__ void wide_mfma(typename Mfma16<T>::acc_t (&acc)[CT], const T *M, int mp, int t, int ksteps, const T *sB, int SB, int lane) {
+__device__ __forceinline__ void wide_mfma(typename Mfma16<T>::acc_t (&acc)[CT], const T *M, int mp, int t, int ksteps, const T *sB, int SB, int lane, const T *Mf = nullptr) {
     typedef typename Mfma16<T>::acc_t acc_t;
     const int col = lane & 15, kq = lane >> 4;
-    const T *Ap[1] = {M + (size_t)t * 16 + col + (size_t)kq * mp};
+    const T *Ap[1] = {Mf ? Mf + ((size_t)t * (ksteps / 2) * 64 + lane) * 2 : M + (size_t)t * 16 + col + (size_t)kq * mp};
     acc_t a2[1][CT];
 #pragma unroll
     for (int c = 0; c < CT; c++) a2[0][c] = acc_t{0, 0, 0, 0};
+    if (Mf) slab_mfma_pipe<T, 1, CT, KU, true>(a2, Ap, 0, sB + col * SB + kq, 16 * SB, ksteps / KU);
+    else
     slab_mfma_pipe<T, 1, CT, KU>(a2, Ap, (size_t)4 * mp, sB + col * SB + kq, 16 * SB, ksteps / KU);
 #pragma unroll
     for (int c = 0; c < CT; c++) acc[c] = a2[0][c];
@@ -1792,7 +1835,7 @@ __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, 
             }
         }
         RN_KT(EPI == EPI_V ? 7 : 11);
-        wide_mfma<T, CT, RN_WIDE_KU>(acc, g.M, g.mp, t, ksteps, sB, SB, lane);
+        wide_mfma<T, CT, RN_WIDE_KU>(acc, g.M, g.mp, t, ksteps, sB, SB, lane, g.Mf);
         RN_KT(EPI == EPI_V ? 8 : 12);
 #pragma unroll
         for (int c = 0; c < CT; c++) {

@@ -532,6 +532,26 @@ struct Ctx : CtxBase {
         for (int j = 0; j < k; j++) for (int i = 0; i < m; i++) tmp[i + (size_t)j * mp] = src[i + (size_t)j * m];
         return upload(dst, tmp.data(), tmp.size());
     }
+    // the shared operators of the slab products once more in MFMA fragment order (kernels.hpp, GemmArgs::Mf): [16-row tile][pair of k-steps][lane][2],
+    // zero-padded like the column-major copies (pad16(m) rows, pad4(k) columns): a wave's A operands of two k-steps are one contiguous request
+    T *d_RTf = nullptr, *d_LBLf = nullptr, *d_BLf = nullptr;
+    int fragMode = -1;       // 1: the lean loops of the slab products take their A operands from the fragment-ordered copies (RAPIDNET_SLAB_FRAG, default on)
+    bool frag_on() {
+        if (fragMode < 0) { const char *e = std::getenv("RAPIDNET_SLAB_FRAG"); fragMode = e ? (std::atoi(e) != 0) : 1; }
+        return fragMode != 0;
+    }
+    int upload_fragments(T *dst, const double *src, int m, int k) {
+        const int mp = pad16(m), kp = pad4(k), tiles = mp / 16, pairs = kp / 8;
+        std::vector<double> tmp((size_t)mp * kp, 0.0);
+        for (int t = 0; t < tiles; t++)
+            for (int p2 = 0; p2 < pairs; p2++)
+                for (int l = 0; l < 64; l++)
+                    for (int e = 0; e < 2; e++) {
+                        const int row = t * 16 + (l & 15), col = 4 * (2 * p2 + e) + (l >> 4);
+                        if (row < m && col < k) tmp[(((size_t)t * pairs + p2) * 64 + l) * 2 + e] = src[row + (size_t)col * m];
+                    }
+        return upload(dst, tmp.data(), tmp.size());
+    }
     // LDS image of a shared operator for the LDS-staged slab products (kernels.hpp, LdsImage): col-major m x k -> per pass of 16 row tiles
     // and chunk of 16 columns, 16 columns of ldm values, zero padded
     T *d_imgRT = nullptr, *d_imgLBL = nullptr, *d_imgBL = nullptr;
@@ -728,6 +748,7 @@ struct Ctx : CtxBase {
         DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lvb, n * (nu + nx)) DA(d_eb, n * nx) DA(d_bw0, nx) DA(d_bw, n * nx)
         DA(d_imgRT, lds_image_values(nv, nv + nx)) DA(d_imgLBL, lds_image_values(nu + nx, nv)) DA(d_imgBL, lds_image_values(nv, nx + nu))
         DA(d_LBLp, (size_t)pad16(nu + nx) * pad4(nv))
+        DA(d_LBLf, (size_t)pad16(nu + nx) * pad4(nv)) DA(d_BLf, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_RTf, (size_t)pad16(nv) * pad4(nv + nx))
         DA(d_BLp, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_ab, n * (nx + nu))
         DA(d_RTp, (size_t)pad16(nv) * pad4(nv + nx)) DA(d_Lp, (size_t)pad16(nu) * pad4(nv)) DA(d_Bp, (size_t)pad16(nx) * pad4(nu))
         DA(d_lo, n * ny) DA(d_hi, n * ny) DA(d_z, n * ny) DA(d_res, n * ny)
@@ -794,6 +815,7 @@ struct Ctx : CtxBase {
             std::copy(h_Bbt.begin(), h_Bbt.end(), BL.begin());
             std::copy(Lt.begin(), Lt.end(), BL.begin() + (size_t)nv * nx);
             if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
+            if (int rc = upload_fragments(d_BLf, BL.data(), nv, nx + nu)) return rc;
             if (int rc = upload_lds_image(d_imgBL, BL.data(), nv, nx + nu)) return rc;
         }
         {   // [L ; B L]  ((nu+nx) x nv) for the forward GEMM
@@ -804,12 +826,14 @@ struct Ctx : CtxBase {
                 for (int i = 0; i < nx; i++) LBL[nu + i + (size_t)j * (nu + nx)] = BLm[i + (size_t)j * nx];
             }
             if (int rc = upload_padded(d_LBLp, LBL.data(), nu + nx, nv)) return rc;
+            if (int rc = upload_fragments(d_LBLf, LBL.data(), nu + nx, nv)) return rc;
             if (int rc = upload_lds_image(d_imgLBL, LBL.data(), nu + nx, nv)) return rc;
         }
         std::vector<double> RTm((size_t)nv * (nv + nx));
         std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
         if (int rc = upload_padded(d_RTp, RTm.data(), nv, nv + nx)) return rc;
+        if (int rc = upload_fragments(d_RTf, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_lds_image(d_imgRT, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
@@ -1098,6 +1122,7 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
         GemmArgs<T> g{d_BLp, nv, nx + nu, pad16(nv), pad4(nx + nu), d_ab, nx + nu, d_my + nv, 2 * nv, nullptr, 0, d_prob, d.nodes};
+        if (frag_on()) g.Mf = d_BLf;
         const int SB = slab_stride(g.kp);
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
@@ -1187,6 +1212,7 @@ struct Ctx : CtxBase {
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v + (size_t)n0 * nv, nv, a.lvb + (size_t)n0 * (nu + nx), nu + nx, nullptr, 0, d_prob + n0, nSub};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
+        if (frag_on()) { gV.Mf = d_RTf; gL.Mf = d_LBLf; }     // (read by the lean loops only: launches with more slabs than CUs)
         if (lds <= 64 * 1024) {
             const int nSlabs = (nSub + 15) / 16;
             // more slabs than CUs, Barcelona-shaped operators: the register-resident persistent form (every wave keeps its operator tiles in

@@ -79,3 +79,24 @@ def test_register_resident_slab_kernel_is_bitwise_the_default(monkeypatch, name,
     assert np.array_equal(h0, h1)
     for b in BUFS:
         assert np.array_equal(o0[b], o1[b]), b
+
+
+@pytest.mark.parametrize("name,structured,precision,wide", [("medium", False, "f64", None), ("medium", True, "f64", None), ("ragged", False, "f64", None),
+                                                            ("barcelona31", True, "f64", None), ("medium", False, "f32", None), ("wide16", False, "f32", "3"),
+                                                            ("wide16", True, "f32", None), ("barcelona493", True, "f64", None)])
+def test_fragment_ordered_operands_are_bitwise_the_column_major_ones(monkeypatch, name, structured, precision, wide):
+    """RAPIDNET_SLAB_FRAG (default 1): the slab products take their A operands from the operators' fragment-ordered copies (GemmArgs::Mf: one
+    contiguous 16-byte request per lane and pair of k-steps) instead of the column-major ones (two strided 8-byte requests) -- the same
+    operands into the same chain of MFMAs, so the same bits: the software-pipelined loop (small trees), the wide kernel (forced on wide16)
+    and, on the whole 493-scenario tree in structured mode (no per-node blocks: cheap), the lean loop of k_gemm_vlv and k_gemm_prep_m2."""
+    p = synth.make_problem(name)
+    if wide:
+        monkeypatch.setenv("RAPIDNET_VLV_WIDE", wide)
+    n = 12 if name == "barcelona493" else 40
+    monkeypatch.setenv("RAPIDNET_SLAB_FRAG", "0")
+    h0, o0, _ = run(p, structured, precision, n)
+    monkeypatch.setenv("RAPIDNET_SLAB_FRAG", "1")
+    h1, o1, _ = run(p, structured, precision, n)
+    assert np.array_equal(h0, h1)
+    for b in BUFS:
+        assert np.array_equal(o0[b], o1[b]), b
