@@ -1281,6 +1281,7 @@ struct GemmArgs {
 // the auxiliary operand of node i, row r (EPI_V: m1, both partials of a split node added; EPI_Z: e)
 template <typename T, int EPI>
 __device__ __forceinline__ T gemm_aux(const GemmArgs<T> &g, int i, int r) {
+    if (g.aux == nullptr) return (T)0;            // structured operator mode: m1 is folded into the v product, nothing to add (uniform branch)
     T v = g.aux[(size_t)i * g.ldaux + r];
     if (EPI == EPI_V && g.aux2 != nullptr && i >= g.auxSplit) v += g.aux2[(size_t)(i - g.auxSplit) * g.ldaux + r];
     return v;

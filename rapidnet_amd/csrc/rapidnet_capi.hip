@@ -1209,6 +1209,7 @@ struct Ctx : CtxBase {
         GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk + (size_t)n0 * (nv + nx), nv + nx, a.v + (size_t)n0 * nv, nv, a.my + (size_t)n0 * 2 * nv, 2 * nv,
                        d_prob + n0, nSub, a.my2, a.splitFirst - n0};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
+        if (structured) gV.aux = nullptr;       // m1_i is folded into the v product (d_my's m1 half stays zero): the epilogue has nothing to fetch
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v + (size_t)n0 * nv, nv, a.lvb + (size_t)n0 * (nu + nx), nu + nx, nullptr, 0, d_prob + n0, nSub};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
