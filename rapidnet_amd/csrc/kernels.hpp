@@ -1408,6 +1408,16 @@ constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #ifndef RN_SLAB_ROTATE
 #define RN_SLAB_ROTATE 1
 #endif
+// 1 (ablation builds; measured slower, so 0 ships): the slab products multiply TRANSPOSED -- the MFMA's A operand is the slab (16 nodes x 4 k,
+// from LDS), its B operand the operator's fragment (4 k x 16 rows), so a lane's four accumulator entries are ONE operator row for FOUR nodes
+// instead of four rows of one node: for a fixed entry the 64 lanes of a wave touch 4 nodes x 16 consecutive rows = four whole 128-byte pieces of
+// the node-major vectors (m1 loads, v / [Lv; BLv] stores) where the untransposed form touches sixteen 32-byte pieces.  Same operand values, same
+// k order: the same bits (checked against the LDS-staged and register-resident forms).  But the epilogue then holds four nodes' scales and
+// indices per lane: k_gemm_vlv 152 -> 173 registers = two waves per SIMD instead of three, 28.3 -> 32.7 us on the 493-scenario tree (k_down_chain,
+// which reads the whole lines, 18.0 -> 17.6); capped at 168 registers it spills.
+#ifndef RN_SLAB_T
+#define RN_SLAB_T 0
+#endif
 #ifndef RN_SLAB_KU
 #define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k)
 #endif
@@ -1472,7 +1482,7 @@ __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                 \
             _Pragma("unroll") for (int j = 0; j < TG; j++)                                                             \
-                _Pragma("unroll") for (int c = 0; c < CT; c++) acc[j][c] = Mfma16<T>::run(cur[i][j], bcur[i][c], acc[j][c]); \
+                _Pragma("unroll") for (int c = 0; c < CT; c++) acc[j][c] = RN_SLAB_T ? Mfma16<T>::run(bcur[i][c], cur[i][j], acc[j][c]) : Mfma16<T>::run(cur[i][j], bcur[i][c], acc[j][c]); \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int i = 0; i < KU; i++) {                                                               \
             _Pragma("unroll") for (int j = 0; j < TG; j++) asm volatile("" ::"v"(nxt[i][j]));                          \
@@ -1548,7 +1558,7 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
 #pragma unroll
             for (int i = 0; i < KU; i++)
 #pragma unroll
-                for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+                for (int j = 0; j < TG; j++) acc[j] = RN_SLAB_T ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
         }
         return;
     }
@@ -1563,16 +1573,30 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
 #pragma unroll
         for (int i = 0; i < KU; i++)
 #pragma unroll
-            for (int j = 0; j < TG; j++) acc[j] = Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+            for (int j = 0; j < TG; j++) acc[j] = RN_SLAB_T ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
     }
 }
 // auxiliary operands of the epilogue (m1_i or e_i), requested BEFORE the MFMA loop so that their latency hides behind it
 template <typename T, int EPI, int TG>
-__device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T &scale, const GemmArgs<T> &g, int t0, int ts, int node0, int lane) {
+__device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T (&scale)[4], const GemmArgs<T> &g, int t0, int ts, int node0, int lane) {
+#if RN_SLAB_T
+    // accumulator entry `reg` of tile j: node node0 + row(lane, reg), operator row 16 (t0 + ts j) + (lane & 15)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int node = node0 + Mfma16<T>::row(lane, reg);
+        const int nodeC = node < g.nodes ? node : g.nodes - 1;
+        scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+#pragma unroll
+        for (int j = 0; j < TG; j++) {
+            const int gr = (t0 + ts * j) * 16 + (lane & 15);
+            auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
+        }
+    }
+#else
     const int node = node0 + (lane & 15);
     const int nodeC = node < g.nodes ? node : g.nodes - 1;
-    scale = 0;
-    if (EPI == EPI_V) scale = (T)(-0.5) / g.prob[nodeC];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
 #pragma unroll
     for (int j = 0; j < TG; j++)
 #pragma unroll
@@ -1580,26 +1604,27 @@ __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T &scale, const GemmA
             const int gr = (t0 + ts * j) * 16 + Mfma16<T>::row(lane, reg);
             auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
         }
+#endif
 }
 // epilogue of one pass; sOut != nullptr also keeps the results in LDS ([16][SO], the B operand of a following product)
 template <typename T, int EPI, int TG>
-__device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc)[TG], const T (&auxv)[TG][4], T scale, const GemmArgs<T> &g,
+__device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc)[TG], const T (&auxv)[TG][4], const T (&scale)[4], const GemmArgs<T> &g,
                                            int t0, int ts, int tiles, int node0, int lane, T *sOut, int SO) {
-    const int col = lane & 15;
-    const int node = node0 + col;
-    const bool nodeOk = node < g.nodes;
 #pragma unroll
     for (int j = 0; j < TG; j++) {
         const int t = t0 + ts * j;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+            const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);                    // node of the entry, within the slab
+            const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));         // operator row of the entry
+            const int node = node0 + ln;
+            const bool nodeOk = node < g.nodes;
             T r = acc[j][reg];
-            if (EPI == EPI_V) r = auxv[j][reg] + scale * r;
+            if (EPI == EPI_V) r = auxv[j][reg] + scale[reg] * r;
             if (EPI == EPI_Z) r = auxv[j][reg] + r;
             const bool live = t < tiles && gr < g.m;
             if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;   // out == nullptr: the result only lives in sOut
-            if (sOut && live) sOut[col * SO + gr] = nodeOk ? r : (T)0;
+            if (sOut && live) sOut[ln * SO + gr] = nodeOk ? r : (T)0;
         }
     }
 }
@@ -1614,7 +1639,7 @@ template <typename T, int EPI, int TG, int KU, bool PIPE>
 __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int SB, int node0, int t0, int nw, int tiles, int ksteps, int lane,
                                           T *sOut, int SO) {
     typename Mfma16<T>::acc_t acc[TG];
-    T auxv[TG][4], scale;
+    T auxv[TG][4], scale[4];
     RN_KT(EPI == EPI_V ? 6 : 10);
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
     RN_KT(EPI == EPI_V ? 7 : 11);
@@ -1818,20 +1843,21 @@ template <typename T, int EPI, int CT>
 __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, int SB, int node0, int wave, int nw, int lane, T *sOut, int SO) {
     typedef typename Mfma16<T>::acc_t acc_t;
     const int tiles = (g.m + 15) / 16, ksteps = g.kp / 4;
-    const int col = lane & 15;
     for (int t = wave; t < tiles; t += nw) {
         acc_t acc[CT];
-        T auxv[CT][4], scale[CT];
+        T auxv[CT][4], scale[CT][4];
         RN_KT(EPI == EPI_V ? 6 : 10);
         // the epilogue's operands (m1_i) are requested before the MFMA loop: their latency hides behind it
+        // (entry `reg` of slab c: node c * 16 + ln, operator row 16 t + lr -- which of the lane's two coordinates is which: RN_SLAB_T, see slab_store)
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            const int node = node0 + c * 16 + col;
-            const int nodeC = node < g.nodes ? node : g.nodes - 1;
-            scale[c] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);
+                const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));
+                const int node = node0 + c * 16 + ln;
+                const int nodeC = node < g.nodes ? node : g.nodes - 1;
+                scale[c][reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
                 auxv[c][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
             }
         }
@@ -1840,17 +1866,18 @@ __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, 
         RN_KT(EPI == EPI_V ? 8 : 12);
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            const int node = node0 + c * 16 + col;
-            const bool nodeOk = node < g.nodes;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int gr = t * 16 + Mfma16<T>::row(lane, reg);
+                const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);
+                const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));
+                const int node = node0 + c * 16 + ln;
+                const bool nodeOk = node < g.nodes;
                 T r = acc[c][reg];
-                if (EPI == EPI_V) r = auxv[c][reg] + scale[c] * r;
+                if (EPI == EPI_V) r = auxv[c][reg] + scale[c][reg] * r;
                 if (EPI == EPI_Z) r = auxv[c][reg] + r;
                 const bool live = gr < g.m;
                 if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
-                if (sOut && live) sOut[(c * 16 + col) * SO + gr] = nodeOk ? r : (T)0;
+                if (sOut && live) sOut[(c * 16 + ln) * SO + gr] = nodeOk ? r : (T)0;
             }
         }
         RN_KT(EPI == EPI_V ? 9 : 13);
