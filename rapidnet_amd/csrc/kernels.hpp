@@ -1408,16 +1408,19 @@ constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #ifndef RN_SLAB_ROTATE
 #define RN_SLAB_ROTATE 1
 #endif
-// 1 (ablation builds; measured slower, so 0 ships): the slab products multiply TRANSPOSED -- the MFMA's A operand is the slab (16 nodes x 4 k,
+// 1 (ablation builds; measured slower): ALL slab products multiply TRANSPOSED -- the MFMA's A operand is the slab (16 nodes x 4 k,
 // from LDS), its B operand the operator's fragment (4 k x 16 rows), so a lane's four accumulator entries are ONE operator row for FOUR nodes
 // instead of four rows of one node: for a fixed entry the 64 lanes of a wave touch 4 nodes x 16 consecutive rows = four whole 128-byte pieces of
 // the node-major vectors (m1 loads, v / [Lv; BLv] stores) where the untransposed form touches sixteen 32-byte pieces.  Same operand values, same
 // k order: the same bits (checked against the LDS-staged and register-resident forms).  But the epilogue then holds four nodes' scales and
 // indices per lane: k_gemm_vlv 152 -> 173 registers = two waves per SIMD instead of three, 28.3 -> 32.7 us on the 493-scenario tree (k_down_chain,
 // which reads the whole lines, 18.0 -> 17.6); capped at 168 registers it spills.
+// 2: only the products without epilogue operands are transposed (EPI_LV: [L v; B L v] and the structured mode's m2) -- their stores leave as
+// whole lines and no register is added.
 #ifndef RN_SLAB_T
-#define RN_SLAB_T 0
+#define RN_SLAB_T 2
 #endif
+#define RN_SLAB_TR(EPI) (RN_SLAB_T == 1 || (RN_SLAB_T == 2 && (EPI) == EPI_LV))
 #ifndef RN_SLAB_KU
 #define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k)
 #endif
@@ -1451,7 +1454,7 @@ __device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, 
 // Same order of accumulation over k as every earlier version of these kernels.
 // FRAG: Ap[j] points at the tile's data in the operator's fragment-ordered copy (GemmArgs::Mf: this lane's pair of k-steps 2p, 2p + 1 at
 // Ap[j] + p * 128): one 16-byte request per pair instead of two strided 8-byte ones; aStep is not used.  Same operands, same order of MFMAs.
-template <typename T, int TG, int CT, int KU, bool FRAG = false>
+template <typename T, int TG, int CT, int KU, bool FRAG = false, bool TR = false>
 __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[TG][CT], const T *(&Ap)[TG], size_t aStep, const T *Bp,
                                                int bTile, int G) {
     typedef T frag2 __attribute__((ext_vector_type(2)));
@@ -1482,7 +1485,7 @@ __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int i = 0; i < KU; i++)                                                                 \
             _Pragma("unroll") for (int j = 0; j < TG; j++)                                                             \
-                _Pragma("unroll") for (int c = 0; c < CT; c++) acc[j][c] = RN_SLAB_T ? Mfma16<T>::run(bcur[i][c], cur[i][j], acc[j][c]) : Mfma16<T>::run(cur[i][j], bcur[i][c], acc[j][c]); \
+                _Pragma("unroll") for (int c = 0; c < CT; c++) acc[j][c] = TR ? Mfma16<T>::run(bcur[i][c], cur[i][j], acc[j][c]) : Mfma16<T>::run(cur[i][j], bcur[i][c], acc[j][c]); \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int i = 0; i < KU; i++) {                                                               \
             _Pragma("unroll") for (int j = 0; j < TG; j++) asm volatile("" ::"v"(nxt[i][j]));                          \
@@ -1509,7 +1512,7 @@ __device__ __forceinline__ void slab_mfma_pipe(typename Mfma16<T>::acc_t (&acc)[
 // PIPE: the software-pipelined loop above (220 VGPRs: for launches with at most one workgroup per CU, where nothing else hides
 // the operand latency -- small and sharded trees); otherwise the lean loop (request a group, multiply it; 100 VGPRs), which
 // leaves the latency hiding to the three workgroups that share a CU when there are more slabs than CUs.
-template <typename T, int TG, int KU, bool PIPE>
+template <typename T, int TG, int KU, bool PIPE, bool TR = false>
 __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], const T *M, int mp, int t0, int ts, int tiles, int ksteps,
                                           const T *sB, int SB, int lane, const T *Mf = nullptr) {
     typedef typename Mfma16<T>::acc_t acc_t;
@@ -1524,9 +1527,9 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
             Ap[j] = Mf ? Mf + ((size_t)(t < tiles ? t : t0) * (ksteps / 2) * 64 + lane) * 2 : M + (size_t)(t < tiles ? t : t0) * 16 + col + (size_t)kq * mp;
             a2[j][0] = acc_t{0, 0, 0, 0};
         }
-        if (Mf) slab_mfma_pipe<T, TG, 1, KU, true>(a2, Ap, 0, Bp, 0, ksteps / KU);
+        if (Mf) slab_mfma_pipe<T, TG, 1, KU, true, TR>(a2, Ap, 0, Bp, 0, ksteps / KU);
         else
-        slab_mfma_pipe<T, TG, 1, KU>(a2, Ap, (size_t)4 * mp, Bp, 0, ksteps / KU);
+        slab_mfma_pipe<T, TG, 1, KU, false, TR>(a2, Ap, (size_t)4 * mp, Bp, 0, ksteps / KU);
 #pragma unroll
         for (int j = 0; j < TG; j++) acc[j] = a2[j][0];
         return;
@@ -1558,7 +1561,7 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
 #pragma unroll
             for (int i = 0; i < KU; i++)
 #pragma unroll
-                for (int j = 0; j < TG; j++) acc[j] = RN_SLAB_T ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+                for (int j = 0; j < TG; j++) acc[j] = TR ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
         }
         return;
     }
@@ -1573,26 +1576,27 @@ __device__ __forceinline__ void slab_mfma(typename Mfma16<T>::acc_t (&acc)[TG], 
 #pragma unroll
         for (int i = 0; i < KU; i++)
 #pragma unroll
-            for (int j = 0; j < TG; j++) acc[j] = RN_SLAB_T ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
+            for (int j = 0; j < TG; j++) acc[j] = TR ? Mfma16<T>::run(bv[i], av[i][j], acc[j]) : Mfma16<T>::run(av[i][j], bv[i], acc[j]);
     }
 }
 // auxiliary operands of the epilogue (m1_i or e_i), requested BEFORE the MFMA loop so that their latency hides behind it
 template <typename T, int EPI, int TG>
 __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T (&scale)[4], const GemmArgs<T> &g, int t0, int ts, int node0, int lane) {
-#if RN_SLAB_T
-    // accumulator entry `reg` of tile j: node node0 + row(lane, reg), operator row 16 (t0 + ts j) + (lane & 15)
+    if (RN_SLAB_TR(EPI)) {
+        // accumulator entry `reg` of tile j: node node0 + row(lane, reg), operator row 16 (t0 + ts j) + (lane & 15)
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-        const int node = node0 + Mfma16<T>::row(lane, reg);
-        const int nodeC = node < g.nodes ? node : g.nodes - 1;
-        scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+        for (int reg = 0; reg < 4; reg++) {
+            const int node = node0 + Mfma16<T>::row(lane, reg);
+            const int nodeC = node < g.nodes ? node : g.nodes - 1;
+            scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
 #pragma unroll
-        for (int j = 0; j < TG; j++) {
-            const int gr = (t0 + ts * j) * 16 + (lane & 15);
-            auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
+            for (int j = 0; j < TG; j++) {
+                const int gr = (t0 + ts * j) * 16 + (lane & 15);
+                auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
+            }
         }
+        return;
     }
-#else
     const int node = node0 + (lane & 15);
     const int nodeC = node < g.nodes ? node : g.nodes - 1;
 #pragma unroll
@@ -1604,7 +1608,6 @@ __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T (&scale)[4], const 
             const int gr = (t0 + ts * j) * 16 + Mfma16<T>::row(lane, reg);
             auxv[j][reg] = (EPI != EPI_LV) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
         }
-#endif
 }
 // epilogue of one pass; sOut != nullptr also keeps the results in LDS ([16][SO], the B operand of a following product)
 template <typename T, int EPI, int TG>
@@ -1615,8 +1618,8 @@ __device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc
         const int t = t0 + ts * j;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);                    // node of the entry, within the slab
-            const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));         // operator row of the entry
+            const int ln = RN_SLAB_TR(EPI) ? Mfma16<T>::row(lane, reg) : (lane & 15);                    // node of the entry, within the slab
+            const int gr = t * 16 + (RN_SLAB_TR(EPI) ? (lane & 15) : Mfma16<T>::row(lane, reg));         // operator row of the entry
             const int node = node0 + ln;
             const bool nodeOk = node < g.nodes;
             T r = acc[j][reg];
@@ -1643,7 +1646,7 @@ __device__ __forceinline__ void slab_pass(const GemmArgs<T> &g, const T *sB, int
     RN_KT(EPI == EPI_V ? 6 : 10);
     slab_aux<T, EPI, TG>(auxv, scale, g, t0, nw, node0, lane);
     RN_KT(EPI == EPI_V ? 7 : 11);
-    slab_mfma<T, TG, KU, PIPE>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane, g.Mf);
+    slab_mfma<T, TG, KU, PIPE, RN_SLAB_TR(EPI)>(acc, g.M, g.mp, t0, nw, tiles, ksteps, sB, SB, lane, g.Mf);
     RN_KT(EPI == EPI_V ? 8 : 12);
     slab_store<T, EPI, TG>(acc, auxv, scale, g, t0, nw, tiles, node0, lane, sOut, SO);
     RN_KT(EPI == EPI_V ? 9 : 13);
@@ -1825,7 +1828,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 #ifndef RN_WIDE_LD
 #define RN_WIDE_LD 18     // slab rows x 64-element chunks a wave requests at once (48 rows x 3 chunks over 8 waves: one round trip)
 #endif
-template <typename T, int CT, int KU>
+template <typename T, int CT, int KU, bool TR = false>
 __device__ __forceinline__ void wide_mfma(typename Mfma16<T>::acc_t (&acc)[CT], const T *M, int mp, int t, int ksteps, const T *sB, int SB, int lane, const T *Mf = nullptr) {
     typedef typename Mfma16<T>::acc_t acc_t;
     const int col = lane & 15, kq = lane >> 4;
@@ -1833,9 +1836,9 @@ __device__ __forceinline__ void wide_mfma(typename Mfma16<T>::acc_t (&acc)[CT], 
     acc_t a2[1][CT];
 #pragma unroll
     for (int c = 0; c < CT; c++) a2[0][c] = acc_t{0, 0, 0, 0};
-    if (Mf) slab_mfma_pipe<T, 1, CT, KU, true>(a2, Ap, 0, sB + col * SB + kq, 16 * SB, ksteps / KU);
+    if (Mf) slab_mfma_pipe<T, 1, CT, KU, true, TR>(a2, Ap, 0, sB + col * SB + kq, 16 * SB, ksteps / KU);
     else
-    slab_mfma_pipe<T, 1, CT, KU>(a2, Ap, (size_t)4 * mp, sB + col * SB + kq, 16 * SB, ksteps / KU);
+    slab_mfma_pipe<T, 1, CT, KU, false, TR>(a2, Ap, (size_t)4 * mp, sB + col * SB + kq, 16 * SB, ksteps / KU);
 #pragma unroll
     for (int c = 0; c < CT; c++) acc[c] = a2[0][c];
 }
@@ -1853,8 +1856,8 @@ __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, 
         for (int c = 0; c < CT; c++) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);
-                const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));
+                const int ln = RN_SLAB_TR(EPI) ? Mfma16<T>::row(lane, reg) : (lane & 15);
+                const int gr = t * 16 + (RN_SLAB_TR(EPI) ? (lane & 15) : Mfma16<T>::row(lane, reg));
                 const int node = node0 + c * 16 + ln;
                 const int nodeC = node < g.nodes ? node : g.nodes - 1;
                 scale[c][reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
@@ -1862,14 +1865,14 @@ __device__ __forceinline__ void wide_product(const GemmArgs<T> &g, const T *sB, 
             }
         }
         RN_KT(EPI == EPI_V ? 7 : 11);
-        wide_mfma<T, CT, RN_WIDE_KU>(acc, g.M, g.mp, t, ksteps, sB, SB, lane, g.Mf);
+        wide_mfma<T, CT, RN_WIDE_KU, RN_SLAB_TR(EPI)>(acc, g.M, g.mp, t, ksteps, sB, SB, lane, g.Mf);
         RN_KT(EPI == EPI_V ? 8 : 12);
 #pragma unroll
         for (int c = 0; c < CT; c++) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int ln = RN_SLAB_T ? Mfma16<T>::row(lane, reg) : (lane & 15);
-                const int gr = t * 16 + (RN_SLAB_T ? (lane & 15) : Mfma16<T>::row(lane, reg));
+                const int ln = RN_SLAB_TR(EPI) ? Mfma16<T>::row(lane, reg) : (lane & 15);
+                const int gr = t * 16 + (RN_SLAB_TR(EPI) ? (lane & 15) : Mfma16<T>::row(lane, reg));
                 const int node = node0 + c * 16 + ln;
                 const bool nodeOk = node < g.nodes;
                 T r = acc[c][reg];
