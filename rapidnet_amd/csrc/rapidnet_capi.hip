@@ -1699,7 +1699,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
-        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false;
+        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxPending = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
@@ -2094,7 +2094,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
- poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false;
+        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxPending = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }
