@@ -1488,9 +1488,10 @@ struct Ctx : CtxBase {
             return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
         };
         // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
-        // launch is the slab kernel and stage 0 is neither the whole crown nor the multi-GPU exchange stage
+        // launch is the slab kernel and stage 0 is not the multi-GPU exchange stage (single GPU: also when the root IS the whole crown --
+        // the 31-scenario tree: one launch of 4.6 us less, helper path 40.2 -> 38.8 us)
         // 2: sharded with a two-stage crown whose stage 1 is the exchange stage -- its (presummed) step is folded as well
-        int foldRoot = (RN_FOLD_ROOT && phase == 0 && cs >= 2 && !(a.cutSums && cutStage == 1) && v_lv_is_slab()) ? 1 : 0;
+        int foldRoot = (RN_FOLD_ROOT && phase == 0 && cs >= (a.cutSums ? 2 : 1) && !(a.cutSums && cutStage == 1) && v_lv_is_slab()) ? 1 : 0;
         if (foldRoot && a.cutSums && cs == 2 && cutStage == 2) foldRoot = 2;
         // overlapped exchange: the sharded two-stage crown (what the Barcelona shards run), a real or stand-in communicator, not while every
         // interval is being bracketed by profiling events on the one stream; the chain region's slabs start behind the crown's
