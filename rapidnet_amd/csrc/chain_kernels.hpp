@@ -1006,5 +1006,16 @@ __global__ void __launch_bounds__(ELT_THREADS) k_hx_finish(FinishArgs<T> f) {
     }
 }
 
+// Hx from the primal values k_down_chain<T, true> left in its place (every node): hx = (sqrt(p_i) d_k) * value -- the expression of
+// k_dual_stage<..., SCALE>; only for a consumer of Hx other than that kernel behind an unscaled walk (does not happen in the batch loops as they are).
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_hx_scale(T *hx, const T *sqrtp, const T *dy, const int *stageOf, int ny, long long total) {
+    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * ELT_THREADS) {
+        const long long node = i / ny;
+        const int r = (int)(i - node * ny);
+        hx[i] = (sqrtp[node] * dy[(size_t)stageOf[node] * ny + r]) * hx[i];
+    }
+}
+
 }  // namespace rn
 #endif

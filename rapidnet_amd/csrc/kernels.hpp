@@ -2441,7 +2441,10 @@ __global__ void __launch_bounds__(REG8_THREADS, 2) k_gemm_vlv_reg8(GemmArgs<T> g
 constexpr int CROWN_MAX_DEPTH = 8;
 template <typename T>
 __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads);
-template <typename T>
+// UNSC (inner iterations of a device-resident batch whose dual update is k_dual_stage<..., HXM = 2>): the Hx buffer receives the PRIMAL values
+// (x_i | x_i | u_i) and the dual update applies the scaling sqrt(p_i) d_k -- it has that factor in registers for the bounds anyway, the product is
+// the same two roundings -- so the walk does not request the preconditioner table at all (a third to a half of its load instructions)
+template <typename T, bool UNSC = false>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, int foldCrown) {
     // foldCrown = 2 (sharded runs): the grid has one more workgroup per crown node behind the K chain workgroups; it writes that
     // node (root -> node walk at the end of this kernel) while the chain workgroups walk their chains, instead of 18 of the 62
@@ -2493,7 +2496,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         if (writer[dd]) {
                             const T spc = a.tr.sqrtp[anc[dd]];
                             if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
-                            a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
+                            a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = UNSC ? uv : spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
                         }
                     }
             } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
@@ -2505,7 +2508,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
                     uh[j] = uhat[node * nu + t];
-                    d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t];
+                    d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + 2 * nx + t];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
@@ -2514,7 +2517,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         run += dv[j];
                         const T uv = uh[j] + run;
                         if (a.writePrimal) a.u[node * nu + t] = uv;
-                        a.hx[node * ny + 2 * nx + t] = sp * d0[j] * uv;
+                        a.hx[node * ny + 2 * nx + t] = UNSC ? uv : sp * d0[j] * uv;
                     }
                 }
             }
@@ -2537,8 +2540,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                             const T spc = a.tr.sqrtp[anc[dd]];
                             a.bw[(size_t)anc[dd] * nx + j0] = bw;
                             if (a.writePrimal) a.x[(size_t)anc[dd] * nx + j0] = xr;
-                            a.hx[(size_t)anc[dd] * ny + j0] = spc * dyAll[(size_t)k * ny + j0] * xr;
-                            a.hx[(size_t)anc[dd] * ny + nx + j0] = spc * dyAll[(size_t)k * ny + nx + j0] * xr;
+                            a.hx[(size_t)anc[dd] * ny + j0] = UNSC ? xr : spc * dyAll[(size_t)k * ny + j0] * xr;
+                            a.hx[(size_t)anc[dd] * ny + nx + j0] = UNSC ? xr : spc * dyAll[(size_t)k * ny + nx + j0] * xr;
                         }
                     }
             } else {
@@ -2553,8 +2556,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
                     ev[j] = eb[node * nx + j0];
-                    d0[j] = dyAll[(size_t)kk * ny + j0];
-                    d1[j] = dyAll[(size_t)kk * ny + nx + j0];
+                    d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + j0];
+                    d1[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + nx + j0];
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
@@ -2563,8 +2566,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         bw += dv[j];
                         xr += ev[j] + bw;
                         if (a.writePrimal) a.x[node * nx + j0] = xr;
-                        a.hx[node * ny + j0] = sp * d0[j] * xr;
-                        a.hx[node * ny + nx + j0] = sp * d1[j] * xr;
+                        a.hx[node * ny + j0] = UNSC ? xr : sp * d0[j] * xr;
+                        a.hx[node * ny + nx + j0] = UNSC ? xr : sp * d1[j] * xr;
                     }
                 }
             }
@@ -2595,7 +2598,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                         if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
                     if (a.writePrimal) a.u[(size_t)j * nu + t] = uv;
-                    a.hx[(size_t)j * ny + 2 * nx + t] = spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv;
+                    a.hx[(size_t)j * ny + 2 * nx + t] = UNSC ? uv : spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv;
                 } else {
                     const int j0 = t - nu;
                     T bw = a.bw0[j0], xr = a.curX[j0];
@@ -2608,8 +2611,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
                     a.bw[(size_t)j * nx + j0] = bw;
                     if (a.writePrimal) a.x[(size_t)j * nx + j0] = xr;
-                    a.hx[(size_t)j * ny + j0] = spj * dyAll[(size_t)kj * ny + j0] * xr;
-                    a.hx[(size_t)j * ny + nx + j0] = spj * dyAll[(size_t)kj * ny + nx + j0] * xr;
+                    a.hx[(size_t)j * ny + j0] = UNSC ? xr : spj * dyAll[(size_t)kj * ny + j0] * xr;
+                    a.hx[(size_t)j * ny + nx + j0] = UNSC ? xr : spj * dyAll[(size_t)kj * ny + nx + j0] * xr;
                 }
             }
         }
@@ -2999,7 +3002,7 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
 // instead of 5, and 21 MB of dirty lines less in front of the streaming kernel): LAZY = 3 (first iteration): w is read, w_next not
 // stored; LAZY = 1 (inner iterations): w derived, w_next not stored; LAZY = 2 (last iteration): w derived, and both w_t (wview)
 // and w_next stored, so that the state a caller can observe is what it always was.
-template <typename T, bool MATERIALIZE, int LAZY, bool OFFS = false>
+template <typename T, bool MATERIALIZE, int LAZY, bool OFFS = false, bool SCALE = false>
 __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualArgs<T> &a, T ln, DualAcc<T> &r) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
@@ -3015,7 +3018,8 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
         const T lo = k * s.blo[e];
         const T hi = (isXi && !isBox) ? s.bhi[e] : k * s.bhi[e];
         wcur[e] = (LAZY == 1 || LAZY == 2) ? extrap_elem(s.yp[e], s.w[e], a.lnCur) : s.w[e];
-        const T hxv = (OFFS && s.offs) ? k * cf_primal<T>(s.hx[e], s.cnt, s.o1[e], s.o0[e]) : s.hx[e];
+        // OFFS: chain-fused sweep (partial primal + the crown's offsets); SCALE: k_down_chain<T, true> left the primal values (every node)
+        const T hxv = (OFFS && s.offs) ? k * cf_primal<T>(s.hx[e], s.cnt, s.o1[e], s.o0[e]) : (SCALE ? k * s.hx[e] : s.hx[e]);
         const DualOut<T> o = dual_elem<T, false>(hxv, wcur[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
         yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
 #if !(RN_DUAL_ABL & 2)
@@ -3045,7 +3049,7 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
 }
 // PIPE = 1: one vector at a time;  PIPE = 2: double-buffered -- the loads of trip t+1 are requested before trip t is consumed, so
 // a wave always has a trip in flight (the kernel lives on memory-level parallelism: its VALU phase is a gap in the streams)
-template <typename T, bool MATERIALIZE, int PIPE, int LAZY, bool OFFS = false>
+template <typename T, bool MATERIALIZE, int PIPE, int LAZY, bool OFFS = false, bool SCALE = false>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualStageShape g) {
     __shared__ Partial sh_p[ELT_THREADS / 64];
     const T ln = (T)g.lnNext;
@@ -3067,7 +3071,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
         for (int t = 0; t < g.trips; t++) {
             DualSlot<T> s;
             dual_slot_load<T, OFFS>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(s, a, ln, r);
+            dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(s, a, ln, r);
         }
     } else {
         DualSlot<T> sA, sB;
@@ -3075,9 +3079,9 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
         for (int t = 0; t < g.trips; t += 2) {
             const bool hasB = t + 1 < g.trips;
             if (hasB) dual_slot_load<T, OFFS>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(sA, a, ln, r);
+            dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(sA, a, ln, r);
             if (t + 2 < g.trips) dual_slot_load<T, OFFS>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
-            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY, OFFS>(sB, a, ln, r);
+            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(sB, a, ln, r);
         }
     }
 #if RN_DUAL_ABL & 2

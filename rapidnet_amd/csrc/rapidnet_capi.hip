@@ -348,6 +348,18 @@ struct Ctx : CtxBase {
     T *d_cfCut = nullptr, *d_cfOff0 = nullptr, *d_cfOff1 = nullptr;
     int *d_chainPar = nullptr;
     bool hxPending = false;      // d_hx holds the partial primal P of the chain nodes (the next dual update adds the crown's offsets, or cf_finish does)
+    bool hxUnscaled = false;     // d_hx holds the primal values of every node (k_down_chain<T, true>): the next dual update applies sqrt(p_i) d_k (k_dual_stage SCALE)
+    int unscaledWalk = -1;       // 1: inner iterations of optimistic batches take that pair of kernels (RAPIDNET_UNSCALED_WALK, default on)
+    bool unscaled_on() {
+        if (unscaledWalk < 0) { const char *e = std::getenv("RAPIDNET_UNSCALED_WALK"); unscaledWalk = e ? (std::atoi(e) != 0) : 1; }
+        return unscaledWalk != 0;
+    }
+    void hx_scale_now() {        // (safety net: a consumer of Hx other than k_dual_stage SCALE behind an unscaled walk)
+        const long long total = ntot();
+        const int blocks = (int)std::min<long long>((total + ELT_THREADS - 1) / ELT_THREADS, (long long)numCUs * 16);
+        hipLaunchKernelGGL(k_hx_scale<T>, dim3(blocks), dim3(ELT_THREADS), 0, stream, d_hx, d_sqrtp, d_dy, d_stageOf, ny, total);
+        hxUnscaled = false;
+    }
     T *d_lo = nullptr, *d_hi = nullptr, *d_z = nullptr, *d_res = nullptr;
     T *d_ybuf[2] = {nullptr, nullptr}, *d_wbuf[2] = {nullptr, nullptr};
     T *d_tmp = nullptr;  // nodes*max(2nx,nu) staging for reference-layout get/set
@@ -1536,7 +1548,13 @@ struct Ctx : CtxBase {
             else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
             fuseDone = true; mainPartials = downGrid;
         } else
-        hipLaunchKernelGGL(k_down_chain<T>, dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
+        {
+            // inner iterations of an optimistic batch whose dual update is the stage-tiled kernel reading w: the walk leaves the primal values and
+            // the dual update scales them (k_down_chain UNSC / k_dual_stage SCALE: the walk requests no preconditioner entries; bitwise the same Hx)
+            const bool unsc = allowPending && !a.writePrimal && phase == 0 && !hessianInput && foldCrown && dualU != 0 && !lazy_w() && a.hx == d_hx && unscaled_on();
+            if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
+            else hipLaunchKernelGGL((k_down_chain<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
+        }
         prof_end(e1);
         RN_HIP(hipGetLastError());
         return RN_OK;
@@ -1605,6 +1623,7 @@ struct Ctx : CtxBase {
     // w_t and w_next stored (always the materialising last iteration of a batch); 3 = w read, w_next not stored
     void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false, int lazy = 0) {
         if (flat || dualU == 0) {
+            if (hxUnscaled) hx_scale_now();
             if (hxPending) cf_finish(false);
             if (materialize) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
@@ -1614,6 +1633,13 @@ struct Ctx : CtxBase {
         mainPartials = dualBlocks;
         DualStageShape g = dshape;
         g.lnNext = h_lam[h_it + 1];   // ensure_tables(h_it + n) has run: the table covers every iteration of the batch
+        if (hxUnscaled && lazy == 0 && !materialize) {   // unscaled walk: Hx = sqrt(p_i) d_k * (primal value) is formed here
+            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, false, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, false, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            hxUnscaled = false;
+            return;
+        }
+        if (hxUnscaled) hx_scale_now();
         if (hxPending && lazy == 0 && !materialize) {    // chain-fused sweep: Hx is formed here from the partial primal and the crown's offsets
             DualArgs<T> b = a;
             b.off0 = d_cfOff0; b.off1 = d_cfOff1; b.chainPar = d_chainPar;
@@ -1700,7 +1726,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
-        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxPending = false;
+        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxPending = false; hxUnscaled = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
@@ -1745,7 +1771,7 @@ struct Ctx : CtxBase {
             lazyIn = lazy && k > 0;
             fuseReq = !lazy && fuse_want(); fuseDone = false;
             if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
-            if (int rc = launch_sweep(0, nullptr, k == n - 1)) { lazyIn = false; carryTail = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { lazyIn = false; carryTail = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
             fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
@@ -2095,7 +2121,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
-        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxPending = false;
+        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxPending = false; hxUnscaled = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }
