@@ -759,6 +759,10 @@ __device__ void finalize_optimistic_body(const FinArgs &fin, const PeerTable *pe
 // (the walk is spelled out twice, here and in k_up_chain_cut: shared through a device function it measured 8 us slower on the
 //  493-scenario tree -- 20.1 instead of 11.8 us)
 // SPLIT: the instantiation that adds the second partial m2 of k_stream_gemv's split last round (the other one is the walk as it always was)
+#ifndef RN_UP_PF
+#define RN_UP_PF 24
+#endif
+constexpr int UP_PF = RN_UP_PF;     // stages per batch of loads of k_up_chain: the 22 stages of a Barcelona chain in ONE batch (88 -> see the resource report; the walk down keeps CHAIN_PF: four arrays per stage)
 template <typename T, bool SPLIT = false>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinArgs fin) {
     if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }   // CHAIN_THREADS == ELT_THREADS
@@ -782,10 +786,10 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
                 const bool has = SPLIT && a.N - 1 - j >= top && node >= (size_t)a.splitFirst;
                 mx[j] = has ? a.my2[(node - (has ? (size_t)a.splitFirst : 0)) * 2 * nv + nv + t] : (T)0;
             }
-            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-                T b[CHAIN_PF], m[CHAIN_PF];
+            for (int k = a.N - 1; k >= top; k -= UP_PF) {
+                T b[UP_PF], m[UP_PF];
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < UP_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     b[j] = beta[node * nv + t];
@@ -793,10 +797,10 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
                 }
                 if (SPLIT && k == a.N - 1) {
 #pragma unroll
-                    for (int j = 0; j < STREAM_SPLIT_STAGES && j < CHAIN_PF; j++) m[j] += mx[j];      // (first half) + (second half)
+                    for (int j = 0; j < STREAM_SPLIT_STAGES && j < UP_PF; j++) m[j] += mx[j];      // (first half) + (second half)
                 }
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < UP_PF; j++) {
                     if (k - j >= top) {
                         const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         const T sv = b[j] + rho;                   // s_i
@@ -809,15 +813,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
         } else {
             const int j0 = t - nv;
             T kap = 0, q = 0;
-            for (int k = a.N - 1; k >= top; k -= CHAIN_PF) {
-                T av[CHAIN_PF];
+            for (int k = a.N - 1; k >= top; k -= UP_PF) {
+                T av[UP_PF];
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < UP_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
                     av[j] = qa[(nodeTop + (size_t)(kk - top) * a.K) * nx + j0];
                 }
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < UP_PF; j++) {
                     if (k - j >= top) {
                         const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         kap += q;                                  // kappa_i = kappa_c + q_c
@@ -2444,7 +2448,7 @@ __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage
 // UNSC (inner iterations of a device-resident batch whose dual update is k_dual_stage<..., HXM = 2>): the Hx buffer receives the PRIMAL values
 // (x_i | x_i | u_i) and the dual update applies the scaling sqrt(p_i) d_k -- it has that factor in registers for the bounds anyway, the product is
 // the same two roundings -- so the walk does not request the preconditioner table at all (a third to a half of its load instructions)
-template <typename T, bool UNSC = false>
+template <typename T, bool UNSC = false, int PF = CHAIN_PF>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, int foldCrown) {
     // foldCrown = 2 (sharded runs): the grid has one more workgroup per crown node behind the K chain workgroups; it writes that
     // node (root -> node walk at the end of this kernel) while the chain workgroups walk their chains, instead of 18 of the 62
@@ -2500,10 +2504,10 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         }
                     }
             } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-            for (int k = top; k < a.N; k += CHAIN_PF) {
-                T dv[CHAIN_PF], uh[CHAIN_PF], d0[CHAIN_PF];
+            for (int k = top; k < a.N; k += PF) {
+                T dv[PF], uh[PF], d0[PF];
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < PF; j++) {
                     const int kk = k + j < a.N ? k + j : a.N - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
@@ -2511,7 +2515,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + 2 * nx + t];
                 }
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < PF; j++) {
                     if (k + j < a.N) {
                         const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         run += dv[j];
@@ -2548,10 +2552,10 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                 bw = par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0];
                 xr = par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0];
             }
-            for (int k = top; k < a.N; k += CHAIN_PF) {
-                T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
+            for (int k = top; k < a.N; k += PF) {
+                T dv[PF], ev[PF], d0[PF], d1[PF];
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < PF; j++) {
                     const int kk = k + j < a.N ? k + j : a.N - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
@@ -2560,7 +2564,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     d1[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + nx + j0];
                 }
 #pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
+                for (int j = 0; j < PF; j++) {
                     if (k + j < a.N) {
                         const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         bw += dv[j];

@@ -42,6 +42,9 @@
 #ifndef RN_DUAL_REGEN
 #define RN_DUAL_REGEN 1
 #endif
+#ifndef RN_DOWN_PF_UNSC
+#define RN_DOWN_PF_UNSC 12   // stages per batch of loads of the unscaled walk (24: one batch, 212 registers, two waves per SIMD: 16.6 -> 16.8 us)
+#endif
 #ifndef RN_FOLD_ROOT
 #define RN_FOLD_ROOT 1
 #endif
@@ -1552,7 +1555,7 @@ struct Ctx : CtxBase {
             // inner iterations of an optimistic batch whose dual update is the stage-tiled kernel reading w: the walk leaves the primal values and
             // the dual update scales them (k_down_chain UNSC / k_dual_stage SCALE: the walk requests no preconditioner entries; bitwise the same Hx)
             const bool unsc = allowPending && !a.writePrimal && phase == 0 && !hessianInput && foldCrown && dualU != 0 && !lazy_w() && a.hx == d_hx && unscaled_on();
-            if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
+            if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true, RN_DOWN_PF_UNSC>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
             else hipLaunchKernelGGL((k_down_chain<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         }
         prof_end(e1);
