@@ -1017,5 +1017,26 @@ __global__ void __launch_bounds__(ELT_THREADS) k_hx_scale(T *hx, const T *sqrtp,
     }
 }
 
+// Opening of an optimistic batch in ONE launch: the checkpoint of (y, y+, w) the exact replay would start from, the verdict flag cleared, and -- sharded
+// contexts -- the 2-element dist^2 tail of the cut payload zeroed (three device-to-device copies, a fill and, sharded, one more fill before: per batch
+// of 20 iterations that was 4-5 launches of 5-6 us each; the copies of the small trees are launch floors).
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_batch_open(const T *y0, const T *y1, const T *w, T *c0, T *c1, T *c2, long long n, IterState *st, T *tail) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->violated = 0; if (tail) { tail[0] = (T)0; tail[1] = (T)0; } }
+    const long long nv = n / VN;
+    const bool aligned = ((((size_t)y0 | (size_t)y1 | (size_t)w | (size_t)c0 | (size_t)c1 | (size_t)c2) & 15) == 0);
+    if (aligned) {
+        for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * ELT_THREADS) {
+            const VT a = reinterpret_cast<const VT *>(y0)[i], b = reinterpret_cast<const VT *>(y1)[i], c = reinterpret_cast<const VT *>(w)[i];
+            reinterpret_cast<VT *>(c0)[i] = a; reinterpret_cast<VT *>(c1)[i] = b; reinterpret_cast<VT *>(c2)[i] = c;
+        }
+        for (long long i = nv * VN + (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * ELT_THREADS) { c0[i] = y0[i]; c1[i] = y1[i]; c2[i] = w[i]; }
+    } else {
+        for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * ELT_THREADS) { c0[i] = y0[i]; c1[i] = y1[i]; c2[i] = w[i]; }
+    }
+}
+
 }  // namespace rn
 #endif

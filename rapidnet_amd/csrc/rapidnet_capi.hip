@@ -1754,14 +1754,10 @@ struct Ctx : CtxBase {
         for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         if (int rc = ensure_tables(h_it + n)) return rc;
         // checkpoint
-        RN_HIP(hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream));
-        RN_HIP(hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream));
-        RN_HIP(hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream));
+        const size_t tail = cut_tail_offset();
+        batch_open(d_cut + tail);  // checkpoint of (y, y+, w), the payload's dist^2 tail and the verdict flag cleared: one launch
         T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
         const bool s_ready = acc_ready;
-        const size_t tail = cut_tail_offset();
-        RN_HIP(hipMemsetAsync(d_cut + tail, 0, 2 * sizeof(T), stream));
-        RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
         carryTail = true; inBatch = true;
         const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
@@ -1829,6 +1825,21 @@ struct Ctx : CtxBase {
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
+    void batch_open(T *tail) {
+        static const int one = [] { const char *e = std::getenv("RAPIDNET_BATCH_OPEN"); return e ? std::atoi(e) : 1; }();   // 0: the copies and fills as launches of their own (A/B)
+        if (!one) {
+            const size_t bytes = (size_t)ntot() * sizeof(T);
+            (void)hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream);
+            (void)hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream);
+            (void)hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream);
+            if (tail) (void)hipMemsetAsync(tail, 0, 2 * sizeof(T), stream);
+            (void)hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream);
+            return;
+        }
+        const long long n = ntot();
+        const int blocks = (int)std::max<long long>(1, std::min<long long>((n / (16 / (long long)sizeof(T)) + ELT_THREADS - 1) / ELT_THREADS, (long long)numCUs * 8));
+        hipLaunchKernelGGL(k_batch_open<T>, dim3(blocks), dim3(ELT_THREADS), 0, stream, (const T *)p_xi, (const T *)p_upd, (const T *)p_acc, d_ck[0], d_ck[1], d_ck[2], n, d_state, tail);
+    }
     // Single GPU, optimistic bookkeeping: the same idea without a collective.  The fused dual update runs the prox as a
     // pure projection; instead of a decision launch after every iteration (the 64-workgroup fix-up launch, ~5 us that
     // almost always exits at once) the fold of its partials, the history entry and the distance check of iteration t ride
@@ -1839,12 +1850,9 @@ struct Ctx : CtxBase {
         const size_t bytes = (size_t)ntot() * sizeof(T);
         for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         if (int rc = ensure_tables(h_it + n)) return rc;
-        RN_HIP(hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream));
-        RN_HIP(hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream));
-        RN_HIP(hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream));
+        batch_open(nullptr);       // checkpoint of (y, y+, w) + the verdict flag cleared: one launch
         T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
         const bool s_ready = acc_ready;
-        RN_HIP(hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream));
         const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
