@@ -3424,8 +3424,11 @@ __device__ void finalize_optimistic_body(const FinArgs &fin, const PeerTable *pe
 }
 template <typename T>
 __global__ void __launch_bounds__(ELT_THREADS) k_finalize_optimistic(const Partial *partials, int nblocks, IterState *st, T *tail,
-                                                                     double *hist, double *histParts, int histCap, double thrX, double thrS) {
+                                                                     double *hist, double *histParts, int histCap, double thrX, double thrS, int *hostVerdict = nullptr) {
     finalize_optimistic_body<T>(FinArgs{partials, nblocks, st, (void *)tail, hist, histParts, histCap, thrX, thrS});
+    // single GPU: the batch's verdict goes straight into a host-mapped word (thread 0 did the bookkeeping above: program order), so the host
+    // reads it behind its stream synchronisation without a device-to-host copy of its own
+    if (hostVerdict != nullptr && threadIdx.x == 0) __hip_atomic_store(hostVerdict, st->violated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Sharded APG, end of a batch (SmpcController::updatePrimalInfeasibity, SmpcController.cu:1480-1496, records ONE tree-global value
 // per iteration in vecPrimalInfs, :1521): the ranks' history entries are made tree-global by one MAX all-reduce per BATCH, which

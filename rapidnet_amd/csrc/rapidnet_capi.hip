@@ -351,6 +351,7 @@ struct Ctx : CtxBase {
     T *d_cfCut = nullptr, *d_cfOff0 = nullptr, *d_cfOff1 = nullptr;
     int *d_chainPar = nullptr;
     bool hxPending = false;      // d_hx holds the partial primal P of the chain nodes (the next dual update adds the crown's offsets, or cf_finish does)
+    int *h_verdict = nullptr;    // host-mapped word the last launch of a single-GPU optimistic batch writes the batch's verdict into (nullptr: not granted -- a copy is used)
     bool hxUnscaled = false;     // d_hx holds the primal values of every node (k_down_chain<T, true>): the next dual update applies sqrt(p_i) d_k (k_dual_stage SCALE)
     int unscaledWalk = -1;       // 1: inner iterations of optimistic batches take that pair of kernels (RAPIDNET_UNSCALED_WALK, default on)
     bool unscaled_on() {
@@ -435,6 +436,7 @@ struct Ctx : CtxBase {
         for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         for (auto e : freeEvents) (void)hipEventDestroy(e);
         for (void *p : ipcOpened) (void)hipIpcCloseMemHandle(p);
+        if (h_verdict) (void)hipHostFree(h_verdict);
         if (d_inbox) (void)hipFree(d_inbox);
         for (void *p : allocs) (void)hipFree(p);
         if (evCommFork) (void)hipEventDestroy(evCommFork);
@@ -701,6 +703,11 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) numCUs = cu; }
+        {
+            const char *e = std::getenv("RAPIDNET_HOST_VERDICT");      // 0: the verdict is copied back (A/B)
+            if (e && std::atoi(e) == 0) h_verdict = nullptr;
+            else if (hipHostMalloc((void **)&h_verdict, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_verdict = nullptr; } else *h_verdict = 0;
+        }
         const int N = d.N, nodes = d.nodes;
         // validate and convert the tree (reference conventions -> 0-based parent/children ranges)
         h_stageCum.assign(tr->nodesPerStageCumul, tr->nodesPerStageCumul + N + 1);
@@ -1875,7 +1882,7 @@ struct Ctx : CtxBase {
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
                 hipEvent_t e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, (T *)nullptr,
-                                   d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize);
+                                   d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize, h_verdict);
                 prof_end(e3);
             } else pendingFin = true;
             std::swap(p_xi, p_upd);
@@ -1884,8 +1891,13 @@ struct Ctx : CtxBase {
         }
         RN_HIP(hipGetLastError());
         int violated = 0;
-        RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
-        RN_HIP(hipStreamSynchronize(stream));
+        if (h_verdict && n > 0) {      // written by the batch's last launch (k_finalize_optimistic): no copy, one synchronisation
+            RN_HIP(hipStreamSynchronize(stream));
+            violated = *(volatile int *)h_verdict;
+        } else {
+            RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
+            RN_HIP(hipStreamSynchronize(stream));
+        }
         if (violated) {   // replay the batch exactly
             fallbacks++;
             p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
