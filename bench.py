@@ -953,32 +953,6 @@ def main():
                                  "roofline target names it)"}
             except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
                 fused = {"error": "%s: %s" % (type(e).__name__, e)}
-        # the other opt-in form of the helper path, same context, same protocol: one workgroup per chain (pair of chains) + one for the crown
-        # (rn_set_sweep_form; csrc/chain_kernels.hpp) -- iterates agree with the six-launch form to rounding, so the context's state simply carries on
-        chain_fused = None
-        if fused_ab and not sharded and not structured and rep and hasattr(s, "setSweepForm"):
-            try:
-                if s.setSweepForm(1) == 1:
-                    iterate(40)
-                    crep = []
-                    for _ in range(len(rep)):
-                        barrier()
-                        t0 = time.perf_counter()
-                        iterate(steps)
-                        barrier()
-                        crep.append(time.perf_counter() - t0)
-                    cm, um = float(np.median(crep)), float(np.median(rep))
-                    chain_fused = {"value": steps / cm, "ms_per_step": 1e3 * cm / steps, "ms_per_step_min": 1e3 * min(crep) / steps, "ms_per_step_max": 1e3 * max(crep) / steps,
-                                   "regions": len(crep), "same_context_six_launches": {"ms_per_step": 1e3 * um / steps, "regions": len(rep)}, "speedup": um / cm,
-                                   "what": "rn_set_sweep_form(ctx, 1): k_chain_sweep_reg + k_cut_partial_sums + k_crown_small_reg, the crown's offsets added inside k_dual_stage "
-                                           "(4 helper launches instead of 5; iterates within 1e-11 of the six-launch form); timed in the headline's own context; opt-in because it is slower"}
-                else:
-                    chain_fused = {"error": "the context does not qualify (crown of more than 32 nodes, chains of more than 32, or one chain from the root)"}
-                s.setSweepForm(0)
-                iterate(40)
-                s.synchronize()
-            except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
-                chain_fused = {"error": "%s: %s" % (type(e).__name__, e)}
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
         ctrl_ms = None
         if not sharded and control_step:
@@ -1132,7 +1106,7 @@ def main():
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
-               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res, "fused_walk_dual": fused, "chain_fused_sweep": chain_fused}
+               "dims": (s.nx, s.nu, s.nv, s.nd, s.N), "alt_exchange": alt_res, "fused_walk_dual": fused}
         s.close()
         return res
 
@@ -1217,8 +1191,6 @@ def main():
             out["structured_mode"] = {"error": struct_error}
         if dense is not None and dense.get("fused_walk_dual"):
             out["fused_walk_dual"] = dense["fused_walk_dual"]
-        if dense is not None and dense.get("chain_fused_sweep"):
-            out["chain_fused_sweep"] = dense["chain_fused_sweep"]
         if head.get("per_rank"):
             out["per_rank"] = head["per_rank"]
         if args.worker:   # under a supervisor (N > 1): the headline is on record from here on -- a first, partial line; the supervisor keeps

@@ -375,29 +375,11 @@ int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64 /* 64 bytes out */);
 int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 bytes, rank order */, int nranks);
 int rn_set_exchange_transport(rn_ctx *ctx, int transport);
-/* Overlapped exchange (opt-in; transport 0 only; measured on one GPU it LOSES 27-29 us per iteration to the two cross-stream
- * dependencies it needs, more than the 12 us of products it can hide: DESIGN.md section 6).  Of one iteration's shared-operator products
- * (SmpcController.cu:604-611, :692-736) only the crown's depend on the exchanged children sums; with 1 the per-iteration all-reduce
- * runs on a stream of its own while the solver's stream multiplies the chain region's nodes, and only the crown's slabs -- and the
- * forward walk behind them -- wait for it.  Same launches on the same data in the same order per node: identical iterates. */
-int rn_set_exchange_overlap(rn_ctx *ctx, int on);
 /* The forward walk and the fused dual update of the nodes it has just walked in ONE launch (k_down_chain_dual: Hx stays in LDS between
  * the two; SmpcController.cu:676-747 + :759-864 per node) inside batches of >= 16 iterations; identical iterates.  Opt-in (default:
  * $RAPIDNET_FUSE_DOWN_DUAL, else off): 0.9 % faster per iteration on the 493-scenario tree, slower on small shards, and the default
  * keeps the dual update a kernel of its own (the one the roofline target names). */
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on);
-/* Form of the sweep's helper path behind the streaming launch (SmpcController.cu:587-747: the vector recursions and the products with
- * the shared matrices).  0 (default): the six-launch form (up_chain | up_crown | gemm_vlv | down_chain).  1: CHAIN-FUSED wherever it
- * applies -- single-GPU contexts, plain sweeps, trees whose crown (the stages above the K parallel chains) has at most 32 nodes and whose
- * chains have at most 32: one workgroup per chain (or pair of chains) does the leaf-to-top sums, both MFMA products and the local
- * top-to-leaf sums of ITS chain in LDS, one workgroup does the crown, and the dual update adds the crown's offsets
- * (csrc/chain_kernels.hpp: four helper launches instead of five, 44 MB less through global memory per iteration on the 493-scenario
- * tree).  Opt-in because it is SLOWER on this part: the chain launch is 22 us shorter than the three it replaces, the crown -- a few nodes in
- * one workgroup behind the children sums -- 33 us longer (DESIGN.md section 3 has the in-kernel phase times).  The two forms associate
- * the sums along a chain differently: iterates agree to rounding, not bitwise.  `*active` (may be NULL) returns the form sweeps will
- * use: 1 only if the context qualifies.  $RAPIDNET_CHAIN_FUSED=1 makes 1 the default of new contexts. */
-int rn_set_sweep_form(rn_ctx *ctx, int form, int *active);
-
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red
  * zone on both sides; red zones and payloads of floating-point buffers start as NaN (0xFF bytes), so an out-of-bounds or

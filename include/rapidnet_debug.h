@@ -47,6 +47,26 @@ int rn_debug_peer_seq(rn_ctx *ctx, unsigned int seq);
  * first buffer */
 int rn_debug_guard_poke(rn_ctx *ctx, int nbytes);
 
+/* Launch-shape choices the library makes by problem size, forced from outside: the parity tests run the kernels that only large
+ * trees take (three slabs per workgroup, double-buffered dual update, ...) on small ones, and the A/B tools time a shipped choice against
+ * its alternative.  value = -1 gives the choice back to the library.  Before the factor step only: RN_E_STATE afterwards.  Every knob
+ * selects between forms with IDENTICAL results (bitwise where the test of the knob says so); none changes what is computed. */
+enum {
+    RN_KNOB_DUAL_TRIPS = 0,        /* k_dual_stage: 16-byte vectors per thread (1 .. 64) */
+    RN_KNOB_DUAL_PIPE = 1,         /* k_dual_stage: 1 = one vector at a time, 2 = double-buffered */
+    RN_KNOB_VLV_WIDE = 2,          /* v / Lv products: slabs per workgroup of k_gemm_vlv_wide (2, 3; 0 / 1 = k_gemm_vlv) */
+    RN_KNOB_SLAB_PIPE = 3,         /* slab products: 1 = the software-pipelined MFMA loop, 0 = the lean one */
+    RN_KNOB_SLAB_FRAG = 4,         /* slab products: 0 = A operands from the column-major operators instead of the fragment-ordered copies */
+    RN_KNOB_UNSCALED_WALK = 5,     /* 0 = the forward walk always applies the preconditioner itself (k_down_chain / k_dual_stage pair) */
+    RN_KNOB_STREAM_TWO_PER_CU = 6, /* k_stream_gemv: 1 = the instantiation that leaves room for two workgroups per CU, 0 = the other */
+    RN_KNOB_STREAM_SPLIT = 7,      /* k_stream_gemv: 0 = the last partial round is not split by columns */
+    RN_KNOB_NAMA_PAIR = 8,         /* NAMA: 0 = its two Hessian sweeps one after the other instead of one pass over the operator blocks */
+    RN_KNOB_LS_SEQUENTIAL = 9,     /* global FBE / NAMA: 1 = trial-by-trial line search instead of the batched candidates */
+    RN_KNOB_VALUE_MFMA = 10,       /* global FBE / NAMA: 0 = the value's primal terms on the vector ALUs */
+    RN_KNOB_COUNT = 11
+};
+int rn_debug_set_knob(rn_ctx *ctx, int knob, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ def _stamp(out, srcs, extra=()):
 
 
 def kernel_sources():
-    return [os.path.join(CSRC, f) for f in ("rapidnet_capi.hip", "kernels.hpp", "fbe_kernels.hpp", "chain_kernels.hpp", "fbe_methods.inc")]
+    return [os.path.join(CSRC, f) for f in ("rapidnet_capi.hip", "kernels.hpp", "fbe_kernels.hpp", "fbe_methods.inc")]
 
 
 def kernel_sources_sha256():

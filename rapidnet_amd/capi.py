@@ -19,6 +19,9 @@ RN_F32, RN_F64 = 0, 1
 ALG_APG, ALG_GLOBAL_FBE, ALG_NAMA = 0, 1, 2
 ALGORITHMS = {"proximalAlgorithm": ALG_APG, "globalFbeAlgorithm": ALG_GLOBAL_FBE, "namaAlgorithm": ALG_NAMA}  # Engine.cu:151-163
 OP_PHI, OP_PSI, OP_D, OP_F, OP_OMEGA, OP_THETA, OP_G = range(7)
+# include/rapidnet_debug.h, RN_KNOB_*
+KNOBS = {k: i for i, k in enumerate(("dual_trips", "dual_pipe", "vlv_wide", "slab_pipe", "slab_frag", "unscaled_walk", "stream_two_per_cu",
+                                     "stream_split", "nama_pair", "ls_sequential", "value_mfma"))}
 
 # every symbol include/rapidnet.h (the boundary) and include/rapidnet_debug.h (test hooks, rn_debug_*) declare
 SYMBOLS = [
@@ -36,7 +39,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_exchange_overlap", "rn_set_fused_walk_dual", "rn_set_sweep_form",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_fused_walk_dual", "rn_debug_set_knob",
 ]
 
 
@@ -206,9 +209,8 @@ def load():
     lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
     lib.rn_debug_peer_seq.argtypes = [vp, C.c_uint]
     lib.rn_set_exchange_transport.argtypes = [vp, ip]
-    lib.rn_set_exchange_overlap.argtypes = [vp, ip]
     lib.rn_set_fused_walk_dual.argtypes = [vp, ip]
-    lib.rn_set_sweep_form.argtypes = [vp, ip, C.POINTER(C.c_int)]
+    lib.rn_debug_set_knob.argtypes = [vp, ip, ip]
     lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
     _LIB = lib
     return lib
@@ -239,7 +241,7 @@ class Solver:
     """
 
     def __init__(self, network, tree, config, precision="f64", device=0, structured=False, rank=0, nranks=1, cut_stage=0,
-                 unique_id=None):
+                 unique_id=None, knobs=None):
         """nranks > 1: `tree` is the FULL scenario tree and the context is rank `rank`'s shard of it (rn_create_sharded:
         partition, communicator from `unique_id` -- None = none, the exchange is a test's job --, cut stage, children
         moments); self.nodes is then the LOCAL node count and self.global_nodes maps local -> full-tree node ids."""
@@ -276,6 +278,8 @@ class Solver:
                                                float(_s(config, "penaltySafetyX"))))
         if self.structured:
             self._check(self.lib.rn_set_operator_mode(self.h, 1))
+        for k, v in (knobs or {}).items():
+            self.debugSetKnob(k, v)
 
     def close(self):
         if getattr(self, "h", None):
@@ -539,15 +543,11 @@ class Solver:
         """1: forward walk + dual update in one launch inside batches of >= 16 iterations (identical iterates; opt-in)"""
         self._check(self.lib.rn_set_fused_walk_dual(self.h, int(bool(on))))
 
-    def setSweepForm(self, form):
-        """0 (default): the six-launch helper path everywhere; 1: the chain-fused form where the context qualifies (opt-in: measured slower).  Returns 1 if sweeps will be chain-fused."""
-        act = C.c_int(0)
-        self._check(self.lib.rn_set_sweep_form(self.h, int(form), C.byref(act)))
-        return act.value
-
-    def setExchangeOverlap(self, on):
-        """1: the per-iteration all-reduce on a stream of its own, beside the chain region's shared-operator products (identical iterates)"""
-        self._check(self.lib.rn_set_exchange_overlap(self.h, int(bool(on))))
+    def debugSetKnob(self, knob, value):
+        """rn_debug_set_knob (include/rapidnet_debug.h): force a launch-shape choice the library otherwise makes by problem size; before factorStep.
+        knob: a KNOB_* id or its name without the prefix ("dual_trips", "vlv_wide", ...); value -1: the library's own choice"""
+        k = KNOBS[knob.lower()] if isinstance(knob, str) else int(knob)
+        self._check(self.lib.rn_debug_set_knob(self.h, k, int(value)))
 
     def debugGuardPoke(self, nbytes):
         self._check(self.lib.rn_debug_guard_poke(self.h, int(nbytes)))

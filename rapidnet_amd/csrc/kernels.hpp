@@ -94,113 +94,11 @@ __device__ __forceinline__ void peer_push(const PeerTable &p, unsigned int seq, 
         if (r < p.nranks) __hip_atomic_store(p.inbox[r] + wd, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // dst[i] = sum over the ranks, in ascending rank order, of element i of exchange `seq`, for i in [i0, i1): called by a whole
-// workgroup (tid / nthreads); the caller makes the values visible to itself (fence + barrier) before it reads dst back.
-// ONE workgroup pulls the whole payload of all ranks through its CU (8 ranks x 3 793 elements x 16 B = 485 KB for the 8-way split
-// of the 17 x 29 tree), so two things decide its time.  Memory-level parallelism: a thread works in passes of PEER_PASS
-// (element, rank) pairs -- all ranks of one or several of its elements (elements are dealt to the threads interleaved: consecutive
-// lanes read consecutive 16 bytes of one rank's slice) -- and the next pass's loads are requested before the current pass is
-// looked at (two register sets).  And CODE SIZE: this code runs once per launch, cold (the streaming kernel in front has swept
-// the instruction cache's backing store too): a first version that unrolled 32 pairs with a polling loop inlined per packet was
-// 12 000 instructions and cost 10 us of instruction fetch for 1.4 us of loads (tools/probes/probe_uncached.hip).  So: one loop, two
-// passes per trip, and ONE retry block per pass -- a pass with a packet that has not arrived (or a stale first look) is re-read as a
-// whole with system-scope atomic loads until it is complete or the time is up.
-constexpr int PEER_PASS = 16;
-template <typename T>
-struct PeerPass { unsigned long long pk[PEER_PASS][PeerPk<T>::N]; };
-template <typename T>
-__device__ __forceinline__ void peer_pass_load(PeerPass<T> &b, const unsigned long long *base, unsigned int ib, unsigned int i1, int R, int live,
-                                               unsigned int slotsN, unsigned int estep, unsigned int nthreads, bool atomicLoads) {
-    constexpr int N = PeerPk<T>::N;
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-    unsigned int off = ib * N, i = ib;
-    int r = 0;
-#pragma unroll
-    for (int q = 0; q < PEER_PASS; q++) {
-        if (q < live && i < i1) {
-            if (atomicLoads) {
-#pragma unroll
-                for (int h = 0; h < N; h++) b.pk[q][h] = __hip_atomic_load(base + off + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else if (N == 2) {
-                const ull2 v = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(base + off));
-                b.pk[q][0] = v[0]; b.pk[q][N - 1] = v[1];
-            } else b.pk[q][0] = __builtin_nontemporal_load(base + off);
-        }
-        if (++r == R) { r = 0; off += estep - (unsigned int)(R - 1) * slotsN; i += nthreads; } else off += slotsN;
-    }
-}
-template <typename T>
-__device__ __forceinline__ bool peer_pass_complete(const PeerPass<T> &b, unsigned int ib, unsigned int i1, int R, int live, unsigned int nthreads, unsigned int seq) {
-    constexpr int N = PeerPk<T>::N;
-    unsigned int i = ib;
-    int r = 0;
-    bool all = true;
-#pragma unroll
-    for (int q = 0; q < PEER_PASS; q++) {
-        if (q < live && i < i1) {
-#pragma unroll
-            for (int h = 0; h < N; h++) all = all && (unsigned int)(b.pk[q][h] >> 32) == seq;
-        }
-        if (++r == R) { r = 0; i += nthreads; }
-    }
-    return all;
-}
-template <typename T>
-__device__ __forceinline__ void peer_pass_sum(const PeerPass<T> &b, T *dst, unsigned int ib, unsigned int i1, int R, int live, unsigned int nthreads) {
-    constexpr int N = PeerPk<T>::N;
-    unsigned int i = ib;
-    int r = 0;
-    T s = 0;
-#pragma unroll
-    for (int q = 0; q < PEER_PASS; q++) {
-        if (q < live && i < i1) {
-            T v;
-            if (N == 2) v = (T)__hiloint2double((int)(unsigned int)b.pk[q][N - 1], (int)(unsigned int)b.pk[q][0]);
-            else v = (T)__uint_as_float((unsigned int)b.pk[q][0]);
-            s = (r == 0) ? v : s + v;
-            if (r == R - 1) dst[i] = s;
-        }
-        if (++r == R) { r = 0; i += nthreads; }
-    }
-}
-template <typename T>
-__device__ __forceinline__ void peer_gather(const PeerTable &pt, unsigned int seq, T *dst, int i0, int i1s, int tid, int nthreadsS, IterState *st) {
-    static_assert(PEER_PASS >= PEER_MAX, "all ranks of an element are requested together");
-    constexpr int N = PeerPk<T>::N;
-    const int R = pt.nranks;
-    const unsigned int slotsN = pt.slots * N;                         // words between two ranks' slices (32-bit offsets: an inbox is < 2^31 words)
-    const unsigned long long limit = pt.timeoutTicks;
-    const unsigned long long *base = pt.own + (size_t)(seq & 1u) * (size_t)R * slotsN;
-    const long long t0 = wall_clock64();
-    const int CH = PEER_PASS / R, live = CH * R;                      // elements of a thread per pass; (element, rank) pairs per pass
-    const unsigned int nthreads = (unsigned int)nthreadsS, i1 = (unsigned int)i1s, estep = nthreads * N, step = (unsigned int)CH * nthreads;
-    bool ok = true;
-    PeerPass<T> A;
-    unsigned int ib = (unsigned int)(i0 + tid);
-    PeerPass<T> B;
-    if (ib < i1) peer_pass_load<T>(A, base, ib, i1, R, live, slotsN, estep, nthreads, false);
-    // r, the pass bounds and the offsets' increments are wave-uniform (scalar unit); a lane only adds, compares and moves
-    while (ib < i1) {
-#define RN_PEER_TRIP(cur, nxt)                                                                                                                \
-        {                                                                                                                                     \
-            if (ib + step < i1) peer_pass_load<T>(nxt, base, ib + step, i1, R, live, slotsN, estep, nthreads, false);   /* next pass on its way */ \
-            while (!peer_pass_complete<T>(cur, ib, i1, R, live, nthreads, seq)) {   /* rare: a peer is late (or the first look was stale) */   \
-                if ((unsigned long long)(wall_clock64() - t0) > limit) { ok = false; break; }                                                    \
-                __builtin_amdgcn_s_sleep(4);                                                                                                     \
-                peer_pass_load<T>(cur, base, ib, i1, R, live, slotsN, estep, nthreads, true);                                                   \
-            }                                                                                                                                 \
-            peer_pass_sum<T>(cur, dst, ib, i1, R, live, nthreads);                                                                            \
-            ib += step;                                                                                                                       \
-        }
-        RN_PEER_TRIP(A, B)
-        if (ib < i1) RN_PEER_TRIP(B, A)
-#undef RN_PEER_TRIP
-    }
-    if (!ok) st->commFail = 1;
-}
-// The small form, for callers whose threads own one element each and have no registers to spare (k_up_crown: 1 024-thread
-// workgroups, one workgroup per cut parent): four ranks of an element at a time with system-scope atomic loads (always a fresh
-// look), a packet that has not arrived is polled on the spot.  nranks / 4 round trips instead of one -- microseconds on launches
-// that are not on the Barcelona shards' critical path (those gather in k_gemm_vlv, above).
+// workgroup (tid / nthreads) right behind its own pushes -- the cut parent's workgroup of k_up_chain_cut / k_cut_partial_sums gathers
+// the parent's own 223 values x ranks, so the exchange is spread over as many workgroups as there are cut parents.  Four ranks of an
+// element at a time with system-scope atomic loads (always a fresh look), a packet that has not arrived is polled on the spot; the
+// wait is bounded by the wall clock (IterState::commFail on time-out: the grid always drains).  (Round 4's first form gathered the
+// whole payload in workgroup 0 of the v / Lv launch: +5 us on that launch's critical workgroup; removed in round 6.)
 template <typename T>
 __device__ __forceinline__ void peer_gather_small(const PeerTable &pt, unsigned int seq, T *dst, int i0, int i1, int tid, int nthreads, IterState *st) {
     constexpr int N = PeerPk<T>::N;
@@ -476,10 +374,6 @@ __device__ __forceinline__ T extrap_elem(T y1, T y0, T ln) {
     return fma_rn(-ln, y0, a);
 }
 
-// chain-fused sweep (chain_kernels.hpp): the primal value behind an entry of Hx from the chain-local partial p and the offsets of the
-// chain's parent in the crown -- the ONE expression every consumer uses (k_dual_stage OFFS, k_hx_finish), roundings spelled out
-template <typename T>
-__device__ __forceinline__ T cf_primal(T p, T cnt, T off1, T off0) { return p + fma_rn(cnt, off1, off0); }
 template <typename T> struct Slot;
 template <> struct Slot<double> { typedef nat_d2 type; static constexpr int N = 2; };
 template <> struct Slot<float> { typedef nat_f4 type; static constexpr int N = 4; };
@@ -1155,8 +1049,7 @@ __device__ __forceinline__ void up_crown2_wg0(const SweepArgs<T> &a, T *sh, int 
 }
 // one launch per stage, one workgroup per node; the children are split over `parts` thread groups so that all the
 // loads of a node are in flight at once, partial sums are folded through LDS
-// ONESHOT: the instantiation that takes the all-reduced sums out of the one-shot exchange's inbox (the other one is unchanged by it)
-template <typename T, bool ONESHOT = false>
+template <typename T>
 __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh = reinterpret_cast<T *>(smem_raw);            // parts x w
@@ -1165,17 +1058,6 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     const bool presummed = (a.cutSums != nullptr) && (stage == a.cutStage - 1);
-    if (ONESHOT && presummed && a.peer.nranks > 0) {   // one-shot exchange: this node's all-reduced sums (workgroup 0: the dist^2 tail as well) come out of the inbox
-        T *cs = const_cast<T *>(a.cutSums);
-        IterState *st = reinterpret_cast<IterState *>(a.iterState);
-        peer_gather_small<T>(a.peer, a.peerSeq, cs, pos * w, (pos + 1) * w, threadIdx.x, CROWN_THREADS, st);
-        if (blockIdx.x == 0 && a.peerTail && threadIdx.x < 64) {   // (one wave: the 2-element dist^2 tail)
-            const int nP = a.tr.stageCum[stage + 1] - a.tr.stageCum[stage];
-            peer_gather_small<T>(a.peer, a.peerSeq, cs, nP * w, nP * w + 2, threadIdx.x, 64, st);
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
     if (presummed && a.distTail != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         IterState *st = reinterpret_cast<IterState *>(a.iterState);
         const double dX = sqrt((double)a.distTail[0]), dS = sqrt((double)a.distTail[1]);
@@ -1724,13 +1606,8 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_prep_m2(GemmArgs<T
 // of the second product (gL.in is ignored; gL.k must equal gV.m)
 // foldRoot: the leaf-to-root recursion of the ROOT node (stage 0: its children sums) is done here by workgroup 0, which
 // owns the root's slab, instead of in a launch of its own -- the other workgroups do not wait for it.
-// ONESHOT: the instantiation whose crown workgroups take the all-reduced sums out of the one-shot exchange's inbox (cutLds > 0:
-// into an LDS array of that many values behind the crown scratch -- nobody else needs them, and a round trip through global
-// memory would sit on the critical path of the launch's critical workgroup); the other instantiation is unchanged by it
-template <typename T, bool PIPE, bool ONESHOT = false>
-__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a0, int foldRoot, int crownScratch,
-                                                                  int cutLds = 0) {
-    SweepArgs<T> a = a0;
+template <typename T, bool PIPE>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int crownScratch) {
     extern __shared__ unsigned char gemm_smem[];
     T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [s; kappa]
     T *sV = sB + 16 * SB;                        // [16][SV] v of the slab, zero beyond gV.m
@@ -1745,24 +1622,6 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
         const int s1 = a.s1, e1 = a.e1;
         const int lo = s1 > (int)blockIdx.x * 16 ? s1 : (int)blockIdx.x * 16;
         const int hi = e1 < (int)blockIdx.x * 16 + 16 ? e1 : (int)blockIdx.x * 16 + 16;
-        if (ONESHOT && a.peer.nranks > 0 && (blockIdx.x == 0 || lo < hi)) {   // one-shot exchange: the workgroups that use the all-reduced sums take them out of the inbox
-            const int w = a.nv + 2 * a.nx, nP = e1 - s1;
-            T *cs = const_cast<T *>(a.cutSums);
-            if (cutLds >= nP * w + 2) {      // gathered into LDS; the crown step below reads them from there (generic pointers: flat loads)
-                cs = sB + 16 * (SB + SV) + crownScratch;
-                a.cutSums = cs;
-                if (a.distTail) {            // the dist^2 tail: gathered with the payload, or (first iteration of a batch: nobody sent one) what d_cut holds
-                    if (!a.peerTail && threadIdx.x < 2) cs[nP * w + threadIdx.x] = a0.distTail[threadIdx.x];
-                    a.distTail = cs + nP * w;
-                }
-            }
-            IterState *st = reinterpret_cast<IterState *>(a.iterState);
-            // workgroup 0: everything (the root folds all the stage's nodes) and the tail; the others: the nodes of their own slab
-            const int g0 = blockIdx.x == 0 ? 0 : (lo - s1) * w, g1 = blockIdx.x == 0 ? nP * w + (a.peerTail ? 2 : 0) : (hi - s1) * w;
-            peer_gather<T>(a.peer, a.peerSeq, cs, g0, g1, threadIdx.x, blockDim.x, st);
-            __threadfence_block();
-            __syncthreads();
-        }
         // workgroup 0 does both steps in one batch of loads when the children's values fit in the (still unused) slab
         // buffers and it has a thread per component; every dependent batch costs 1-2.5 us right after the streaming kernel
         // has swept the caches and TLBs
@@ -1919,510 +1778,6 @@ __global__ void __launch_bounds__(RN_WIDE_THREADS) k_gemm_vlv_wide(GemmArgs<T> g
     __syncthreads();
     RN_KT(5);
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------------
-// LDS-staged form of the shared-operator products, for launches with MORE slabs than CUs (the whole 493-scenario tree: 679 slabs on
-// 256 CUs; round 5).  k_gemm_vlv / k_gemm_prep_m2 take every A fragment of the shared operator from L2, once per 16-node slab and
-// wave: 297 KB per slab, 200 MB per launch, and the latency of those loads -- not the matrix pipe -- sets the pace (30 us against a
-// 12 us MFMA floor; the register-pipelined k_gemm_vlv_wide only trades latency for occupancy: 31 us).  Here ONE workgroup per CU owns
-// CT consecutive slabs and walks K in chunks of LDSG_KC = 16 columns of the operator; TWO LOADER WAVES copy chunk c + 1 from L2 into
-// the other half of a two-slot LDS ring with global_load_lds_dwordx4 (1 KiB per wave-instruction, no register on the way) while the
-// EIGHT MFMA WAVES multiply chunk c: A and B fragments both come from LDS (ds_read_b64, ~100 cycles, no queue behind a stream), every
-// operator byte is fetched once per CT slabs (164 KB + 137 KB per workgroup instead of 3 x 297 KB), and an MFMA wave never waits for
-// global memory inside the loop.  One s_barrier per chunk: the loaders wait for their own copies (vmcnt(0)) in front of it, the MFMA
-// waves have consumed the chunk they read when they reach it.
-// The operator travels as an LDS IMAGE prepared by the host (LdsImage): per pass of 16 row tiles (256 rows; an MFMA wave owns up to
-// LDSG_TPW = 2 of them) and chunk, 16 columns of `ldm` values, ldm = (rows of the pass) rounded so that ldm % 32 == 16 -- the four
-// k-quarters of a 16x16x4 A fragment then start 128 bytes apart modulo the 256 bytes of one LDS pass: conflict-free ds_read_b64 / b32
-// -- zero padded; a chunk is a whole number of KiB, so the lane-linear copy of global_load_lds reproduces the image as it is.
-// Every output element is the same chain of MFMAs over k (ascending, 4 per instruction) as in k_gemm_vlv: bitwise the same results.
-constexpr int LDSG_MMA = 8, LDSG_LD = 2, LDSG_KC = 16, LDSG_TPW = 2, LDSG_PASS_TILES = LDSG_MMA * LDSG_TPW;
-constexpr int LDSG_THREADS = 64 * (LDSG_MMA + LDSG_LD);
-template <typename T>
-struct LdsImage {
-    const T *img;      // [pass][chunk][LDSG_KC][ldm(pass)]
-    int tiles;         // 16-row tiles of the operator (ceil(m / 16))
-    int chunks;        // kp / LDSG_KC
-};
-__host__ __device__ __forceinline__ int ldsg_pass_tiles(int tiles, int pass) { const int left = tiles - pass * LDSG_PASS_TILES; return left < LDSG_PASS_TILES ? left : LDSG_PASS_TILES; }
-__host__ __device__ __forceinline__ int ldsg_ldm(int passTiles) { const int r = passTiles * 16; return (r % 32 == 16) ? r : r + 16; }
-typedef __attribute__((address_space(1))) const void ldsg_gptr;
-typedef __attribute__((address_space(3))) void ldsg_lptr;
-// end of a chunk step: everything this wave has in flight that the others depend on is complete, then the workgroup's barrier
-__device__ __forceinline__ void ldsg_barrier_mma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void ldsg_barrier_loader() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
-// One product  out = epi(M * in)  for the workgroup's CT slabs.  sIn: [CT * 16][SIN] (zero beyond k), ring: 2 slots of LDSG_KC * ldmMax values;
-// sOut != nullptr keeps the results in LDS as well ([CT * 16][SO]).  Called by ALL waves of the workgroup (MFMA waves: wave < LDSG_MMA).
-// On return every wave has passed the barrier behind the last chunk; the epilogue's LDS writes are NOT yet fenced (the caller's next
-// barrier does that).
-template <typename T, int EPI, int CT>
-__device__ __forceinline__ void ldsg_product(const GemmArgs<T> &g, const LdsImage<T> &im, const T *sIn, int SIN, T *ring, int ringSlot, int node0, int wave, int lane,
-                                             T *sOut, int SO) {
-    typedef typename Mfma16<T>::acc_t acc_t;
-    const int col = lane & 15, kq = lane >> 4;
-    const int passes = (im.tiles + LDSG_PASS_TILES - 1) / LDSG_PASS_TILES;
-    size_t passOff = 0;
-    for (int p = 0; p < passes; p++) {
-        const int pt = ldsg_pass_tiles(im.tiles, p), ldm = ldsg_ldm(pt);
-        const int chunkVals = LDSG_KC * ldm;
-        if (wave >= LDSG_MMA) {
-            // ---- loader waves: chunk c + 1 into the other slot while chunk c is multiplied
-            const int lw = wave - LDSG_MMA;
-            constexpr int PIECE = 1024 / (int)sizeof(T);            // values per 1 KiB piece (one wave-instruction)
-            const int pieces = chunkVals / PIECE;
-            const T *src = im.img + passOff + (size_t)lane * (16 / sizeof(T));
-            for (int c = -1; c < im.chunks; c++) {
-                if (c + 1 < im.chunks) {
-                    const T *cs = src + (size_t)(c + 1) * chunkVals;
-                    T *dst = ring + (size_t)((c + 1) & 1) * ringSlot;
-                    for (int i = lw; i < pieces; i += LDSG_LD)
-                        __builtin_amdgcn_global_load_lds((ldsg_gptr *)(cs + (size_t)i * PIECE), (ldsg_lptr *)(dst + (size_t)i * PIECE), 16, 0, 0);
-                }
-                ldsg_barrier_loader();
-            }
-        } else {
-            // ---- MFMA waves: row tiles wave and wave + LDSG_MMA of this pass, all CT column tiles (slabs)
-            const int nT = wave < pt ? (wave + LDSG_MMA < pt ? 2 : 1) : 0;
-            acc_t acc[LDSG_TPW][CT];
-#pragma unroll
-            for (int j = 0; j < LDSG_TPW; j++)
-#pragma unroll
-                for (int c = 0; c < CT; c++) acc[j][c] = acc_t{0, 0, 0, 0};
-            // the epilogue's operands (m1_i) of the wave's FIRST tile are requested in front of the loop: nothing in the loop waits for
-            // global memory; a second tile's (operators of more than 8 row tiles per pass with an epilogue operand: not the Barcelona
-            // shapes) are requested in the epilogue -- both sets live across the loop cost 24 more registers and spilled (fp64, CT = 3)
-            T auxv[CT][4], scale[CT];
-#pragma unroll
-            for (int c = 0; c < CT; c++) {
-                const int node = node0 + c * 16 + col;
-                const int nodeC = node < g.nodes ? node : g.nodes - 1;
-                scale[c] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int gr = (p * LDSG_PASS_TILES + wave) * 16 + Mfma16<T>::row(lane, reg);
-                    auxv[c][reg] = (EPI != EPI_LV && nT > 0) ? gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1) : (T)0;
-                }
-            }
-            const T *Bp = sIn + (size_t)col * SIN + kq;
-            const int aOff = kq * ldm + wave * 16 + col;              // this lane's element of the wave's first tile, k-step 0 of a chunk
-            ldsg_barrier_mma();                                       // chunk 0 has landed (and the caller's LDS writes are visible)
-            for (int c = 0; c < im.chunks; c++) {
-                const T *Ac = ring + (size_t)(c & 1) * ringSlot + aOff;
-                if (nT > 0) {
-                    T av[LDSG_KC / 4][LDSG_TPW], bv[LDSG_KC / 4][CT];
-#pragma unroll
-                    for (int s = 0; s < LDSG_KC / 4; s++) {
-#pragma unroll
-                        for (int j = 0; j < LDSG_TPW; j++) av[s][j] = Ac[(size_t)(4 * s) * ldm + (j < nT ? j : 0) * (LDSG_MMA * 16)];
-#pragma unroll
-                        for (int cc = 0; cc < CT; cc++) bv[s][cc] = Bp[(size_t)cc * 16 * SIN + c * LDSG_KC + 4 * s];
-                    }
-#pragma unroll
-                    for (int s = 0; s < LDSG_KC / 4; s++)
-#pragma unroll
-                        for (int j = 0; j < LDSG_TPW; j++)
-                            if (j < nT) {
-#pragma unroll
-                                for (int cc = 0; cc < CT; cc++) acc[j][cc] = Mfma16<T>::run(av[s][j], bv[s][cc], acc[j][cc]);
-                            }
-                }
-                ldsg_barrier_mma();
-            }
-            // ---- epilogue
-#pragma unroll
-            for (int j = 0; j < LDSG_TPW; j++) {
-                if (j >= nT) break;
-                const int t = p * LDSG_PASS_TILES + wave + j * LDSG_MMA;
-                if (j > 0 && EPI != EPI_LV) {
-#pragma unroll
-                    for (int c = 0; c < CT; c++) {
-                        const int node = node0 + c * 16 + col;
-                        const int nodeC = node < g.nodes ? node : g.nodes - 1;
-#pragma unroll
-                        for (int reg = 0; reg < 4; reg++) {
-                            const int gr = t * 16 + Mfma16<T>::row(lane, reg);
-                            auxv[c][reg] = gemm_aux<T, EPI>(g, nodeC, gr < g.m ? gr : g.m - 1);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < CT; c++) {
-                    const int node = node0 + c * 16 + col;
-                    const bool nodeOk = node < g.nodes;
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int gr = t * 16 + Mfma16<T>::row(lane, reg);
-                        T r = acc[j][c][reg];
-                        if (EPI == EPI_V) r = auxv[c][reg] + scale[c] * r;
-                        if (EPI == EPI_Z) r = auxv[c][reg] + r;
-                        const bool live = gr < g.m;
-                        if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;
-                        if (sOut && live) sOut[(size_t)(c * 16 + col) * SO + gr] = nodeOk ? r : (T)0;
-                    }
-                }
-            }
-        }
-        passOff += (size_t)im.chunks * chunkVals;
-        // the next pass's chunk 0 goes into slot 0: the last chunk's barrier has been passed by everybody, slot 0 is free
-    }
-}
-// v_i = m1_i - RT [s_i; kappa_i] / (2 p_i)  and  [L v_i ; B L v_i]  (k_gemm_vlv's two products), LDS-staged.
-// LDS: sB [CT * 16][SB] | sV [CT * 16][SV] | ring (2 slots); the second product's ring lies over sB, which is dead by then.
-template <typename T, int CT>
-__global__ void __launch_bounds__(LDSG_THREADS) k_gemm_vlv_lds(GemmArgs<T> gV, GemmArgs<T> gL, LdsImage<T> imV, LdsImage<T> imL, int SB, int SV, int ringSlotV, int ringSlotL,
-                                                             SweepArgs<T> a, int foldRoot) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    T *sB = reinterpret_cast<T *>(gemm_smem);
-    T *sV = sB + (size_t)CT * 16 * SB;
-    T *ringV = sV + (size_t)CT * 16 * SV;
-    T *ringL = sB;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv); foldRoot = 2 never comes here
-        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
-        __threadfence_block();
-        __syncthreads();
-    }
-    const int node0 = blockIdx.x * 16 * CT;
-    const int cnt = gV.nodes - node0 < 16 * CT ? gV.nodes - node0 : 16 * CT;
-    if (wave < LDSG_MMA) {
-        slab_load<T, RN_WIDE_LD>(sB, SB, gV.in, gV.ldin, gV.k, gV.kp, node0, cnt, wave, LDSG_MMA, lane, 16 * CT);
-        for (int i = threadIdx.x; i < CT * 16 * SV; i += 64 * LDSG_MMA) sV[i] = (T)0;
-    }
-    ldsg_product<T, EPI_V, CT>(gV, imV, sB, SB, ringV, ringSlotV, node0, wave, lane, sV, SV);
-    __syncthreads();                            // v of the slabs is complete in sV; sB is free for the second ring
-    ldsg_product<T, EPI_LV, CT>(gL, imL, sV, SV, ringL, ringSlotL, node0, wave, lane, nullptr, 0);
-}
-// Structured operator mode, first product of the sweep (k_gemm_prep_m2), LDS-staged: the slabs of [a; b] are built in LDS straight
-// from the duals by the MFMA waves while the loaders fetch the first chunk of [Bbt | L'].
-template <typename T, int CT>
-__global__ void __launch_bounds__(LDSG_THREADS) k_gemm_prep_m2_lds(GemmArgs<T> g, LdsImage<T> im, SweepArgs<T> a, int SB, int ringSlot) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    T *sB = reinterpret_cast<T *>(gemm_smem);   // [CT * 16][SB]
-    T *ring = sB + (size_t)CT * 16 * SB;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node0 = blockIdx.x * 16 * CT;
-    const int cnt = g.nodes - node0 < 16 * CT ? g.nodes - node0 : 16 * CT;
-    const int nx = a.nx, ny = a.ny, k = g.k;     // k = nx + nu
-    if (wave < LDSG_MMA) {
-        for (int r = wave; r < 16 * CT; r += LDSG_MMA) {         // one slab row (node) per wave and pass
-            const int node = node0 + (r < cnt ? r : 0);
-            const T *dy = a.tr.dy + (size_t)a.tr.stageOf[node] * ny;
-            const size_t y = (size_t)node * ny;
-            const T sp = a.tr.sqrtp[node];
-            for (int t = lane; t < SB; t += 64) {
-                T val = 0;
-                if (r < cnt && t < k) {
-                    if (t < nx) { val = sp * (dy[t] * sweep_w(a, y + t) + dy[nx + t] * sweep_w(a, y + nx + t)); a.qa[(size_t)node * nx + t] = val; }
-                    else { const int j = t - nx; val = sp * dy[2 * nx + j] * sweep_w(a, y + 2 * nx + j); }
-                }
-                sB[(size_t)r * SB + t] = val;
-            }
-        }
-    }
-    ldsg_product<T, EPI_LV, CT>(g, im, sB, SB, ring, ringSlot, node0, wave, lane, nullptr, 0);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// REGISTER-RESIDENT form of the shared-operator products, for launches with more slabs than CUs (round 5).  The shared operators are
-// tiny -- RT: 7 row tiles x 160 columns, [L; BL]: 12 row tiles x 97 columns on the Barcelona network -- and every slab multiplies the
-// SAME operator: one 16-row tile over the full K is 40 (25) fp64 values per lane in the MFMA's A layout.  So a wave loads its tiles
-// ONCE -- FOUR waves, one per SIMD, each with the SIMD's whole register file to itself (512 per lane, arch + accumulation registers:
-// MFMA operands may live in either): wave w keeps RT's tiles w, w + 4 (160 registers) and [L; BL]'s tiles w, w + 4, w + 8 (150) --
-// and the workgroup, one per CU and PERSISTENT, walks the slabs blockIdx,
-// blockIdx + gridDim, ...: per slab two barriers and nothing but LDS reads (the slab's [s; kappa], then its v) between the MFMAs.  No
-// operator byte crosses the L2 in steady state (k_gemm_vlv re-reads 297 KB per slab: 200 MB per launch, and waits for it a third of
-// its time: profiles/r05_sq_counters.json), no barrier per K-chunk (the LDS-staged form above: slower than the L2-fed kernel).
-// The next slab's input is requested into registers before the current slab's MFMAs and written into the other half of a
-// double-buffered slab after them.  Same chain of MFMAs over k for every output element as in k_gemm_vlv: bitwise the same results
-// (the k-steps beyond k that the padded operators carry multiply zeros and are left out).
-// KSV / KSL: k-steps (of 4) of the two products = ceil(k / 4), compile-time: the tiles live in registers.
-constexpr int REGG_WAVES = 4, REGG_THREADS = 64 * REGG_WAVES;   // one wave per SIMD: it may use the whole register file (512 per lane)
-// acc[j] += A[j] (16 x 4 KS, in registers) * B (4 KS x 16, LDS) for the NT tiles of a wave.  One wave per SIMD: nobody else covers a
-// wait, so the B fragments of group g + 1 (REGG_G k-steps) are requested before the MFMAs of group g and pinned behind them (the
-// scheduling barriers keep the compiler from sinking the requests to their first use: "request, wait, multiply" leaves the matrix
-// pipe idle for an LDS round trip per group -- measured: 34 instead of 30 us for the whole launch).  KS is a compile-time constant:
-// the loop unrolls completely, the two fragment sets are renamed, no copies.
-constexpr int REGG_G = 4;
-template <typename T, int KS, int NT>
-__device__ __forceinline__ void regg_mfma(typename Mfma16<T>::acc_t (&acc)[NT], const T (&A)[NT][KS], const T *Bp) {
-    T bc[REGG_G], bn[REGG_G];
-#pragma unroll
-    for (int i = 0; i < REGG_G; i++) bc[i] = Bp[4 * (i < KS ? i : KS - 1)];
-#pragma unroll
-    for (int g = 0; g < KS; g += REGG_G) {
-        if (g + REGG_G < KS) {
-#pragma unroll
-            for (int i = 0; i < REGG_G; i++) bn[i] = Bp[4 * (g + REGG_G + i < KS ? g + REGG_G + i : KS - 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < REGG_G; i++)
-            if (g + i < KS) {
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[j] = Mfma16<T>::run(A[j][g + i], bc[i], acc[j]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + REGG_G < KS) {
-#pragma unroll
-            for (int i = 0; i < REGG_G; i++) { asm volatile("" ::"v"(bn[i])); bc[i] = bn[i]; }
-        }
-    }
-}
-// the slab loop's barriers: LDS traffic complete, then s_barrier -- NOT __syncthreads(), whose fence also drains the vector-memory
-// counter: the next slab's input (requested a slab ahead) and this slab's result stores would be waited for at every barrier
-__device__ __forceinline__ void regg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// REGG_TV / REGG_TL: row tiles per wave of the two operators (ceil(tiles / 4)); NST: staged input values per thread (ceil(16 k / 256))
-template <typename T, int KSV, int KSL, int NST, int REGG_TV, int REGG_TL>
-__global__ void __launch_bounds__(REGG_THREADS, 1) k_gemm_vlv_reg(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int nSlabs) {
-    typedef typename Mfma16<T>::acc_t acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    T *sB0 = reinterpret_cast<T *>(gemm_smem);  // [2][16][SB] slabs of [s; kappa], double-buffered
-    T *sV = sB0 + (size_t)2 * 16 * SB;           // [16][SV] v of the slab, zero beyond gV.m
-    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tilesV = (gV.m + 15) / 16, tilesL = (gL.m + 15) / 16;     // <= REGG_WAVES * REGG_TV, REGG_WAVES * REGG_TL (the host checks)
-    // ---- the operator tiles of this wave, once per launch: tiles wave, wave + 4, ... (padded col-major operators: mp rows, zero beyond m and k)
-    T aV[REGG_TV][KSV], aL[REGG_TL][KSL];
-#pragma unroll
-    for (int j = 0; j < REGG_TV; j++) {
-        const int t = wave + REGG_WAVES * j;
-        const T *pV = gV.M + (size_t)(t < tilesV ? t : 0) * 16 + col + (size_t)kq * gV.mp;
-#pragma unroll
-        for (int s = 0; s < KSV; s++) aV[j][s] = pV[(size_t)(4 * s) * gV.mp];
-    }
-#pragma unroll
-    for (int j = 0; j < REGG_TL; j++) {
-        const int t = wave + REGG_WAVES * j;
-        const T *pL = gL.M + (size_t)(t < tilesL ? t : 0) * 16 + col + (size_t)kq * gL.mp;
-#pragma unroll
-        for (int s = 0; s < KSL; s++) aL[j][s] = pL[(size_t)(4 * s) * gL.mp];
-    }
-    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv): workgroup 0 owns the root's slab and takes it first
-        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 16 * SV; i += REGG_THREADS) sV[i] = (T)0;
-    // the slab's input [16 nodes][k], staged through registers: element e = tid + REGG_THREADS * j  ->  row e / kst, column e % kst
-    const int kst = gV.k;
-    T stage[NST];
-    auto stage_load = [&](int slab) {
-        const int node0 = slab * 16;
-#pragma unroll
-        for (int j = 0; j < NST; j++) {
-            const int e = (int)threadIdx.x + REGG_THREADS * j, r = e / kst, kk = e - r * kst;
-            const bool live = slab < nSlabs && r < 16 && node0 + r < gV.nodes;
-            stage[j] = live ? gV.in[(size_t)(node0 + r) * gV.ldin + kk] : (T)0;
-        }
-    };
-    auto stage_write = [&](T *dst) {
-#pragma unroll
-        for (int j = 0; j < NST; j++) {
-            const int e = (int)threadIdx.x + REGG_THREADS * j, r = e / kst, kk = e - r * kst;
-            if (r < 16) dst[r * SB + kk] = stage[j];
-        }
-    };
-    // (columns k .. 4 ceil(k / 4) of both slab buffers are zeroed here once; the k-steps stop there)
-    for (int i = threadIdx.x; i < 2 * 16 * 4; i += REGG_THREADS) { const int r = i >> 2, c = kst + (i & 3); if (c < SB) sB0[(size_t)r * SB + c] = (T)0; }
-    RN_KT(0);
-    stage_load((int)blockIdx.x);
-    stage_write(sB0);
-    __syncthreads();
-    RN_KT(1);
-    int it = 0;
-    for (int slab = blockIdx.x; slab < nSlabs; slab += gridDim.x, it++) {
-        const T *sB = sB0 + (size_t)(it & 1) * 16 * SB;
-        const int node = slab * 16 + col;
-        const bool nodeOk = node < gV.nodes;
-        const int nodeC = nodeOk ? node : gV.nodes - 1;
-        stage_load(slab + (int)gridDim.x);        // the next slab's input: in flight behind this slab's MFMAs
-        // ---- v = m1 - RT [s; kappa] / (2 p)
-        {
-            T auxv[REGG_TV][4];
-            const T scale = (T)(-0.5) / gV.prob[nodeC];
-#pragma unroll
-            for (int j = 0; j < REGG_TV; j++)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
-                    auxv[j][reg] = gemm_aux<T, EPI_V>(gV, nodeC, gr < gV.m ? gr : gV.m - 1);
-                }
-            acc_t acc[REGG_TV];
-#pragma unroll
-            for (int j = 0; j < REGG_TV; j++) acc[j] = acc_t{0, 0, 0, 0};
-            regg_mfma<T, KSV, REGG_TV>(acc, aV, sB + (size_t)col * SB + kq);     // (tiles past the end multiply tile 0 again: dropped below)
-            if (it < 3) RN_KT(2 + 4 * it);
-#pragma unroll
-            for (int j = 0; j < REGG_TV; j++)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
-                    const T r = auxv[j][reg] + scale * acc[j][reg];
-                    if (wave + REGG_WAVES * j < tilesV && gr < gV.m) {
-                        if (gV.out && nodeOk) gV.out[(size_t)node * gV.ldout + gr] = r;
-                        sV[(size_t)col * SV + gr] = nodeOk ? r : (T)0;
-                    }
-                }
-        }
-        regg_barrier();                          // v of the slab is complete in sV
-        if (it < 3) RN_KT(3 + 4 * it);
-        // ---- [L v ; B L v]
-        {
-            acc_t acc[REGG_TL];
-#pragma unroll
-            for (int j = 0; j < REGG_TL; j++) acc[j] = acc_t{0, 0, 0, 0};
-            regg_mfma<T, KSL, REGG_TL>(acc, aL, sV + (size_t)col * SV + kq);
-            if (it < 3) RN_KT(4 + 4 * it);
-            if (nodeOk) {
-#pragma unroll
-                for (int j = 0; j < REGG_TL; j++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int gr = (wave + REGG_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
-                        if (wave + REGG_WAVES * j < tilesL && gr < gL.m) gL.out[(size_t)node * gL.ldout + gr] = acc[j][reg];
-                    }
-            }
-        }
-        stage_write(sB0 + (size_t)((it + 1) & 1) * 16 * SB);
-        regg_barrier();                          // the next slab's input is in place; sV may be overwritten
-        if (it < 3) RN_KT(5 + 4 * it);
-    }
-}
-
-// The same idea with EIGHT waves (two per SIMD, 256 registers each -- everything in arch registers: no copies out of the accumulation
-// file in front of the MFMAs; the partner wave of a SIMD covers a wave's epilogue, its barrier waits and the one-chain dependency of
-// the v product) and the next slab's input copied global -> LDS by global_load_lds_dwordx4 with PER-LANE source addresses (the LDS
-// image is lane-linear: position o of the padded slab [16][SB] takes its 16 bytes from row o / SB, column o % SB of the node-major
-// input, or from a page of zeros for the padding columns and the rows past the last node): no staging registers at all, three or four
-// pieces per wave and slab.  Wave w: RT's tile w (80 registers), [L; BL]'s tiles w and w + 8 (100).
-constexpr int REG8_WAVES = 8, REG8_THREADS = 64 * REG8_WAVES;
-template <typename T, int KSV, int KSL>
-__global__ void __launch_bounds__(REG8_THREADS, 2) k_gemm_vlv_reg8(GemmArgs<T> gV, GemmArgs<T> gL, int SB, int SV, SweepArgs<T> a, int foldRoot, int nSlabs, const T *zeros) {
-    typedef typename Mfma16<T>::acc_t acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
-    T *sB0 = reinterpret_cast<T *>(gemm_smem);  // [2][16][SB] slabs of [s; kappa], double-buffered
-    T *sV = sB0 + (size_t)2 * 16 * SB;           // [16][SV] v of the slab, zero beyond gV.m
-    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tilesV = (gV.m + 15) / 16, tilesL = (gL.m + 15) / 16;     // <= 8, <= 16 (the host checks)
-    const bool hasV = wave < tilesV, hasL1 = wave + REG8_WAVES < tilesL;
-    T aV[1][KSV], aL[2][KSL];
-    {
-        const T *pV = gV.M + (size_t)(hasV ? wave : 0) * 16 + col + (size_t)kq * gV.mp;
-#pragma unroll
-        for (int s = 0; s < KSV; s++) aV[0][s] = pV[(size_t)(4 * s) * gV.mp];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int t = wave + REG8_WAVES * j;
-            const T *pL = gL.M + (size_t)(t < tilesL ? t : 0) * 16 + col + (size_t)kq * gL.mp;
-#pragma unroll
-            for (int s = 0; s < KSL; s++) aL[j][s] = pL[(size_t)(4 * s) * gL.mp];
-        }
-    }
-    if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv): workgroup 0 owns the root's slab and takes it first
-        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 16 * SV; i += REG8_THREADS) sV[i] = (T)0;
-    // one slab's input into `dst` ([16][SB]) by LDS-DMA, issued by ONE wave; the caller waits (vmcnt(0)) before the barrier that publishes it
-    constexpr int VPL = 16 / (int)sizeof(T), PIECE = 64 * VPL;          // values per lane and per wave-instruction (1 KiB)
-    const int kst = gV.k, kz = (kst + 3) & ~3;                          // columns [kst, kz) must read as zeros, [kz, SB) are never read
-    // Every wave issues the pieces wave, wave + 8, ... (one 1 KiB piece = one wave-instruction); (row, column) of a lane's group in its
-    // first piece are computed once, the step from one of its pieces to the next is wave-uniform.
-    const int r0 = (wave * PIECE + lane * VPL) / SB, c0 = wave * PIECE + lane * VPL - r0 * SB;
-    const int dr = (REG8_WAVES * PIECE) / SB, dc = REG8_WAVES * PIECE - dr * SB;
-    auto slab_dma = [&](int slab, T *dst) {
-        const int node0 = slab * 16, total = 16 * SB;
-        int r = r0, c = c0;
-        for (int p0 = wave * PIECE; p0 < total; p0 += REG8_WAVES * PIECE) {
-            if (p0 + lane * VPL < total) {
-                // a lane's VPL values lie in one row (SB % VPL == 0); they are live when the whole group is inside [0, kst) of a live row
-                const bool rowOk = slab < nSlabs && node0 + r < gV.nodes;
-                const bool live = rowOk && c + VPL <= kst;
-                const bool part = rowOk && c < kst && !live;       // the group straddles kst: element-wise below
-                const T *src = live ? gV.in + (size_t)(node0 + r) * gV.ldin + c : zeros;
-                if (!part) __builtin_amdgcn_global_load_lds((ldsg_gptr *)src, (ldsg_lptr *)(dst + p0), 16, 0, 0);
-            }
-            r += dr; c += dc;
-            if (c >= SB) { c -= SB; r++; }
-        }
-        // (groups that straddle the last column -- k not a multiple of the lane's vector -- are written element by element by wave 0)
-        if (kst % VPL && wave == 0) {
-            for (int rr = lane; rr < 16; rr += 64) {
-                const int cc0 = kst - kst % VPL;
-                for (int cc = cc0; cc < cc0 + VPL && cc < SB; cc++)
-                    dst[rr * SB + cc] = (slab < nSlabs && node0 + rr < gV.nodes && cc < kst) ? gV.in[(size_t)(node0 + rr) * gV.ldin + cc] : (T)0;
-            }
-        }
-        (void)kz;
-    };
-    RN_KT(0);
-    // Slabs of a workgroup: with the root's step folded in (foldRoot = 1), workgroup 0 takes ONLY the root's slab -- the step costs it
-    // ~5 us before its first MFMA, a third slab behind it would be the launch's critical path -- and the others share the rest
-    const bool solo = foldRoot == 1 && gridDim.x > 1;
-    const int slabStep = solo ? (int)gridDim.x - 1 : (int)gridDim.x;
-    const int slabEnd = (solo && blockIdx.x == 0) ? 1 : nSlabs;
-    slab_dma((int)blockIdx.x, sB0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    RN_KT(1);
-    int it = 0;
-    for (int slab = blockIdx.x; slab < slabEnd; slab += slabStep, it++) {
-        const T *sB = sB0 + (size_t)(it & 1) * 16 * SB;
-        const int node = slab * 16 + col;
-        const bool nodeOk = node < gV.nodes;
-        const int nodeC = nodeOk ? node : gV.nodes - 1;
-        slab_dma(slab + slabStep < slabEnd ? slab + slabStep : nSlabs, sB0 + (size_t)((it + 1) & 1) * 16 * SB);   // the next slab's input (3-4 pieces per wave), behind this slab's MFMAs
-        // ---- v = m1 - RT [s; kappa] / (2 p)
-        if (hasV) {
-            T auxv[4];
-            const T scale = (T)(-0.5) / gV.prob[nodeC];
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int gr = wave * 16 + Mfma16<T>::row(lane, reg);
-                auxv[reg] = gemm_aux<T, EPI_V>(gV, nodeC, gr < gV.m ? gr : gV.m - 1);
-            }
-            acc_t acc[1] = {acc_t{0, 0, 0, 0}};
-            regg_mfma<T, KSV, 1>(acc, aV, sB + (size_t)col * SB + kq);
-            if (it < 3) RN_KT(2 + 4 * it);
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int gr = wave * 16 + Mfma16<T>::row(lane, reg);
-                const T r = auxv[reg] + scale * acc[0][reg];
-                if (gr < gV.m) {
-                    if (gV.out && nodeOk) gV.out[(size_t)node * gV.ldout + gr] = r;
-                    sV[(size_t)col * SV + gr] = nodeOk ? r : (T)0;
-                }
-            }
-        }
-        regg_barrier();                          // v of the slab is complete in sV
-        if (it < 3) RN_KT(3 + 4 * it);
-        // ---- [L v ; B L v]
-        {
-            acc_t acc[2] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
-            if (hasL1) regg_mfma<T, KSL, 2>(acc, aL, sV + (size_t)col * SV + kq);
-            else { acc_t a1[1] = {acc[0]}; const T (&aL0)[1][KSL] = reinterpret_cast<const T (&)[1][KSL]>(aL[0]); regg_mfma<T, KSL, 1>(a1, aL0, sV + (size_t)col * SV + kq); acc[0] = a1[0]; }
-            if (it < 3) RN_KT(4 + 4 * it);
-            // this wave's pieces of the next slab's input have landed (requested a slab-time ago; waited for HERE, in front of the result
-            // stores, so that the barrier below need not drain those)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (nodeOk) {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int gr = (wave + REG8_WAVES * j) * 16 + Mfma16<T>::row(lane, reg);
-                        if (wave + REG8_WAVES * j < tilesL && gr < gL.m) gL.out[(size_t)node * gL.ldout + gr] = acc[j][reg];
-                    }
-            }
-        }
-        regg_barrier();                          // the next slab's input is published; sV may be overwritten
-        if (it < 3) RN_KT(5 + 4 * it);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2703,9 +2058,6 @@ struct DualArgs {
     // partials of the main pass; this launch writes its own partials to `partials`.
     int decideHere, itHost, nMain;
     const Partial *mainPartials;
-    // k_dual_stage OFFS (chain-fused sweep): hx holds the partial primal P of the chain nodes; Hx = sqrt(p_i) d (P + off0 + cnt off1) with the
-    // offset rows of the chain's parent (chainPar[chain] = its position in stage c* - 1), cnt = stage - c* + 1
-    const T *off0, *off1; const int *chainPar;
 };
 
 
@@ -2956,9 +2308,8 @@ struct DualStageShape {
 // one 16-byte vector of the tile with everything its update needs (all seven loads are independent)
 template <typename T>
 struct DualSlot {
-    typename VecOf<T>::type hx, w, yp, blo, bhi, dy, o0, o1;
-    T sp, cnt;        // (o0, o1, cnt: OFFS only)
-    bool offs;
+    typename VecOf<T>::type hx, w, yp, blo, bhi, dy;
+    T sp;
     int c;            // column of the vector's first element
     long long iv;     // global vector index
     bool on;
@@ -2968,7 +2319,7 @@ struct DualAcc {      // per-thread running reductions; arg-max keeps the signed
     double d2x = 0, d2s = 0, valXi = 0, valPsi = 0;   // the 32-bit element index of its first occurrence (strict >, ascending walk)
     unsigned int idxXi = 0xffffffffu, idxPsi = 0xffffffffu;
 };
-template <typename T, bool OFFS = false>
+template <typename T>
 __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T> &a, const DualStageShape &g, int trip, int jbase, int cnt,
                                                int nodeFirst, int stageU, bool crownBlock) {
     typedef typename VecOf<T>::type VT;
@@ -2982,9 +2333,6 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
     s.iv = (long long)nodeFirst * g.vpn + J;
     int stage = stageU;
     if (crownBlock) stage = a.stageOf[node];
-    s.offs = OFFS && !crownBlock;
-    int ppos = 0;
-    if (OFFS && !crownBlock) ppos = a.chainPar[q];      // (a regular stage holds the K chains in order: q is the chain) requested first: the offset rows wait for it
     s.hx = reinterpret_cast<const VT *>(a.hx)[s.iv]; s.w = reinterpret_cast<const VT *>(a.w)[s.iv];
     s.yp = reinterpret_cast<const VT *>(a.yprev)[s.iv];
 #if RN_DUAL_ABL & 1
@@ -2995,18 +2343,13 @@ __device__ __forceinline__ void dual_slot_load(DualSlot<T> &s, const DualArgs<T>
     s.blo = *reinterpret_cast<const VT *>(a.blo + s.c);
     s.bhi = *reinterpret_cast<const VT *>(a.bhi + s.c);
 #endif
-    if (OFFS && !crownBlock) {
-        s.cnt = (T)(stageU - g.cs + 1);
-        s.o0 = *reinterpret_cast<const VT *>(a.off0 + (size_t)ppos * a.ny + s.c);
-        s.o1 = *reinterpret_cast<const VT *>(a.off1 + (size_t)ppos * a.ny + s.c);
-    }
 }
 // LAZY = 0: w is read, y+ and w_next are stored.  Device-resident batches of more than one iteration keep the accelerated dual
 // out of memory between their iterations -- the next sweep and the next dual update derive it from the two iterates (4 streams
 // instead of 5, and 21 MB of dirty lines less in front of the streaming kernel): LAZY = 3 (first iteration): w is read, w_next not
 // stored; LAZY = 1 (inner iterations): w derived, w_next not stored; LAZY = 2 (last iteration): w derived, and both w_t (wview)
 // and w_next stored, so that the state a caller can observe is what it always was.
-template <typename T, bool MATERIALIZE, int LAZY, bool OFFS = false, bool SCALE = false>
+template <typename T, bool MATERIALIZE, int LAZY, bool SCALE = false>
 __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualArgs<T> &a, T ln, DualAcc<T> &r) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
@@ -3022,8 +2365,8 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
         const T lo = k * s.blo[e];
         const T hi = (isXi && !isBox) ? s.bhi[e] : k * s.bhi[e];
         wcur[e] = (LAZY == 1 || LAZY == 2) ? extrap_elem(s.yp[e], s.w[e], a.lnCur) : s.w[e];
-        // OFFS: chain-fused sweep (partial primal + the crown's offsets); SCALE: k_down_chain<T, true> left the primal values (every node)
-        const T hxv = (OFFS && s.offs) ? k * cf_primal<T>(s.hx[e], s.cnt, s.o1[e], s.o0[e]) : (SCALE ? k * s.hx[e] : s.hx[e]);
+        // SCALE: k_down_chain<T, true> left the primal values (every node)
+        const T hxv = SCALE ? k * s.hx[e] : s.hx[e];
         const DualOut<T> o = dual_elem<T, false>(hxv, wcur[e], lo, hi, s.yp[e], a.lambda, a.invLambda, ln, (T)0);
         yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
 #if !(RN_DUAL_ABL & 2)
@@ -3053,7 +2396,7 @@ __device__ __forceinline__ void dual_slot_use(const DualSlot<T> &s, const DualAr
 }
 // PIPE = 1: one vector at a time;  PIPE = 2: double-buffered -- the loads of trip t+1 are requested before trip t is consumed, so
 // a wave always has a trip in flight (the kernel lives on memory-level parallelism: its VALU phase is a gap in the streams)
-template <typename T, bool MATERIALIZE, int PIPE, int LAZY, bool OFFS = false, bool SCALE = false>
+template <typename T, bool MATERIALIZE, int PIPE, int LAZY, bool SCALE = false>
 __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualStageShape g) {
     __shared__ Partial sh_p[ELT_THREADS / 64];
     const T ln = (T)g.lnNext;
@@ -3074,18 +2417,18 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dual_stage(DualArgs<T> a, DualS
     if (PIPE == 1) {
         for (int t = 0; t < g.trips; t++) {
             DualSlot<T> s;
-            dual_slot_load<T, OFFS>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(s, a, ln, r);
+            dual_slot_load<T>(s, a, g, t, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE, LAZY, SCALE>(s, a, ln, r);
         }
     } else {
         DualSlot<T> sA, sB;
-        dual_slot_load<T, OFFS>(sA, a, g, 0, jbase, cnt, nodeFirst, stageU, crownBlock);
+        dual_slot_load<T>(sA, a, g, 0, jbase, cnt, nodeFirst, stageU, crownBlock);
         for (int t = 0; t < g.trips; t += 2) {
             const bool hasB = t + 1 < g.trips;
-            if (hasB) dual_slot_load<T, OFFS>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
-            dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(sA, a, ln, r);
-            if (t + 2 < g.trips) dual_slot_load<T, OFFS>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
-            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY, OFFS, SCALE>(sB, a, ln, r);
+            if (hasB) dual_slot_load<T>(sB, a, g, t + 1, jbase, cnt, nodeFirst, stageU, crownBlock);
+            dual_slot_use<T, MATERIALIZE, LAZY, SCALE>(sA, a, ln, r);
+            if (t + 2 < g.trips) dual_slot_load<T>(sA, a, g, t + 2, jbase, cnt, nodeFirst, stageU, crownBlock);
+            if (hasB) dual_slot_use<T, MATERIALIZE, LAZY, SCALE>(sB, a, ln, r);
         }
     }
 #if RN_DUAL_ABL & 2
@@ -3812,6 +3155,38 @@ __global__ void k_pack(T *y, T *part, int ny, int off, int dim, long long nodes,
 template <typename T>
 __global__ void k_clamp_vec(T *u, const T *lo, const T *hi, int n) {   // projectionBox<<<1,nu>>> SmpcController.cu:1649
     for (int i = threadIdx.x; i < n; i += blockDim.x) { const T v = u[i]; u[i] = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v); }
+}
+
+// Hx from the primal values k_down_chain<T, true> left in its place (every node): hx = (sqrt(p_i) d_k) * value -- the expression of
+// k_dual_stage<..., SCALE>; only for a consumer of Hx other than that kernel behind an unscaled walk (does not happen in the batch loops as they are).
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_hx_scale(T *hx, const T *sqrtp, const T *dy, const int *stageOf, int ny, long long total) {
+    for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * ELT_THREADS) {
+        const long long node = i / ny;
+        const int r = (int)(i - node * ny);
+        hx[i] = (sqrtp[node] * dy[(size_t)stageOf[node] * ny + r]) * hx[i];
+    }
+}
+
+// Opening of an optimistic batch in ONE launch: the checkpoint of (y, y+, w) the exact replay would start from, the verdict flag cleared, and -- sharded
+// contexts -- the 2-element dist^2 tail of the cut payload zeroed (three device-to-device copies, a fill and, sharded, one more fill before: per batch
+// of 20 iterations that was 4-5 launches of 5-6 us each; the copies of the small trees are launch floors).
+template <typename T>
+__global__ void __launch_bounds__(ELT_THREADS) k_batch_open(const T *y0, const T *y1, const T *w, T *c0, T *c1, T *c2, long long n, IterState *st, T *tail) {
+    typedef typename VecOf<T>::type VT;
+    constexpr int VN = VecOf<T>::N;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->violated = 0; if (tail) { tail[0] = (T)0; tail[1] = (T)0; } }
+    const long long nv = n / VN;
+    const bool aligned = ((((size_t)y0 | (size_t)y1 | (size_t)w | (size_t)c0 | (size_t)c1 | (size_t)c2) & 15) == 0);
+    if (aligned) {
+        for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < nv; i += (long long)gridDim.x * ELT_THREADS) {
+            const VT a = reinterpret_cast<const VT *>(y0)[i], b = reinterpret_cast<const VT *>(y1)[i], c = reinterpret_cast<const VT *>(w)[i];
+            reinterpret_cast<VT *>(c0)[i] = a; reinterpret_cast<VT *>(c1)[i] = b; reinterpret_cast<VT *>(c2)[i] = c;
+        }
+        for (long long i = nv * VN + (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * ELT_THREADS) { c0[i] = y0[i]; c1[i] = y1[i]; c2[i] = w[i]; }
+    } else {
+        for (long long i = (long long)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * ELT_THREADS) { c0[i] = y0[i]; c1[i] = y1[i]; c2[i] = w[i]; }
+    }
 }
 
 }  // namespace rn

@@ -24,7 +24,6 @@
 #include "../../include/rapidnet.h"
 #include "../../include/rapidnet_debug.h"
 #include "fbe_kernels.hpp"
-#include "chain_kernels.hpp"
 #include "partition.hpp"
 
 #ifndef RN_FIXUP_BLOCKS
@@ -201,9 +200,8 @@ struct CtxBase {
     virtual int peer_inbox_connect_local(CtxBase **, int) = 0;
     virtual unsigned long long *peer_inbox_ptr() = 0;
     virtual int set_exchange_transport(int) = 0;
-    virtual int set_exchange_overlap(int) = 0;
     virtual int set_fused_walk_dual(int) = 0;
-    virtual int set_sweep_form(int, int *) = 0;
+    virtual int set_knob(int, int) = 0;
     virtual int debug_peer_seq(unsigned int) = 0;
     virtual int fbe_counters(long *) = 0;
 };
@@ -340,23 +338,18 @@ struct Ctx : CtxBase {
                                  // soft bounds would otherwise pay checkpoint + replay on every batch of every control step)
     std::vector<double> h_T1, h_T2, h_Lt;   // zero-padded (rows % 16, cols % 4) copies for the MFMA GEMMs
     int chainStage = 0;
-    // chain-fused form of the sweep's helper path (chain_kernels.hpp; opt-in: measured slower): 1 = used wherever it applies
-    // (single-GPU contexts, plain sweeps, trees whose crown fits one workgroup), 0 (default) = the six-launch form everywhere
-    // (rn_set_sweep_form; RAPIDNET_CHAIN_FUSED=1 makes 1 the default of new contexts, for runs of whole test files in that form)
-    int sweepForm = 0;
-    int cfState = -1;            // -1: not looked at yet, 0: the tree / the dimensions do not qualify, 1: buffers and launch shapes are ready
-    int cfCT = 1, cfSB = 0, cfSV = 0, cfSO = 0, cfParents = 0;
-    int cfReg = 0, cfCPW = 1;    // register-resident forms of the two kernels (operators of at most 40 / 28 k-steps); chains per workgroup
-    size_t cfLdsChain = 0, cfLdsCrown = 0;
-    T *d_cfCut = nullptr, *d_cfOff0 = nullptr, *d_cfOff1 = nullptr;
-    int *d_chainPar = nullptr;
-    bool hxPending = false;      // d_hx holds the partial primal P of the chain nodes (the next dual update adds the crown's offsets, or cf_finish does)
     int *h_verdict = nullptr;    // host-mapped word the last launch of a single-GPU optimistic batch writes the batch's verdict into (nullptr: not granted -- a copy is used)
     bool hxUnscaled = false;     // d_hx holds the primal values of every node (k_down_chain<T, true>): the next dual update applies sqrt(p_i) d_k (k_dual_stage SCALE)
-    int unscaledWalk = -1;       // 1: inner iterations of optimistic batches take that pair of kernels (RAPIDNET_UNSCALED_WALK, default on)
-    bool unscaled_on() {
-        if (unscaledWalk < 0) { const char *e = std::getenv("RAPIDNET_UNSCALED_WALK"); unscaledWalk = e ? (std::atoi(e) != 0) : 1; }
-        return unscaledWalk != 0;
+    bool unscaled_on() const { return knob[RN_KNOB_UNSCALED_WALK] != 0; }   // inner iterations of optimistic batches take that pair of kernels (default on)
+    // rn_debug_set_knob (include/rapidnet_debug.h): launch-shape choices the library otherwise makes by problem size, forced by tests and A/B tools
+    // on trees that would not take them by themselves; -1 = the library's own choice.  Before the factor step only.
+    int knob[RN_KNOB_COUNT];
+    int set_knob(int k, int v) override {
+        RN_CHECK(k >= 0 && k < RN_KNOB_COUNT, RN_E_ARG, "rn_debug_set_knob: unknown knob");
+        RN_CHECK(!factored, RN_E_STATE, "rn_debug_set_knob must precede rn_factor_step");
+        knob[k] = v;
+        if (k == RN_KNOB_DUAL_TRIPS || k == RN_KNOB_DUAL_PIPE) dual_stage_setup();
+        return RN_OK;
     }
     void hx_scale_now() {        // (safety net: a consumer of Hx other than k_dual_stage SCALE behind an unscaled walk)
         const long long total = ntot();
@@ -406,8 +399,7 @@ struct Ctx : CtxBase {
     int fullNodes = 0;
     bool has_comm() const { return comm != nullptr || arHook != nullptr; }
     // sum all-reduce, in place, on the solver's stream: the library's RCCL communicator, or the installed stand-in
-    int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */, hipStream_t on = nullptr) {
-        hipStream_t stream = on ? on : this->stream;      // (the overlapped exchange issues the per-iteration collective on a stream of its own)
+    int all_reduce(void *buf, size_t count, bool f64, const char *what, int op = 0 /* ncclSum; 2 = ncclMax */) {
         if (arHook) {
             hipEvent_t ev = prof_begin(4);
             const int rc = arHook(arUser, buf, count, f64 ? 1 : 0, op, (void *)stream);
@@ -439,9 +431,6 @@ struct Ctx : CtxBase {
         if (h_verdict) (void)hipHostFree(h_verdict);
         if (d_inbox) (void)hipFree(d_inbox);
         for (void *p : allocs) (void)hipFree(p);
-        if (evCommFork) (void)hipEventDestroy(evCommFork);
-        if (evCommJoin) (void)hipEventDestroy(evCommJoin);
-        if (commStream) { (void)hipStreamSynchronize(commStream); (void)hipStreamDestroy(commStream); }
         if (evFork) (void)hipEventDestroy(evFork);
         if (evJoin) (void)hipEventDestroy(evJoin);
         if (stream2) (void)hipStreamDestroy(stream2);
@@ -552,11 +541,7 @@ struct Ctx : CtxBase {
     // the shared operators of the slab products once more in MFMA fragment order (kernels.hpp, GemmArgs::Mf): [16-row tile][pair of k-steps][lane][2],
     // zero-padded like the column-major copies (pad16(m) rows, pad4(k) columns): a wave's A operands of two k-steps are one contiguous request
     T *d_RTf = nullptr, *d_LBLf = nullptr, *d_BLf = nullptr;
-    int fragMode = -1;       // 1: the lean loops of the slab products take their A operands from the fragment-ordered copies (RAPIDNET_SLAB_FRAG, default on)
-    bool frag_on() {
-        if (fragMode < 0) { const char *e = std::getenv("RAPIDNET_SLAB_FRAG"); fragMode = e ? (std::atoi(e) != 0) : 1; }
-        return fragMode != 0;
-    }
+    bool frag_on() const { return knob[RN_KNOB_SLAB_FRAG] != 0; }   // the slab products take their A operands from the fragment-ordered copies (default on)
     int upload_fragments(T *dst, const double *src, int m, int k) {
         const int mp = pad16(m), kp = pad4(k), tiles = mp / 16, pairs = kp / 8;
         std::vector<double> tmp((size_t)mp * kp, 0.0);
@@ -569,99 +554,6 @@ struct Ctx : CtxBase {
                     }
         return upload(dst, tmp.data(), tmp.size());
     }
-    // LDS image of a shared operator for the LDS-staged slab products (kernels.hpp, LdsImage): col-major m x k -> per pass of 16 row tiles
-    // and chunk of 16 columns, 16 columns of ldm values, zero padded
-    T *d_imgRT = nullptr, *d_imgLBL = nullptr, *d_imgBL = nullptr;
-    static size_t lds_image_values(int m, int k) {
-        const int tiles = (m + 15) / 16, chunks = pad4(k) / LDSG_KC;
-        size_t tot = 0;
-        for (int p = 0; p * LDSG_PASS_TILES < tiles; p++) tot += (size_t)chunks * LDSG_KC * ldsg_ldm(ldsg_pass_tiles(tiles, p));
-        return tot;
-    }
-    int upload_lds_image(T *dst, const double *src, int m, int k) {
-        static_assert(LDSG_KC == 4 * RN_SLAB_KU, "the operators' K is padded to whole chunks by pad4");
-        const int tiles = (m + 15) / 16, chunks = pad4(k) / LDSG_KC;
-        std::vector<double> img(lds_image_values(m, k), 0.0);
-        size_t off = 0;
-        for (int p = 0; p * LDSG_PASS_TILES < tiles; p++) {
-            const int pt = ldsg_pass_tiles(tiles, p), ldm = ldsg_ldm(pt);
-            for (int col = 0; col < k; col++)
-                for (int r = 0; r < pt * 16; r++) {
-                    const int row = p * LDSG_PASS_TILES * 16 + r;
-                    if (row < m) img[off + (size_t)col * ldm + r] = src[row + (size_t)col * m];
-                }
-            off += (size_t)chunks * LDSG_KC * ldm;
-        }
-        return upload(dst, img.data(), img.size());
-    }
-    LdsImage<T> lds_image(const T *img, int m, int k) const { return LdsImage<T>{img, (m + 15) / 16, pad4(k) / LDSG_KC}; }
-    static int lds_ring_slot(int m) { return LDSG_KC * ldsg_ldm(ldsg_pass_tiles((m + 15) / 16, 0)); }      // values; pass 0 is the tallest
-    // The register-resident persistent form of the v / Lv products (k_gemm_vlv_reg) is instantiated for the operators of the Barcelona
-    // network -- RT: 97 x 160 (7 row tiles, 40 k-steps), [L; BL]: 177 x 97 (12 row tiles, 25 k-steps): BASELINE.json configs 1-3 -- and
-    // was meant for launches with more slabs than CUs (each workgroup then walks 2-3 slabs with its tiles loaded once).
-    int regVlv = -1;
-    T *d_zeroPage = nullptr;      // k_gemm_vlv_reg8: source of the padding columns of its LDS-DMA
-    bool reg_want(int nSlabs) {
-        if (regVlv < 0) {
-            int force = -1;
-            if (const char *e = std::getenv("RAPIDNET_SLAB_REG")) force = std::atoi(e);   // A/B runs and tests: 0 off, 1 on whenever the shape fits
-            const bool shape = d.nv == 97 && d.nx == 63 && d.nu == 114;
-            const int SB = slab_stride(pad4(d.nv + d.nx)), SV = slab_stride(pad4(d.nv));
-            const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
-            regVlv = 0;
-            // OPT-IN (round 5): measured 31.7-34 against 30.2 us on the 493-scenario tree (same box, profiles/r05_ab_slab_reg.txt).  In-kernel
-            // stamps (profiles/r05_ktiming_slab_reg.txt): 679 slabs on 256 persistent workgroups are 3 slabs for two thirds of them (2.65 on
-            // average: the L2-fed kernel's 679 small workgroups balance themselves); the v product runs at 2/3 of the matrix pipe's rate with
-            // two accumulation chains per wave (its tiles come out of the accumulation registers through v_accvgpr_read), the [Lv; BLv]
-            // product at the full rate; and with ONE wave per SIMD nothing covers the epilogues and barriers (1.4 us per slab).
-            // RAPIDNET_SLAB_REG: 1 = four waves with the whole register file each (k_gemm_vlv_reg); 2 = eight waves, arch registers only, the
-            // next slab's input by LDS-DMA (k_gemm_vlv_reg8): on a par with the default after three rounds of tuning (helpers 66.6-66.9
-            // against 66.2-66.5 us, profiles/r05_ab_slab_reg8.txt; per slab 6.4 us in-kernel where the matrix pipes need 4.5:
-            // profiles/r05_ktiming_slab_reg8.txt) -- not faster, so not the default
-            const void *fn = force == 2 ? (const void *)k_gemm_vlv_reg8<T, 40, 25> : (const void *)k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>;
-            if (shape && force > 0 && (bytes <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)) {
-                regVlv = force == 2 ? 2 : 1;
-                if (regVlv == 2 && !d_zeroPage) {
-                    if (dalloc(&d_zeroPage, (size_t)64) != RN_OK || hipMemset(d_zeroPage, 0, 64 * sizeof(T)) != hipSuccess) regVlv = 0;      // (no zero page: the default kernel runs)
-                }
-            } else (void)hipGetLastError();
-        }
-        return regVlv >= 1;
-    }
-    // Slabs per workgroup of the LDS-staged products (0: the L2-fed kernels run).  They pay when a launch has more slabs than CUs --
-    // there the shared operators' fragments, re-read from L2 per slab and wave, set the pace (kernels.hpp) -- and need one
-    // workgroup's LDS to hold CT slabs of both vectors and the two-slot ring: the largest CT <= 3 that fits 160 KB.
-    int ldsCtVlv = -1, ldsCtM2 = -1;
-    bool lds_want() const {
-        int force = -1;
-        if (const char *e = std::getenv("RAPIDNET_SLAB_LDS")) force = std::atoi(e);   // A/B runs and tests: 0 off, 1 on wherever it fits (read when a context launches its first sweep)
-        // OPT-IN (round 5): measured slower than the L2-fed kernels on the 493-scenario tree -- 36.0 against 30.3 us for the v / Lv pair,
-        // 29.6 against 22.4 us for the structured mode's first product (same box, profiles/r05_ab_lds.txt): one workgroup per CU and a
-        // barrier per chunk leave nothing to overlap the prologue, the epilogue and the LDS round trips with, which three co-resident
-        // workgroups of the L2-fed kernel do for each other
-        return force > 0;
-    }
-    size_t lds_bytes_vlv(int ct) const {
-        const int SB = slab_stride(pad4(d.nv + d.nx)), SV = slab_stride(pad4(d.nv));
-        const size_t ringV = (size_t)2 * lds_ring_slot(d.nv), ringL = (size_t)2 * lds_ring_slot(d.nu + d.nx);
-        if (ringL > (size_t)ct * 16 * SB) return (size_t)-1;            // the second product's ring lies over the first slab buffer
-        return ((size_t)ct * 16 * (SB + SV) + ringV) * sizeof(T);
-    }
-    size_t lds_bytes_m2(int ct) const { return ((size_t)ct * 16 * slab_stride(pad4(d.nx + d.nu)) + (size_t)2 * lds_ring_slot(d.nv)) * sizeof(T); }
-    template <typename F3, typename F2>
-    int lds_pick_ct(size_t (Ctx::*bytes)(int) const, F3 f3, F2 f2) {
-        if (!lds_want() || !d_imgRT) return 0;
-        for (int ct : {3, 2}) {
-            const size_t b = (this->*bytes)(ct);
-            if (b == (size_t)-1 || b > 160 * 1024) continue;
-            const void *fn = ct == 3 ? (const void *)f3 : (const void *)f2;
-            if (b <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) return ct;
-            (void)hipGetLastError();
-        }
-        return 0;
-    }
-    int lds_ct_vlv() { if (ldsCtVlv < 0) ldsCtVlv = lds_pick_ct(&Ctx::lds_bytes_vlv, k_gemm_vlv_lds<T, 3>, k_gemm_vlv_lds<T, 2>); return ldsCtVlv; }
-    int lds_ct_m2() { if (ldsCtM2 < 0) ldsCtM2 = lds_pick_ct(&Ctx::lds_bytes_m2, k_gemm_prep_m2_lds<T, 3>, k_gemm_prep_m2_lds<T, 2>); return ldsCtM2; }
     TreeDev<T> tree_dev() const { return TreeDev<T>{d_stageCum, d_parent, d_childStart, d_childCount, d_stageOf, d_sqrtp, d_prob, d_dy}; }
     SweepArgs<T> sweep_args() const {
         SweepArgs<T> a{};
@@ -690,6 +582,7 @@ struct Ctx : CtxBase {
     int init(const rn_dims *dims, const rn_tree *tr, int dev) {
         d = *dims; device = dev;
         g_liveContexts++;
+        for (int &k : knob) k = -1;
         { const char *e = std::getenv("RAPIDNET_GUARD"); guardMode = e && std::atoi(e) != 0; }
         RN_CHECK(d.nx > 0 && d.nu > 0 && d.nv > 0 && d.nd > 0 && d.N > 0 && d.K > 0 && d.nodes > 0, RN_E_ARG, "rn_create: non-positive dimension");
         RN_CHECK(d.nv <= d.nu, RN_E_ARG, "rn_create: nv must not exceed nu");
@@ -703,11 +596,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) numCUs = cu; }
-        {
-            const char *e = std::getenv("RAPIDNET_HOST_VERDICT");      // 0: the verdict is copied back (A/B)
-            if (e && std::atoi(e) == 0) h_verdict = nullptr;
-            else if (hipHostMalloc((void **)&h_verdict, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_verdict = nullptr; } else *h_verdict = 0;
-        }
+        if (hipHostMalloc((void **)&h_verdict, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_verdict = nullptr; } else *h_verdict = 0;
         const int N = d.N, nodes = d.nodes;
         // validate and convert the tree (reference conventions -> 0-based parent/children ranges)
         h_stageCum.assign(tr->nodesPerStageCumul, tr->nodesPerStageCumul + N + 1);
@@ -768,7 +657,6 @@ struct Ctx : CtxBase {
         DA(d_beta, n * nv) DA(d_uhat, n * nu) DA(d_e, n * nx) DA(d_alpha, n * nu)
         DA(d_x, n * nx) DA(d_u, n * nu) DA(d_v, n * nv) DA(d_hx, n * ny)
         DA(d_my, n * 2 * nv) DA(d_qa, n * nx) DA(d_sk, n * (nv + nx)) DA(d_rkq, n * (nv + 2 * nx)) DA(d_lvb, n * (nu + nx)) DA(d_eb, n * nx) DA(d_bw0, nx) DA(d_bw, n * nx)
-        DA(d_imgRT, lds_image_values(nv, nv + nx)) DA(d_imgLBL, lds_image_values(nu + nx, nv)) DA(d_imgBL, lds_image_values(nv, nx + nu))
         DA(d_LBLp, (size_t)pad16(nu + nx) * pad4(nv))
         DA(d_LBLf, (size_t)pad16(nu + nx) * pad4(nv)) DA(d_BLf, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_RTf, (size_t)pad16(nv) * pad4(nv + nx))
         DA(d_BLp, (size_t)pad16(nv) * pad4(nx + nu)) DA(d_ab, n * (nx + nu))
@@ -794,8 +682,6 @@ struct Ctx : CtxBase {
         const long long want = (ntot() + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
         eltBlocks = (int)std::max<long long>(1, std::min<long long>(ELT_MAX_BLOCKS, want));
         dual_stage_setup();
-        if (const char *e = std::getenv("RAPIDNET_CHAIN_FUSED")) sweepForm = std::atoi(e) != 0 ? 1 : 0;
-        if (sweepForm == 1) (void)cf_ready();      // the chain-fused sweep's small buffers: here, so that no control step allocates (the leak check of controlAction)
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         return apg_reset();
     }
@@ -838,7 +724,6 @@ struct Ctx : CtxBase {
             std::copy(Lt.begin(), Lt.end(), BL.begin() + (size_t)nv * nx);
             if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
             if (int rc = upload_fragments(d_BLf, BL.data(), nv, nx + nu)) return rc;
-            if (int rc = upload_lds_image(d_imgBL, BL.data(), nv, nx + nu)) return rc;
         }
         {   // [L ; B L]  ((nu+nx) x nv) for the forward GEMM
             std::vector<double> BLm((size_t)nx * nv), LBL((size_t)(nu + nx) * nv);
@@ -849,14 +734,12 @@ struct Ctx : CtxBase {
             }
             if (int rc = upload_padded(d_LBLp, LBL.data(), nu + nx, nv)) return rc;
             if (int rc = upload_fragments(d_LBLf, LBL.data(), nu + nx, nv)) return rc;
-            if (int rc = upload_lds_image(d_imgLBL, LBL.data(), nu + nx, nv)) return rc;
         }
         std::vector<double> RTm((size_t)nv * (nv + nx));
         std::copy(h_Rinv.begin(), h_Rinv.end(), RTm.begin());
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
         if (int rc = upload_padded(d_RTp, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_fragments(d_RTf, RTm.data(), nv, nv + nx)) return rc;
-        if (int rc = upload_lds_image(d_imgRT, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
         UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
@@ -868,7 +751,6 @@ struct Ctx : CtxBase {
         if (int rc = stream_split_setup()) return rc;
         if (!structured && !d_A) {   // the dense per-node blocks are only allocated when they are used
             if (int rc = dalloc(&d_A, (size_t)d.nodes * strideA)) return rc;
-            if (std::getenv("RAPIDNET_DEBUG_ALLOC")) std::fprintf(stderr, "rapidnet: operator blocks at %p, %zu bytes\n", (void *)d_A, (size_t)d.nodes * strideA * sizeof(T));
         }
         RN_HIP(hipMemsetAsync(d_my, 0, (size_t)d.nodes * 2 * nv * sizeof(T), stream));   // structured mode never writes m1
         ExpandArgs<T> ea{};
@@ -1024,7 +906,7 @@ struct Ctx : CtxBase {
     int stream_split_setup() {
         if (splitFirst >= 0) return RN_OK;
         splitFirst = d.nodes;
-        static const int mode = [] { const char *e = std::getenv("RAPIDNET_STREAM_SPLIT"); return e ? std::atoi(e) : 1; }();   // tuning runs: 0 = off
+        const int mode = knob[RN_KNOB_STREAM_SPLIT] != 0;
         int G, NL;
         stream_shape(&G, &NL);
         const int D = NL <= 2 ? RN_STREAM_D : RN_STREAM_D_WIDE, groups = (ny / G) / D;
@@ -1036,7 +918,7 @@ struct Ctx : CtxBase {
         // 0.2101 | 0.2119, 1/8 shard (5.4 rounds) 0.1352 | 0.1318; fp32 whole tree 0.3838 | 0.3752 (the streaming kernel 313 -> 303 us
         // = 0.84 of the HBM peak).  So: fp32 always, fp64 for launches of fewer than 8 rounds.
         streamTwoPerCU = sizeof(T) == 4 || d.nodes < 8 * numCUs;
-        if (const char *e = std::getenv("RAPIDNET_STREAM_KERNEL")) streamTwoPerCU = std::atoi(e) != 0;   // tuning runs
+        if (knob[RN_KNOB_STREAM_TWO_PER_CU] >= 0) streamTwoPerCU = knob[RN_KNOB_STREAM_TWO_PER_CU] != 0;
         if (!mode || !streamTwoPerCU || structured || d.nodes <= numCUs || r == 0 || 2 * r > numCUs || groups < 2) return RN_OK;
         if (d.N - cs < STREAM_SPLIT_STAGES || r > STREAM_SPLIT_STAGES * K) return RN_OK;     // (the cut never moves the chain region's END)
         if (int rc = dalloc(&d_my2, (size_t)r * 2 * d.nv)) return rc;
@@ -1059,11 +941,8 @@ struct Ctx : CtxBase {
         int G, NL;
         stream_shape(&G, &NL);
         RN_CHECK(NL <= STREAM_NLMAX, RN_E_ARG, "k_stream_gemv: more than 4096 values per operator column are not supported (2*nv too large)");
-        size_t lds = stream_lds(G);
-        {   // tuning runs: RAPIDNET_STREAM_ONE_PER_CU=1 asks for more than half of the CU's LDS, so that only one workgroup fits a CU
-            static const int one = [] { const char *e = std::getenv("RAPIDNET_STREAM_ONE_PER_CU"); return e ? std::atoi(e) : 0; }();
-            if (one && lds < 81 * 1024 && ensure_stream_lds()) lds = 81 * 1024;
-        }
+        const size_t lds = stream_lds(G);
+        RN_CHECK(lds <= 64 * 1024 || (lds <= 160 * 1024 && ensure_stream_lds()), RN_E_ARG, "k_stream_gemv: a span of operator columns does not fit the CU's LDS");
         const int node0 = h_stageCum[a.chainStage];   // first node of the chain region as this sweep sees it
         const StreamSplit<T> sp{a.splitFirst, splitSpanHalf, d_my2};
         const int grid = d.nodes + (d.nodes - a.splitFirst);      // two workgroups for every block of the split round
@@ -1108,7 +987,7 @@ struct Ctx : CtxBase {
     // a CU); the lean one otherwise.  Measured, k_gemm_vlv, lean | pipelined: 31-scenario tree 14.0 | 12.5 us, 1/8 shard 19.4 |
     // 17.7, 1/2 shard (340 slabs) 27.3 | 28.1, whole 493-scenario tree 30.0 | 35.8; fp32 wide network (k_gemm_prep_m2) 954 | 574.
     bool few_slabs() const {
-        static const int force = [] { const char *e = std::getenv("RAPIDNET_SLAB_PIPE"); return e ? std::atoi(e) : -1; }();   // tuning runs
+        const int force = knob[RN_KNOB_SLAB_PIPE];
         return force >= 0 ? force != 0 : ((d.nodes + 15) / 16 <= numCUs || sizeof(T) == 4);
     }
     int slab_waves(int tilesA, int kstepsA, int tilesB, int kstepsB) const {
@@ -1148,14 +1027,6 @@ struct Ctx : CtxBase {
         const int SB = slab_stride(g.kp);
         const size_t lds = (size_t)16 * SB * sizeof(T);
         if (lds <= 64 * 1024) {
-            const int lct = lds_ct_m2();
-            if (lct >= 2) {
-                const LdsImage<T> im = lds_image(d_imgBL, nv, nx + nu);
-                const int grid = ((d.nodes + 15) / 16 + lct - 1) / lct;
-                if (lct == 3) hipLaunchKernelGGL((k_gemm_prep_m2_lds<T, 3>), dim3(grid), dim3(LDSG_THREADS), lds_bytes_m2(3), stream, g, im, a, SB, lds_ring_slot(nv));
-                else hipLaunchKernelGGL((k_gemm_prep_m2_lds<T, 2>), dim3(grid), dim3(LDSG_THREADS), lds_bytes_m2(2), stream, g, im, a, SB, lds_ring_slot(nv));
-                return;
-            }
             const int nw = slab_waves((nv + 15) / 16, g.kp / 4, 0, 0);
             if (few_slabs()) hipLaunchKernelGGL((k_gemm_prep_m2<T, true>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
             else hipLaunchKernelGGL((k_gemm_prep_m2<T, false>), dim3((d.nodes + 15) / 16), dim3(64 * nw), lds, stream, g, a, SB);
@@ -1183,7 +1054,7 @@ struct Ctx : CtxBase {
         if (wideCt >= 0) return wideCt;
         wideCt = 0;
         int want = nSlabs > 4 * numCUs ? 3 : 0;
-        if (const char *e = std::getenv("RAPIDNET_VLV_WIDE")) want = std::min(3, std::max(0, std::atoi(e)));   // tuning runs; 0 / 1: off
+        if (knob[RN_KNOB_VLV_WIDE] >= 0) want = std::min(3, knob[RN_KNOB_VLV_WIDE]);   // 0 / 1: off
         for (; want >= 2; want--) {
             const size_t bytes = ldsPerSlab * want;
             if (bytes > 160 * 1024) continue;
@@ -1199,15 +1070,12 @@ struct Ctx : CtxBase {
     int crown_scratch(size_t ldsSlab) {
         if (crownScratchVals >= 0) return crownScratchVals;
         crownScratchVals = 0;
-        if (const char *e = std::getenv("RAPIDNET_CROWN_LDS")) { if (std::atoi(e) == 0) return 0; }   // tuning runs
         const size_t want = (size_t)h_childCount[0] * (d.nv + 2 * d.nx), bytes = ldsSlab + want * sizeof(T);
         if (bytes > 160 * 1024) return 0;
-        {   // (always: the one-shot instantiations add the cut payload to their LDS)
+        if (bytes > 64 * 1024) {
             // the attribute belongs to the function, not to this context: always the device's whole LDS, never a smaller value later
             if (hipFuncSetAttribute((const void *)k_gemm_vlv<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void *)k_gemm_vlv<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                hipFuncSetAttribute((const void *)k_gemm_vlv<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 return 0;
             }
@@ -1215,53 +1083,22 @@ struct Ctx : CtxBase {
         crownScratchVals = (int)want;
         return crownScratchVals;
     }
-    static int wide_waves() {
-        static const int nw = [] { const char *e = std::getenv("RAPIDNET_VLV_WIDE_WAVES"); const int v = e ? std::atoi(e) : 8; return std::min(RN_WIDE_THREADS / 64, std::max(4, v)); }();
-        return nw;
-    }
+    static int wide_waves() { return std::min(RN_WIDE_THREADS / 64, 8); }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
-    // [n0, n1): the nodes this launch covers (n1 < 0: all of them; n0 a multiple of 16) -- the overlapped exchange runs the products of the
-    // chain region beside the collective and the crown's slabs behind it.  A sub-range is the same kernel on shifted node-major pointers.
-    void launch_v_lv(const SweepArgs<T> &a, int foldRoot, int n0 = 0, int n1 = -1) {
+    void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
-        if (n1 < 0) n1 = d.nodes;
-        const bool whole = n0 == 0 && n1 == d.nodes;
-        const int nSub = n1 - n0;
 #if RN_GEMM_SLAB
-        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk + (size_t)n0 * (nv + nx), nv + nx, a.v + (size_t)n0 * nv, nv, a.my + (size_t)n0 * 2 * nv, 2 * nv,
-                       d_prob + n0, nSub, a.my2, a.splitFirst - n0};
+        GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk, nv + nx, a.v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         if (structured) gV.aux = nullptr;       // m1_i is folded into the v product (d_my's m1 half stays zero): the epilogue has nothing to fetch
-        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v + (size_t)n0 * nv, nv, a.lvb + (size_t)n0 * (nu + nx), nu + nx, nullptr, 0, d_prob + n0, nSub};
+        GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (frag_on()) { gV.Mf = d_RTf; gL.Mf = d_LBLf; }     // (read by the lean loops only: launches with more slabs than CUs)
         if (lds <= 64 * 1024) {
-            const int nSlabs = (nSub + 15) / 16;
-            // more slabs than CUs, Barcelona-shaped operators: the register-resident persistent form (every wave keeps its operator tiles in
-            // registers for the whole launch; kernels.hpp, k_gemm_vlv_reg)
-            if (whole && foldRoot != 2 && reg_want(nSlabs)) {
-                int grid = std::min(nSlabs, numCUs);
-                if (const char *e = std::getenv("RAPIDNET_SLAB_REG_GRID")) { const int g = std::atoi(e); if (g > 0) grid = std::min(grid, g); }   // tests: several slabs per workgroup on a small tree
-                const size_t bytes = ((size_t)2 * 16 * SB + (size_t)16 * SV) * sizeof(T);
-                if (regVlv == 2) hipLaunchKernelGGL((k_gemm_vlv_reg8<T, 40, 25>), dim3(grid), dim3(REG8_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs, (const T *)d_zeroPage);
-                else hipLaunchKernelGGL((k_gemm_vlv_reg<T, 40, 25, 10, 2, 3>), dim3(grid), dim3(REGG_THREADS), bytes, stream, gV, gL, SB, SV, a, foldRoot, nSlabs);
-                return;
-            }
-            // ... or the LDS-staged form (opt-in: loader waves copy the operators' chunks into an LDS ring, CT slabs per workgroup)
-            if (whole && foldRoot != 2) {
-                const int lct = lds_ct_vlv();
-                if (lct >= 2) {
-                    const LdsImage<T> imV = lds_image(d_imgRT, nv, nv + nx), imL = lds_image(d_imgLBL, nu + nx, nv);
-                    const int grid = (nSlabs + lct - 1) / lct;
-                    const size_t bytes = lds_bytes_vlv(lct);
-                    if (lct == 3) hipLaunchKernelGGL((k_gemm_vlv_lds<T, 3>), dim3(grid), dim3(LDSG_THREADS), bytes, stream, gV, gL, imV, imL, SB, SV, lds_ring_slot(nv), lds_ring_slot(nu + nx), a, foldRoot);
-                    else hipLaunchKernelGGL((k_gemm_vlv_lds<T, 2>), dim3(grid), dim3(LDSG_THREADS), bytes, stream, gV, gL, imV, imL, SB, SV, lds_ring_slot(nv), lds_ring_slot(nu + nx), a, foldRoot);
-                    return;
-                }
-            }
-            // ... or one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
-            const int ct = whole ? wide_ct(nSlabs, lds) : 0;
+            const int nSlabs = (d.nodes + 15) / 16;
+            // many slabs per CU: one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
+            const int ct = wide_ct(nSlabs, lds);
             if (ct >= 2 && foldRoot != 2) {
                 const int grid = (nSlabs + ct - 1) / ct, threads = 64 * wide_waves();
                 if (ct == 2) hipLaunchKernelGGL((k_gemm_vlv_wide<T, 2>), dim3(grid), dim3(threads), lds * 2, stream, gV, gL, SB, SV, a, foldRoot);
@@ -1273,108 +1110,13 @@ struct Ctx : CtxBase {
             // launch's critical path -- fills its own slab in LDS instead of draining its stores and reading them back
             const int scratch = foldRoot == 2 ? crown_scratch(lds) : 0;
             const size_t ldsAll = lds + (size_t)scratch * sizeof(T);
-            if (a.peer.nranks > 0 && foldRoot == 2) {   // one-shot exchange: the instantiation whose crown workgroups gather the peers' packets
-                // ... into LDS behind the crown scratch when the workgroup may have that much (crown_scratch() has raised the limit)
-                int cutVals = (int)peer_slots();
-                if (scratch == 0 || ldsAll + (size_t)cutVals * sizeof(T) > 160 * 1024) cutVals = 0;
-                const size_t ldsOne = ldsAll + (size_t)cutVals * sizeof(T);
-                if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true, true>), dim3(nSlabs), dim3(64 * nw), ldsOne, stream, gV, gL, SB, SV, a, foldRoot, scratch, cutVals);
-                else hipLaunchKernelGGL((k_gemm_vlv<T, false, true>), dim3(nSlabs), dim3(64 * nw), ldsOne, stream, gV, gL, SB, SV, a, foldRoot, scratch, cutVals);
-                return;
-            }
-            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch, 0);
-            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch, 0);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_vlv<T, true>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
+            else hipLaunchKernelGGL((k_gemm_vlv<T, false>), dim3(nSlabs), dim3(64 * nw), ldsAll, stream, gV, gL, SB, SV, a, foldRoot, scratch);
             return;
         }
 #endif
-        (void)whole; (void)nSub;
         launch_gemm<EPI_V>(d_RTp, nv, nv + nx, a.sk, nv + nx, a.v, nv, a.my, 2 * nv);
         launch_gemm<EPI_LV>(d_LBLp, nu + nx, nv, a.v, nv, a.lvb, nu + nx, nullptr, 0);   // [L v_i ; B L v_i]
-    }
-    // ---- chain-fused form (chain_kernels.hpp) -----------------------------------------------------------
-    // does the tree qualify, and if so: launch shapes, LDS limits, the children-sum / offset buffers and the chain -> parent table (once)
-    bool cf_ready() {
-        if (cfState >= 0) return cfState == 1;
-        cfState = 0;
-#if RN_GEMM_SLAB
-        const int nx = d.nx, nu = d.nu, nv = d.nv, cs = chainStage;
-        if (cs < 1 || cs > CROWN_MAX_DEPTH) return false;                 // a tree that is one chain from the root has no crown to hand offsets down
-        const int nCrown = h_stageCum[cs], Lc = d.N - cs;
-        if (nCrown > 32 || Lc < 1 || Lc > CF_MAX_LC) return false;        // crown: at most two 16-column tiles in ONE workgroup; chain: two tiles
-        if (nv + nx > CF_THREADS || nu + nx > CF_THREADS) return false;   // a thread per component of the running sums
-        const int SB = slab_stride(pad4(nv + nx)), SV = slab_stride(pad4(nv)), SO = slab_stride(nu + nx);
-        const int CT = nCrown <= 16 ? 1 : 2;
-        const size_t ldsChain = (size_t)Lc * (std::max(SB, SO) + SV) * sizeof(T), ldsCrown = (size_t)CT * 16 * (SB + SV + SO) * sizeof(T);
-        if (ldsChain > 160 * 1024 || ldsCrown > 160 * 1024) return false;
-        if (SV + SO < nv + 2 * nx || SB + SV < nu + 2 * nx) return false; // k_crown_small keeps (rho, kappa, q) / (du, bw, x) of a node in those rows
-        // (the attribute belongs to the function, not to this context: always the device's whole LDS)
-        const void *fnCrown = CT == 1 ? (const void *)k_crown_small<T, 1> : (const void *)k_crown_small<T, 2>;
-        if ((ldsChain > 64 * 1024 && hipFuncSetAttribute((const void *)k_chain_sweep<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) ||
-            (ldsCrown > 64 * 1024 && hipFuncSetAttribute(fnCrown, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
-            (void)hipGetLastError();
-            return false;
-        }
-        const int nP = h_stageCum[cs] - h_stageCum[cs - 1], K = h_stageCum[cs + 1] - h_stageCum[cs];
-        // the register-resident forms: every wave holds the A fragments of its row tiles (RAPIDNET_CF_REG=0: the forms that stream them from L2)
-        cfReg = (pad4(nv + nx) / 4 <= CFR_KSV && pad4(nv) / 4 <= CFR_KSL && (nv + 15) / 16 <= CF_THREADS / 64 && (nu + nx + 15) / 16 <= 2 * (CF_THREADS / 64)) ? 1 : 0;
-        if ((long long)d.nodes * std::max(std::max(2 * nv, ny), nv + 2 * nx) >= (1ll << 31)) cfReg = 0;     // k_chain_sweep_reg indexes with 32-bit integers
-        if (const char *e = std::getenv("RAPIDNET_CF_REG")) { if (std::atoi(e) == 0) cfReg = 0; }
-        cfCPW = 1;
-        if (cfReg) {
-            // two chains per workgroup when one round of one-chain workgroups would not hold them (one workgroup per CU: 256 registers per lane)
-            if (K > numCUs && 2 * Lc <= 48 && 2 * (nv + nx) <= CF_THREADS && 2 * (nu + nx) <= CF_THREADS && 2 * ldsChain <= 160 * 1024) cfCPW = 2;
-            if (const char *e = std::getenv("RAPIDNET_CF_CPW")) { const int v = std::atoi(e); if (v == 1) cfCPW = 1; }    // tuning runs
-            const void *fnChain = cfCPW == 2 ? (const void *)k_chain_sweep_reg<T, 2> : (const void *)k_chain_sweep_reg<T, 1>;
-            const void *fnCrownR = CT == 1 ? (const void *)k_crown_small_reg<T, 1> : (const void *)k_crown_small_reg<T, 2>;
-            if ((cfCPW * ldsChain > 64 * 1024 && hipFuncSetAttribute(fnChain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) ||
-                (ldsCrown > 64 * 1024 && hipFuncSetAttribute(fnCrownR, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
-                (void)hipGetLastError();
-                cfReg = 0; cfCPW = 1;
-            }
-        }
-        if (dalloc(&d_cfCut, (size_t)nP * (nv + 2 * nx) + 2) || dalloc(&d_cfOff0, (size_t)nP * ny) || dalloc(&d_cfOff1, (size_t)nP * ny) || dalloc(&d_chainPar, (size_t)K)) return false;
-        std::vector<int> par(K);
-        for (int c = 0; c < K; c++) par[c] = h_parent[h_stageCum[cs] + c] - h_stageCum[cs - 1];
-        if (hipMemcpy(d_chainPar, par.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
-        cfCT = CT; cfSB = SB; cfSV = SV; cfSO = SO; cfParents = nP; cfLdsChain = ldsChain; cfLdsCrown = ldsCrown;
-        cfState = 1;
-#endif
-        return cfState == 1;
-    }
-    // P -> Hx in place (and x, u of the chain nodes when the primal iterates are stored): every consumer of Hx other than k_dual_stage OFFS
-    void cf_finish(bool writePrimal) {
-        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
-        FinishArgs<T> f{d_hx, d_cfOff0, d_cfOff1, d_chainPar, d_sqrtp, d_dy, d_x, d_u, d.nx, d.nu, ny, cs, K, h_stageCum[cs], d.N, writePrimal ? 1 : 0};
-        const long long total = (long long)(d.N - cs) * K * ny;
-        const int blocks = (int)std::min<long long>((total + ELT_THREADS - 1) / ELT_THREADS, (long long)numCUs * 16);
-        hipLaunchKernelGGL(k_hx_finish<T>, dim3(blocks), dim3(ELT_THREADS), 0, stream, f);
-        hxPending = false;
-    }
-    // the helper path of a plain single-GPU sweep in the chain-fused form: chain workgroups, the cut parents' children sums (+ the previous
-    // iteration's bookkeeping workgroup), the crown workgroup; allowPending: the caller's next launch is a dual update that adds the offsets itself
-    int cf_helpers(const SweepArgs<T> &a0, bool allowPending) {
-        const int nx = d.nx, nu = d.nu, nv = d.nv, cs = chainStage;
-        SweepArgs<T> a = a0;
-        a.cutSums = d_cfCut; a.cutStage = cs; a.distTail = nullptr;
-        ChainArgs<T> c{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), cfSB, cfSV, cfSO, d.N - cs, a.hx};
-        if (cfReg && cfCPW == 2) hipLaunchKernelGGL((k_chain_sweep_reg<T, 2>), dim3((a.K + 1) / 2), dim3(CF_THREADS), 2 * cfLdsChain, stream, a, c);
-        else if (cfReg) hipLaunchKernelGGL((k_chain_sweep_reg<T, 1>), dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
-        else hipLaunchKernelGGL(k_chain_sweep<T>, dim3(a.K), dim3(CF_THREADS), cfLdsChain, stream, a, c);
-        FinArgs fin{};
-        const bool ride = pendingFin;      // single-GPU optimistic bookkeeping of the previous iteration's dual update (as in k_up_chain)
-        if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
-        hipLaunchKernelGGL((k_cut_partial_sums<T, false>), dim3(cfParents + (ride ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cfCut, cfParents, fin);
-        CrownArgs<T> cr{};
-        cr.gV = GemmArgs<T>{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), nullptr, nv + nx, a.writePrimal ? a.v : nullptr, nv, a.my, 2 * nv, d_prob, h_stageCum[cs], nullptr, 0};
-        cr.gL = GemmArgs<T>{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), nullptr, nv, nullptr, nu + nx, nullptr, 0, d_prob, h_stageCum[cs], nullptr, 0};
-        cr.SB = cfSB; cr.SV = cfSV; cr.SO = cfSO; cr.nCrown = h_stageCum[cs]; cr.off0 = d_cfOff0; cr.off1 = d_cfOff1;
-        if (cfReg && cfCT == 1) hipLaunchKernelGGL((k_crown_small_reg<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
-        else if (cfReg) hipLaunchKernelGGL((k_crown_small_reg<T, 2>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
-        else if (cfCT == 1) hipLaunchKernelGGL((k_crown_small<T, 1>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
-        else hipLaunchKernelGGL((k_crown_small<T, 2>), dim3(1), dim3(CF_THREADS), cfLdsCrown, stream, a, cr);
-        hxPending = true;
-        if (!allowPending || a.writePrimal) cf_finish(a.writePrimal != 0);
-        return RN_OK;
     }
     // crown handling of the forward sweep: 0 = crown launches of their own; 1 = every chain workgroup walks its crown path and
     // the first descendant chain of a crown node writes it; 2 (sharded) = crown nodes dealt round-robin to the workgroups
@@ -1390,7 +1132,6 @@ struct Ctx : CtxBase {
         int most = 0;
         for (int i = h_stageCum[cutStage - 1]; i < h_stageCum[cutStage]; i++) most = std::max(most, h_childCount[i]);
         if (most * lanesPer > UPCUT_THREADS) return 0;
-        if (const char *e = std::getenv("RAPIDNET_UP_CUT")) { if (std::atoi(e) == 0) return 0; }   // tuning runs: the two-launch form
         return lanesPer;
     }
     // phase: 0 = whole sweep; 1 = up to (and including) the cut parents' partial children sums; 2 = the rest,
@@ -1445,18 +1186,9 @@ struct Ctx : CtxBase {
             }
             prof_end(e0);
         }
-        // one-shot exchange: gathered by the launch that produces the cut parents' sums, every parent's workgroup its own (RAPIDNET_ONESHOT_GATHER=0:
-        // by the crown kernels, the first form)
-        static const int gatherHere = [] { const char *e = std::getenv("RAPIDNET_ONESHOT_GATHER"); return e ? std::atoi(e) : 1; }();
+        // one-shot exchange: gathered by the launch that produces the cut parents' sums, every parent's workgroup its own
         auto helpers = [&](SweepArgs<T> &a) -> int {
         e1 = prof_begin(1);
-        // the chain-fused form: plain sweeps of a single-GPU context whose crown fits one workgroup (chain_kernels.hpp)
-        if (sweepForm == 1 && phase == 0 && !hessianInput && !a.cutSums && !fuseReq && cf_ready()) {
-            const int rc = cf_helpers(a, allowPending);
-            prof_end(e1);
-            RN_HIP(hipGetLastError());
-            return rc;
-        }
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
         // sharded, cut right above the chains, few local chains per cut parent: one launch does the chain walks AND the cut
         // parents' local children sums (k_up_chain_cut)
@@ -1467,7 +1199,7 @@ struct Ctx : CtxBase {
             if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
             const size_t ldsCut = (size_t)(UPCUT_THREADS / lanesPer) * (nv + 2 * nx) * sizeof(T);
             const int grid = nk(k) + (pendingFin ? 1 : 0);
-            if (oneShot && gatherHere) {
+            if (oneShot) {
                 if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain_cut<T, true, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
                 else hipLaunchKernelGGL((k_up_chain_cut<T, false, true>), dim3(grid), dim3(UPCUT_THREADS), ldsCut, stream, a, d_cut, nk(k), lanesPer, fin);
                 a.peer.nranks = 0;      // d_cut holds the all-rank sums: every later launch of this sweep is the collective path's
@@ -1490,7 +1222,7 @@ struct Ctx : CtxBase {
             if (!mergedCut) {   // (k_up_chain_cut has already left the payload in d_cut)
                 FinArgs fin{};
                 if (pendingFin) fin = FinArgs{d_partials, main_partials(), d_state, (void *)(d_cut + cut_tail_offset()), d_hist, d_histParts, histCap, -1.0, -1.0};
-                if (oneShot && gatherHere) {
+                if (oneShot) {
                     hipLaunchKernelGGL((k_cut_partial_sums<T, true>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
                     a.peer.nranks = 0;      // d_cut holds the all-rank sums
                 } else hipLaunchKernelGGL((k_cut_partial_sums<T, false>), dim3(nk(k) + (pendingFin ? 1 : 0)), dim3(CUT_THREADS), 0, stream, a, d_cut, nk(k), fin);
@@ -1499,14 +1231,6 @@ struct Ctx : CtxBase {
             if (phase == 1 || !has_comm()) return RN_OK;     // emulation, or a single-rank "sharded" run
             if (oneShot) return RN_OK;                       // the payload has gone to the peers' inboxes straight from the kernel
             const size_t cnt = (size_t)nk(k) * (nv + 2 * nx);
-            if (overlapNow) {   // on its own stream, behind the launch that made the payload; joined in front of the crown's slabs below
-                RN_HIP(hipEventRecord(evCommFork, stream));
-                RN_HIP(hipStreamWaitEvent(commStream, evCommFork, 0));
-                if (int rc = all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)", 0, commStream)) return rc;
-                RN_HIP(hipEventRecord(evCommJoin, commStream));
-                joinPending = true;
-                return RN_OK;
-            }
             return all_reduce(d_cut, cnt + (carryTail ? 2 : 0), sizeof(T) == 8, "ncclAllReduce(cut payload)");
         };
         // the root's own recursion step is folded into workgroup 0 of the v / Lv launch (one launch less) whenever that
@@ -1515,11 +1239,6 @@ struct Ctx : CtxBase {
         // 2: sharded with a two-stage crown whose stage 1 is the exchange stage -- its (presummed) step is folded as well
         int foldRoot = (RN_FOLD_ROOT && phase == 0 && cs >= (a.cutSums ? 2 : 1) && !(a.cutSums && cutStage == 1) && v_lv_is_slab()) ? 1 : 0;
         if (foldRoot && a.cutSums && cs == 2 && cutStage == 2) foldRoot = 2;
-        // overlapped exchange: the sharded two-stage crown (what the Barcelona shards run), a real or stand-in communicator, not while every
-        // interval is being bracketed by profiling events on the one stream; the chain region's slabs start behind the crown's
-        const int crownEnd = (h_stageCum[cs] + 15) / 16 * 16;
-        overlapNow = overlapExchange && commStream && foldRoot == 2 && has_comm() && !oneShot && phase == 0 && !prof && !hessianInput && crownEnd < d.nodes;
-        joinPending = false;
         {
             const int w = nv + 2 * nx, wp = (w + 63) / 64 * 64;
             const size_t ldsCrown = (size_t)std::max(1, CROWN_THREADS / wp) * w * sizeof(T);
@@ -1530,17 +1249,11 @@ struct Ctx : CtxBase {
                     if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
                     if (foldRoot == 2) continue;                       // done by the v / Lv launch
                 }
-                if (a.peer.nranks > 0 && a.cutSums && k == cutStage - 1) hipLaunchKernelGGL((k_up_crown<T, true>), dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
-                else hipLaunchKernelGGL((k_up_crown<T, false>), dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
+                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)
-        if (joinPending) {
-            launch_v_lv(a, 0, crownEnd, d.nodes);                 // the chain region: beside the collective
-            RN_HIP(hipStreamWaitEvent(stream, evCommJoin, 0));
-            launch_v_lv(a, 2, 0, crownEnd);                       // the crown's steps and slabs: behind it
-            joinPending = false;
-        } else launch_v_lv(a, foldRoot);
+        launch_v_lv(a, foldRoot);
         // (4) root-to-leaf: u, x and Hx in one pass (crown, then the chains)
         // shallow crowns: every chain workgroup walks its own crown path (k_down_chain, foldCrown) -- no crown launch.
         // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
@@ -1605,8 +1318,7 @@ struct Ctx : CtxBase {
         if (vpn < 2) return;   // one vector per node: floor(2^32 / 1) + 1 does not fit the 32-bit magic -- the flat kernel runs
         const unsigned long long lim = (1ull << 32) / (unsigned)vpn;          // range in which umulhi(j, magic) == j / vpn
         if ((unsigned long long)K * vpn >= lim || (unsigned long long)node0 * vpn >= lim || (unsigned long long)d.nodes * vpn >= (1ull << 31)) return;
-        int forced = 0;
-        if (const char *e = std::getenv("RAPIDNET_DUAL_TRIPS")) forced = std::atoi(e);   // tuning runs
+        const int forced = knob[RN_KNOB_DUAL_TRIPS] > 0 ? knob[RN_KNOB_DUAL_TRIPS] : 0;
         // workgroups: at most one resident round (numCUs x 8 workgroups of 4 waves) so that every workgroup's loads start at
         // once; measured on the 493-scenario tree: 1 trip (5 113 workgroups) 21.9 us, 2-3 trips 20.8, 4-6 trips 21.6-24 us
         // vectors that do not fit the 256 MiB Infinity Cache stream from HBM: there 4x as many (smaller) workgroups and the
@@ -1622,7 +1334,7 @@ struct Ctx : CtxBase {
                 if (blocks > (pass == 0 && forced <= 0 ? resident : (long long)RN_DUAL_STAGE_MAX_BLOCKS)) continue;
                 dshape = DualStageShape{cs, K, node0, (int)bps, (int)cb, vpn, (unsigned int)((1ull << 32) / (unsigned)vpn) + 1u, trips, 0.0};
                 dualU = (!cacheResident && trips >= 2) ? 2 : 1;
-                if (const char *e = std::getenv("RAPIDNET_DUAL_PIPE")) dualU = std::atoi(e) >= 2 ? 2 : 1;   // tuning runs
+                if (knob[RN_KNOB_DUAL_PIPE] > 0) dualU = knob[RN_KNOB_DUAL_PIPE] >= 2 ? 2 : 1;
                 dualBlocks = (int)blocks;
                 break;
             }
@@ -1634,7 +1346,6 @@ struct Ctx : CtxBase {
     void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false, int lazy = 0) {
         if (flat || dualU == 0) {
             if (hxUnscaled) hx_scale_now();
-            if (hxPending) cf_finish(false);
             if (materialize) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_dual_fused<T, false, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
             mainPartials = eltBlocks;
@@ -1644,21 +1355,12 @@ struct Ctx : CtxBase {
         DualStageShape g = dshape;
         g.lnNext = h_lam[h_it + 1];   // ensure_tables(h_it + n) has run: the table covers every iteration of the batch
         if (hxUnscaled && lazy == 0 && !materialize) {   // unscaled walk: Hx = sqrt(p_i) d_k * (primal value) is formed here
-            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, false, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
-            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, false, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
             hxUnscaled = false;
             return;
         }
         if (hxUnscaled) hx_scale_now();
-        if (hxPending && lazy == 0 && !materialize) {    // chain-fused sweep: Hx is formed here from the partial primal and the crown's offsets
-            DualArgs<T> b = a;
-            b.off0 = d_cfOff0; b.off1 = d_cfOff1; b.chainPar = d_chainPar;
-            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, b, g);
-            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, b, g);
-            hxPending = false;
-            return;
-        }
-        if (hxPending) cf_finish(false);
 #define RN_LAUNCH_DSTAGE(MAT, PIPE, LAZY) hipLaunchKernelGGL((k_dual_stage<T, MAT, PIPE, LAZY>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g)
 #define RN_LAUNCH_DSTAGE_P(PIPE)                                                                                          \
         switch (lazy) {                                                                                                \
@@ -1671,13 +1373,12 @@ struct Ctx : CtxBase {
 #undef RN_LAUNCH_DSTAGE_P
 #undef RN_LAUNCH_DSTAGE
     }
-    // exchange mode 2 (opt-in; RAPIDNET_LAZY_W=1 turns mode 1 into it for A/B runs): inner iterations of a device-resident batch
+    // exchange mode 2 (opt-in): inner iterations of a device-resident batch
     // do not store the accelerated dual (k_dual_stage LAZY); possible whenever the stage-tiled kernel is the batch's dual update.
     // Bitwise the iterates of mode 1.  Measured: the dual update gets 2 us (wide fp32 network: 38 us)
     // shorter, the streaming kernel -- which then reads two dual vectors in its prologue -- as much longer: not the default.
     bool lazy_w() const {
-        static const bool env = [] { const char *e = std::getenv("RAPIDNET_LAZY_W"); return e && std::atoi(e) != 0; }();
-        return dualU != 0 && (optimistic == 2 || (optimistic == 1 && env));
+        return dualU != 0 && optimistic == 2;
     }
     int main_partials() const { return mainPartials; }
     DualArgs<T> dual_args() const {
@@ -1736,7 +1437,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
-        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxPending = false; hxUnscaled = false;
+        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxUnscaled = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
@@ -1762,7 +1463,7 @@ struct Ctx : CtxBase {
         if (int rc = ensure_tables(h_it + n)) return rc;
         // checkpoint
         const size_t tail = cut_tail_offset();
-        batch_open(d_cut + tail);  // checkpoint of (y, y+, w), the payload's dist^2 tail and the verdict flag cleared: one launch
+        if (int rc = batch_open(d_cut + tail)) return fail_batch(rc);  // checkpoint of (y, y+, w), the payload's dist^2 tail and the verdict flag cleared: one launch
         T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
         const bool s_ready = acc_ready;
         carryTail = true; inBatch = true;
@@ -1832,20 +1533,12 @@ struct Ctx : CtxBase {
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
-    void batch_open(T *tail) {
-        static const int one = [] { const char *e = std::getenv("RAPIDNET_BATCH_OPEN"); return e ? std::atoi(e) : 1; }();   // 0: the copies and fills as launches of their own (A/B)
-        if (!one) {
-            const size_t bytes = (size_t)ntot() * sizeof(T);
-            (void)hipMemcpyAsync(d_ck[0], p_xi, bytes, hipMemcpyDeviceToDevice, stream);
-            (void)hipMemcpyAsync(d_ck[1], p_upd, bytes, hipMemcpyDeviceToDevice, stream);
-            (void)hipMemcpyAsync(d_ck[2], p_acc, bytes, hipMemcpyDeviceToDevice, stream);
-            if (tail) (void)hipMemsetAsync(tail, 0, 2 * sizeof(T), stream);
-            (void)hipMemsetAsync(&d_state->violated, 0, sizeof(int), stream);
-            return;
-        }
+    int batch_open(T *tail) {
         const long long n = ntot();
         const int blocks = (int)std::max<long long>(1, std::min<long long>((n / (16 / (long long)sizeof(T)) + ELT_THREADS - 1) / ELT_THREADS, (long long)numCUs * 8));
         hipLaunchKernelGGL(k_batch_open<T>, dim3(blocks), dim3(ELT_THREADS), 0, stream, (const T *)p_xi, (const T *)p_upd, (const T *)p_acc, d_ck[0], d_ck[1], d_ck[2], n, d_state, tail);
+        RN_HIP(hipGetLastError());   // a checkpoint that was not taken must not be replayed from
+        return RN_OK;
     }
     // Single GPU, optimistic bookkeeping: the same idea without a collective.  The fused dual update runs the prox as a
     // pure projection; instead of a decision launch after every iteration (the 64-workgroup fix-up launch, ~5 us that
@@ -1857,7 +1550,7 @@ struct Ctx : CtxBase {
         const size_t bytes = (size_t)ntot() * sizeof(T);
         for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         if (int rc = ensure_tables(h_it + n)) return rc;
-        batch_open(nullptr);       // checkpoint of (y, y+, w) + the verdict flag cleared: one launch
+        if (int rc = batch_open(nullptr)) return fail_batch(rc);       // checkpoint of (y, y+, w) + the verdict flag cleared: one launch
         T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
         const bool s_ready = acc_ready;
         const bool lazy = lazy_w();
@@ -1928,14 +1621,6 @@ struct Ctx : CtxBase {
     std::vector<void *> ipcOpened;
     bool peerReady = false, inBatch = false;
     int transport = 0;            // 0: the cut payload is all-reduced by the collective; 1: one-shot peer writes (inside rn_apg_iterate batches)
-    // Overlapped exchange (rn_set_exchange_overlap; OPT-IN and, as measured on one GPU, a loss: the two cross-stream dependencies and the
-    // extra launch cost 27-29 us per iteration -- 0.1339 -> 0.1608 ms on a 1/8 shard with a one-rank communicator,
-    // profiles/r05_exchange_overlap_one_gpu.txt -- where the products it can hide behind the collective take 12 us): the v / Lv products of the chain region
-    // do not depend on the exchange -- only the crown's steps and, through them, the forward walk do (SmpcController.cu:604-611 are
-    // per-node products; the children sums of :644-672 enter at the cut parents) -- so the per-iteration collective runs on a stream of
-    // its own while the solver's stream multiplies the chain region's slabs, and only the crown's two slabs wait for it.
-    int overlapExchange = 0;
-    bool overlapNow = false, joinPending = false;      // state of the sweep being enqueued
     // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual; opt-in: RAPIDNET_FUSE_DOWN_DUAL=1):
     // the optimistic batches ask for it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened
     bool fuseReq = false, fuseDone = false, fuseMat = false;
@@ -1945,21 +1630,7 @@ struct Ctx : CtxBase {
     int set_fused_walk_dual(int on) override { RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_fused_walk_dual: 0 or 1"); fuseEnv = on; return RN_OK; }
     bool fuse_want() {
         if (fuseEnv < 0) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseEnv = e ? (std::atoi(e) != 0) : 0; }
-        // (a context whose sweeps are chain-fused has no forward walk to fuse the dual update with: that form takes precedence)
-        return fuseEnv != 0 && dualU != 0 && !prof && !(sweepForm == 1 && cutStage <= 0 && cf_ready());
-    }
-    hipStream_t commStream = nullptr;
-    hipEvent_t evCommFork = nullptr, evCommJoin = nullptr;
-    int set_exchange_overlap(int on) override {
-        RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_exchange_overlap: 0 or 1");
-        if (on && !commStream) {
-            RN_HIP(hipSetDevice(device));
-            RN_HIP(hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking));
-            RN_HIP(hipEventCreateWithFlags(&evCommFork, hipEventDisableTiming));
-            RN_HIP(hipEventCreateWithFlags(&evCommJoin, hipEventDisableTiming));
-        }
-        overlapExchange = on;
-        return RN_OK;
+        return fuseEnv != 0 && dualU != 0 && !prof;
     }
     unsigned int peerSeq = 0;     // sequence number of the last one-shot exchange (the same on every rank: they issue the same exchanges)
     unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }
@@ -2023,15 +1694,6 @@ struct Ctx : CtxBase {
     int debug_peer_seq(unsigned int seq) override {      // test hook: the next exchange gets sequence number seq + 1 (all ranks alike)
         RN_CHECK(peerReady, RN_E_STATE, "rn_debug_peer_seq: connect the inboxes first");
         peerSeq = seq;
-        return RN_OK;
-    }
-    int set_sweep_form(int form, int *active) override {
-        RN_CHECK(form == 0 || form == 1, RN_E_ARG, "rn_set_sweep_form: 0 (six-launch form) or 1 (chain-fused where it applies)");
-        RN_HIP(hipSetDevice(device));
-        RN_HIP(hipStreamSynchronize(stream));
-        if (hxPending) cf_finish(false);
-        sweepForm = form;
-        if (active) *active = (sweepForm == 1 && cutStage <= 0 && cf_ready()) ? 1 : 0;
         return RN_OK;
     }
     int set_exchange_transport(int t) override {
@@ -2144,7 +1806,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
-        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxPending = false; hxUnscaled = false;
+        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxUnscaled = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }
@@ -2611,8 +2273,7 @@ struct Ctx : CtxBase {
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         double best = 0;
         const long long c16 = (long long)(pieceBytes / 16), s16 = (long long)(strideBytes / 16);
-        const char *pe = std::getenv("RAPIDNET_PROBE_LDS");   // occupancy experiments: dynamic LDS bytes per probe workgroup
-        const size_t plds = pe ? (size_t)std::strtoull(pe, nullptr, 10) : 0;
+        const size_t plds = 0;
         for (int r = 0; r < reps + 1; r++) {
             float ms = 0;
             (void)hipEventRecord(e0, stream);
@@ -2818,6 +2479,7 @@ int rn_debug_local_group_join(rn_ctx *ctx, void *group, int rank) { RN_GUARD(ctx
 int rn_debug_local_group_destroy(void *group) { if (!group) return RN_E_ARG; delete static_cast<rn::LocalGroup *>(group); return RN_OK; }
 int rn_debug_inject_allocation(rn_ctx *ctx, size_t bytes) { RN_GUARD(ctx); return ctx->impl->inject_allocation(bytes); }
 int rn_debug_guard_poke(rn_ctx *ctx, int nbytes) { RN_GUARD(ctx); return ctx->impl->guard_poke(nbytes); }
+int rn_debug_set_knob(rn_ctx *ctx, int knob, int value) { RN_GUARD(ctx); return ctx->impl->set_knob(knob, value); }
 int rn_debug_peer_seq(rn_ctx *ctx, unsigned int seq) { RN_GUARD(ctx); return ctx->impl->debug_peer_seq(seq); }
 int rn_guard_report(long out[2]) { if (!out) return RN_E_ARG; out[0] = rn::g_guardContexts.load(); out[1] = rn::g_guardBadBytes.load(); return RN_OK; }
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64) { RN_GUARD(ctx); return ctx->impl->peer_inbox_create(ipcHandle64); }
@@ -2830,9 +2492,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
     return RN_OK;
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
-int rn_set_exchange_overlap(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_exchange_overlap(on); }
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_fused_walk_dual(on); }
-int rn_set_sweep_form(rn_ctx *ctx, int form, int *active) { RN_GUARD(ctx); return ctx->impl->set_sweep_form(form, active); }
 int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }
 int rn_device_memory_info(rn_ctx *ctx, size_t info[4]) { RN_GUARD(ctx); return ctx->impl->memory_info(info); }

@@ -115,11 +115,10 @@ def test_barcelona493_sharded_over_8_ranks(barcelona493):
     full.close()
 
 
-@pytest.mark.parametrize("optimistic,overlap", [(True, False), (False, False), (True, True)])
-def test_barcelona493_one_rank_rccl_exchange(barcelona493, optimistic, overlap):
+@pytest.mark.parametrize("optimistic", [True, False])
+def test_barcelona493_one_rank_rccl_exchange(barcelona493, optimistic):
     """The library's own ncclAllReduce on the solver's stream (k_cut_partial_sums -> all-reduce -> presummed crown step in
-    k_gemm_vlv) on the full 493-scenario tree, one-rank communicator, both exchange modes; overlap: the per-iteration ncclAllReduce on a
-    stream of its own beside the chain region's products (rn_set_exchange_overlap: round 5) -- the REAL collective on the second stream."""
+    k_gemm_vlv) on the full 493-scenario tree, one-rank communicator, both exchange modes."""
     p, (dh, ah) = barcelona493
     cut = partition.default_cut_stage(p["tree"])
     full = capi.Solver(p["network"], p["tree"], p["config"])
@@ -129,7 +128,6 @@ def test_barcelona493_one_rank_rccl_exchange(barcelona493, optimistic, overlap):
     s.commInit(0, 1, capi.comm_unique_id())
     s.setCutStage(cut, partition.cut_children_moments(p["tree"], cut))
     s.setExchangeMode(optimistic)
-    s.setExchangeOverlap(overlap)
     s.initialiseSmpcController(dh, ah)
     s.apgReset()
     h = np.concatenate([s.apgIterate(17), s.apgIterate(7)])               # two batches: checkpoint, payload tail, theta carry over

@@ -236,15 +236,14 @@ def test_algorithm_selected_before_the_factor_step(alg):
 
 
 @pytest.mark.parametrize("name,precision", [("medium", "f64"), ("odd", "f64"), ("small", "f32")])
-def test_nama_pair_of_hessian_sweeps_is_bitwise_the_two_sweeps(name, precision, monkeypatch):
+def test_nama_pair_of_hessian_sweeps_is_bitwise_the_two_sweeps(name, precision):
     """NAMA's two Hessian oracles of an iteration (SmpcController.cu:1331, :1341-1345) in ONE pass over the operator blocks
     (k_stream_gemv with two right-hand sides): every buffer and every accepted step as with the two sweeps one after the other."""
     p = synth.make_problem(name)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     runs = []
-    for pair in ("1", "0"):
-        monkeypatch.setenv("RAPIDNET_NAMA_PAIR", pair)
-        s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision)
+    for pair in (1, 0):
+        s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision, knobs={"nama_pair": pair})
         s.initialiseSmpcController(dh, ah)
         s.setAlgorithm("namaAlgorithm", 5)
         h, v, t = s.algorithmNama(10)
@@ -327,17 +326,15 @@ def test_steps_match_oracle(alg):
 
 @pytest.mark.parametrize("alg", ALGS)
 @pytest.mark.parametrize("mfma", ["1", "0"])
-def test_batched_line_search_is_bitwise_the_sequential_one(alg, mfma, monkeypatch):
+def test_batched_line_search_is_bitwise_the_sequential_one(alg, mfma):
     """the candidates of a line search evaluated in batches (two passes + one read-back) against the trials one by one: the same
     accepted steps, values and buffers to the last bit -- with the value's primal terms on the matrix cores (k_value_mfma) and on
     the vector ALUs (k_value_terms / k_ls_value)"""
     p = synth.make_problem("medium")
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    monkeypatch.setenv("RAPIDNET_VALUE_MFMA", mfma)
     runs = []
-    for seq in ("0", "1"):
-        monkeypatch.setenv("RAPIDNET_LS_SEQUENTIAL", seq)
-        s = capi.Solver(p["network"], p["tree"], p["config"])
+    for seq in (0, 1):
+        s = capi.Solver(p["network"], p["tree"], p["config"], knobs={"value_mfma": int(mfma), "ls_sequential": seq})
         s.initialiseSmpcController(dh, ah)
         s.setAlgorithm(alg, 5)
         h, v, t = (s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama)(10)

@@ -14,8 +14,8 @@ BUFS = (capi.BUF_X, capi.BUF_U, capi.BUF_V, capi.BUF_XI, capi.BUF_PSI, capi.BUF_
         capi.BUF_PRIMAL_XI, capi.BUF_PRIMAL_PSI, capi.BUF_DUAL_XI, capi.BUF_DUAL_PSI, capi.BUF_RES_XI, capi.BUF_RES_PSI)
 
 
-def run(p, structured, precision, batches=(20, 17, 3)):
-    s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision)
+def run(p, structured, precision, batches=(20, 17, 3), knobs=None):
+    s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision, knobs=knobs)
     s.initialiseSmpcController(*synth.forecast_at(p["forecast"], 0))
     s.apgReset()
     hist = np.concatenate([s.apgIterate(n) for n in batches])      # batches of >= 16 take the optimistic (fusable) path, the last one the exact path

@@ -25,12 +25,12 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def make_pair(name, precision="f64", structured=False, alias_operators=True, **kw):
+def make_pair(name, precision="f64", structured=False, alias_operators=True, knobs=None, **kw):
     p = synth.make_problem(name, **kw)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     o = Oracle(p["network"], p["tree"], p["config"], precision=precision, alias_operators=alias_operators)
     o.initialise(dh, ah)
-    s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision, structured=structured)
+    s = capi.Solver(p["network"], p["tree"], p["config"], precision=precision, structured=structured, knobs=knobs)
     s.initialiseSmpcController(dh, ah)
     return p, o, s
 
@@ -185,14 +185,14 @@ def test_soft_constraint_branch():
 
 
 @pytest.mark.parametrize("trips,pipe", [(1, 1), (2, 1), (3, 2), (5, 2), (8, 1)])
-def test_dual_stage_launch_shapes(trips, pipe, monkeypatch):
+def test_dual_stage_launch_shapes(trips, pipe):
     """k_dual_stage with every tile / pipelining shape (the defaults pick one by problem size): vectors per thread 1 .. 8,
     single- and double-buffered, on a tree with a two-stage crown (crown workgroups + regular stages) and partially filled
     last tiles; same iterates and history as the oracle."""
-    monkeypatch.setenv("RAPIDNET_DUAL_TRIPS", str(trips))
-    monkeypatch.setenv("RAPIDNET_DUAL_PIPE", str(pipe))
     for name, iters in (("medium", 24), ("small", 20)):
-        p, o, s = make_pair(name)
+        p, o, s = make_pair(name, knobs={"dual_trips": trips, "dual_pipe": pipe})
+        k = s.kernelInfo()
+        assert k["dual_stage"] == 1 and k["dual_trips"] == trips and k["dual_pipe"] == pipe, k
         hist, ohist = s.algorithmApg(iters), o.apg(iters)
         compare_all(s, o, REL_TOL, "%s trips=%d pipe=%d" % (name, trips, pipe))
         assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()

@@ -31,14 +31,13 @@ class Ranks:
     """`world` shard contexts of one problem on one GPU, joined to an in-process group; run(fn) calls fn(solver) on every
     rank from a thread of its own (the collectives inside rn_apg_iterate rendezvous across the threads)."""
 
-    def __init__(self, p, world, cut=0, structured=False, precision="f64", optimistic=True, overlap=False):
+    def __init__(self, p, world, cut=0, structured=False, precision="f64", optimistic=True, knobs=None):
         self.group = capi.local_group_create(world)
         self.shards = []
         for r in range(world):
-            s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=world, cut_stage=cut, structured=structured, precision=precision)
+            s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=world, cut_stage=cut, structured=structured, precision=precision, knobs=knobs)
             s.joinLocalGroup(self.group, r)
             s.setExchangeMode(optimistic)
-            s.setExchangeOverlap(overlap)
             self.shards.append(s)
         self.nodes = self.shards[0].full_nodes
 
@@ -203,32 +202,3 @@ def test_wide_network_fp32_sharded(world, cut):
     finally:
         rk.close()
         full.close()
-
-
-@pytest.mark.parametrize("name,world,structured,precision,kw", [("medium", 2, False, "f64", {}), ("medium", 4, True, "f64", {}), ("ragged", 3, False, "f64", {}),
-                                                                ("medium", 3, False, "f32", {}), ("medium", 4, False, "f64", {"penalty_x": 20.0, "penalty_xs": 5.0})])
-def test_overlapped_exchange_is_bitwise_the_serial_one(name, world, structured, precision, kw):
-    """rn_set_exchange_overlap(1): the per-iteration all-reduce on a stream of its own, the chain region's v / Lv products beside it, the
-    crown's slabs behind it (cut at the default stage: the sharded two-stage crown the Barcelona shards run).  Every node sees the same
-    kernels on the same data, so iterates, histories and batch counters are the serial exchange's, bit for bit -- incl. a batch that
-    trips the soft-constraint thresholds and is replayed."""
-    p = synth.make_problem(name, **kw)
-    dh, ah = synth.forecast_at(p["forecast"], 0)
-    out = []
-    for overlap in (False, True):
-        rk = Ranks(p, world, 0, structured, precision=precision, overlap=overlap)
-        try:
-            def solve(s):
-                s.initialiseSmpcController(dh, ah)
-                s.apgReset()
-                return s.counters(), np.concatenate([s.apgIterate(20), s.apgIterate(5)])
-
-            res = rk.run(solve)
-            d = dims_of(rk.shards[0])
-            out.append((res[0][0], res[0][1], [rk.gathered(bid, d[dm]) for bid, _, dm in VECS]))
-        finally:
-            rk.close()
-    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
-    for a, b in zip(out[0][2], out[1][2]):
-        assert np.array_equal(a, b)

@@ -1,4 +1,4 @@
-"""k_down_chain<T, UNSC> + k_dual_stage<..., SCALE> (round 5, RAPIDNET_UNSCALED_WALK, default 1): in the inner iterations of an optimistic batch the forward walk
+"""k_down_chain<T, UNSC> + k_dual_stage<..., SCALE> (round 5; RN_KNOB_UNSCALED_WALK, default on): in the inner iterations of an optimistic batch the forward walk
 leaves the PRIMAL values in the Hx buffer and the dual update applies sqrt(p_i) d_k -- the factor it holds for the bounds anyway -- so the walk
 requests no preconditioner entries.  The product is the same two roundings in either kernel: iterates, histories and batch counters must be the
 scaled walk's bit for bit -- single GPU and sharded, dense and structured, fp64 and fp32, incl. a batch whose soft-constraint thresholds trip and
@@ -18,10 +18,9 @@ pytestmark = pytest.mark.gpu
                                                           ("barcelona31_infeasible", False, "f64", {"penalty_x": 20.0, "penalty_xs": 5.0})])
 def test_unscaled_walk_is_bitwise_the_scaled_one(monkeypatch, name, structured, precision, kw):
     p = synth.make_problem(name, **kw)
-    monkeypatch.setenv("RAPIDNET_UNSCALED_WALK", "0")
-    h0, o0, c0 = run(p, structured, precision)
-    monkeypatch.setenv("RAPIDNET_UNSCALED_WALK", "1")
-    h1, o1, c1 = run(p, structured, precision)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "0")      # (the fused walk + dual update has no Hx hand-off to scale)
+    h0, o0, c0 = run(p, structured, precision, knobs={"unscaled_walk": 0})
+    h1, o1, c1 = run(p, structured, precision, knobs={"unscaled_walk": 1})
     assert c0 == c1, (c0, c1)
     assert np.array_equal(h0, h1)
     for b in BUFS:
@@ -34,9 +33,9 @@ def test_unscaled_walk_sharded(monkeypatch, name, world, structured, kw):
     p = synth.make_problem(name, **kw)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     out = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("RAPIDNET_UNSCALED_WALK", on)
-        rk = Ranks(p, world, 0, structured)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "0")
+    for on in (0, 1):
+        rk = Ranks(p, world, 0, structured, knobs={"unscaled_walk": on})
         try:
             def solve(s):
                 s.initialiseSmpcController(dh, ah)
