@@ -117,12 +117,18 @@ const char *rn_last_error(const rn_ctx *ctx);
 int rn_synchronize(rn_ctx *ctx);
 
 /* Operator storage, to be chosen BEFORE rn_factor_step.
- *   RN_OPS_DENSE (default): the reference's storage model -- dense per-node blocks Phi_i, Psi_i, D_i, Ftil_i
+ *   RN_OPS_DENSE: the reference's storage model -- dense per-node blocks Phi_i, Psi_i, D_i, Ftil_i
  *     (Engine.cu:166-189), streamed from HBM once per iteration (4.09 GB for the 493-scenario Barcelona tree).
  *   RN_OPS_STRUCTURED: the blocks are never materialised; the factor step's own formulas (block = shared matrix x
- *     stage diagonal x power of p_i, Engine.cu:721-745) are applied as shared-operator GEMMs.  Same iterates. */
-enum { RN_OPS_DENSE = 0, RN_OPS_STRUCTURED = 1 };
+ *     stage diagonal x power of p_i, Engine.cu:721-745) are applied as shared-operator GEMMs.  Same iterates (the parity
+ *     suite runs both), 6-7 x the iteration rate on the 493-scenario tree.
+ *   RN_OPS_AUTO (the default of a new context): structured for as long as every block is the factor step's own -- which is
+ *     always, unless the caller hands in a block through rn_set_operator; the first such call materialises the dense blocks
+ *     (one more factor step on the inputs of the last one) and the context runs dense from then on.
+ * rn_get_operator_mode: *requested = what was asked for, *active = RN_OPS_DENSE or RN_OPS_STRUCTURED, what the context runs. */
+enum { RN_OPS_DENSE = 0, RN_OPS_STRUCTURED = 1, RN_OPS_AUTO = 2 };
 int rn_set_operator_mode(rn_ctx *ctx, int mode);
+int rn_get_operator_mode(rn_ctx *ctx, int *requested, int *active);
 
 /* ---- Engine -------------------------------------------------------------------------------------- */
 /* Engine::factorStep (Engine.cu:671-774) incl. initialiseSystemDevice / preconditioning kernels. */
@@ -226,6 +232,13 @@ int rn_get_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, double *hos
 int rn_set_range(rn_ctx *ctx, int buffer_id, size_t first, size_t n, const double *host);
 /* one node's operator block, reference layout (col-major, ld = nv) */
 int rn_get_operator(rn_ctx *ctx, int op_id, int node, double *host, size_t n);
+/* ... and its counterpart: a block handed in by the caller (the reference's Engine returns the device pointers of these arrays,
+ * Engine.cuh:170-230 getMatPhi() ... getPtrMatF(), so its callers may overwrite any block).  RN_OP_PHI, _PSI, _D, _F of one node -- the
+ * blocks solveStep multiplies with (SmpcController.cu:617-638); the next sweep uses them.  After rn_factor_step; a later rn_factor_step
+ * recomputes every block.  RN_OPS_AUTO contexts switch to dense storage on the first call; RN_OPS_STRUCTURED contexts (no per-node
+ * blocks by request): RN_E_STATE.  Omega_i, Theta_i, G_i are shared matrices scaled by p_i here (K identical copies in the reference,
+ * Engine.cu:306-308): RN_E_ARG. */
+int rn_set_operator(rn_ctx *ctx, int op_id, int node, const double *host, size_t n);
 /* The raw device pointer of a buffer that the library keeps in the reference's own layout -- the counterpart of the reference's raw
  * getters and protected device vectors for those arrays (Engine.cuh:108-318 getVecUhat / getVecBeta / getVecE / getPriceAlpha ...,
  * SmpcController.cuh:336-462 devVecX / devVecU / devVecV): RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA, _XDIR, _UDIR, node-major

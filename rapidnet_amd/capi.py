@@ -19,6 +19,8 @@ RN_F32, RN_F64 = 0, 1
 ALG_APG, ALG_GLOBAL_FBE, ALG_NAMA = 0, 1, 2
 ALGORITHMS = {"proximalAlgorithm": ALG_APG, "globalFbeAlgorithm": ALG_GLOBAL_FBE, "namaAlgorithm": ALG_NAMA}  # Engine.cu:151-163
 OP_PHI, OP_PSI, OP_D, OP_F, OP_OMEGA, OP_THETA, OP_G = range(7)
+OPS_DENSE, OPS_STRUCTURED, OPS_AUTO = 0, 1, 2
+OPS_MODES = {"dense": OPS_DENSE, "structured": OPS_STRUCTURED, "auto": OPS_AUTO}
 # include/rapidnet_debug.h, RN_KNOB_*
 KNOBS = {k: i for i, k in enumerate(("dual_trips", "dual_pipe", "vlv_wide", "slab_pipe", "slab_frag", "unscaled_walk", "stream_two_per_cu",
                                      "stream_split", "nama_pair", "ls_sequential", "value_mfma"))}
@@ -32,7 +34,7 @@ SYMBOLS = [
     "rn_update_primal_infeasibility", "rn_get_prox_distances", "rn_buffer_size", "rn_get", "rn_set", "rn_get_operator",
     "rn_device_pointer", "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_comm_init_timeout", "rn_comm_check", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
-    "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_set_warm_start", "rn_set_exchange_mode",
+    "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_get_operator_mode", "rn_set_operator", "rn_set_warm_start", "rn_set_exchange_mode",
     "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
@@ -170,6 +172,8 @@ def load():
     lib.rn_get_kernel_info.argtypes = [vp, dp]
     lib.rn_set_cut_children_moments.argtypes = [vp, dp, dp, C.c_size_t]
     lib.rn_set_operator_mode.argtypes = [vp, ip]
+    lib.rn_get_operator_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rn_set_operator.argtypes = [vp, ip, ip, dp, C.c_size_t]
     lib.rn_set_warm_start.argtypes = [vp, ip]
     lib.rn_set_exchange_mode.argtypes = [vp, ip]
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
@@ -241,10 +245,12 @@ class Solver:
     """
 
     def __init__(self, network, tree, config, precision="f64", device=0, structured=False, rank=0, nranks=1, cut_stage=0,
-                 unique_id=None, knobs=None):
+                 unique_id=None, knobs=None, operator_mode=None):
         """nranks > 1: `tree` is the FULL scenario tree and the context is rank `rank`'s shard of it (rn_create_sharded:
         partition, communicator from `unique_id` -- None = none, the exchange is a test's job --, cut stage, children
-        moments); self.nodes is then the LOCAL node count and self.global_nodes maps local -> full-tree node ids."""
+        moments); self.nodes is then the LOCAL node count and self.global_nodes maps local -> full-tree node ids.
+        operator_mode: "dense" | "structured" | "auto" (rn_set_operator_mode); None: `structured` decides between the first two --
+        the tests and bench.py always say which storage they measure; the C-ABI's own default is auto."""
         self.lib = load()
         self.structured = bool(structured)
         self.network, self.tree, self.config = network, tree, config
@@ -276,8 +282,9 @@ class Solver:
             self._check(self.lib.rn_set_tree_errors(self.h, ed.ctypes.data, ep.ctypes.data))
         self._check(self.lib.rn_set_parameters(self.h, float(_s(config, "stepSize")), float(_s(config, "penaltyStateX")),
                                                float(_s(config, "penaltySafetyX"))))
-        if self.structured:
-            self._check(self.lib.rn_set_operator_mode(self.h, 1))
+        mode = OPS_MODES[operator_mode] if operator_mode is not None else (OPS_STRUCTURED if self.structured else OPS_DENSE)
+        self._check(self.lib.rn_set_operator_mode(self.h, mode))
+        self.structured = mode != OPS_DENSE
         for k, v in (knobs or {}).items():
             self.debugSetKnob(k, v)
 
@@ -491,6 +498,18 @@ class Solver:
         out = np.zeros(n)
         self._check(self.lib.rn_get_operator(self.h, op, int(node), out.ctypes.data, n))
         return out
+
+    def setOperator(self, op, node, values):
+        """hand in one node's block (OP_PHI, OP_PSI, OP_D, OP_F; col-major nv x (2nx | nu)); an auto context becomes dense"""
+        v = _f64(values)
+        self._check(self.lib.rn_set_operator(self.h, int(op), int(node), v.ctypes.data, v.size))
+
+    def operatorMode(self):
+        """(requested, active) as "dense" | "structured" | "auto" """
+        r, a = C.c_int(0), C.c_int(0)
+        self._check(self.lib.rn_get_operator_mode(self.h, C.byref(r), C.byref(a)))
+        names = {v: k for k, v in OPS_MODES.items()}
+        return names[r.value], names[a.value]
 
     def synchronize(self):
         self._check(self.lib.rn_synchronize(self.h))

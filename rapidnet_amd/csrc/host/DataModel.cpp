@@ -140,6 +140,14 @@ SmpcConfiguration::SmpcConfiguration(string pathToFile) {
     pathToForecaster = doc["pathToForecaster"].str;
     _ASSERT(doc["algorithmName"].IsString());
     algorithmName = doc["algorithmName"].str;
+    // optional key of this implementation (absent in the reference's files = "auto"): how the engine stores the factor step's operators
+    operatorMode = "auto";
+    if (doc.HasMember("operatorMode")) {
+        _ASSERT(doc["operatorMode"].IsString());
+        operatorMode = doc["operatorMode"].str;
+        if (operatorMode != "auto" && operatorMode != "dense" && operatorMode != "structured")
+            throw std::logic_error("controller configuration: operatorMode must be \"auto\", \"dense\" or \"structured\" (got \"" + operatorMode + "\")");
+    }
     lbfgsBufferSize = scalarInt(doc, "lbfgsBufferSize");
     pathToConfiguration = pathToFile;
     // relative paths in the configuration are relative to the configuration file's directory when they do not

@@ -118,6 +118,8 @@ public:
     string getPathToForecaster() { return pathToForecaster; }
     real_t getWeightEconomical() { return weightPrice; }
     string getOptimisationAlgorithm() { return algorithmName; }
+    // "operatorMode" (optional key, not in the reference's files): "auto" (default), "dense" or "structured" -- Engine.hpp, setOperatorMode
+    string getOperatorMode() { return operatorMode; }
     void setCurrentState();     // re-read from the configuration file (SmpcConfiguration.cu:240-256)
     void setPreviousControl();  // :261-277
     void setPreviousDemand();   // :283-299
@@ -130,7 +132,7 @@ private:
     uint_t NX, NU, ND, NV, lbfgsBufferSize, maxIteration;
     std::vector<real_t> matL, matLhat, matCostW, matDiagPrecnd, currentX, prevU, prevDemand;
     real_t penaltyStateX, penaltySafetyX, stepSize, weightPrice, weightSmooth, weightSafety;
-    string pathToConfiguration, pathToNetwork, pathToScenarioTree, pathToForecaster, algorithmName;
+    string pathToConfiguration, pathToNetwork, pathToScenarioTree, pathToForecaster, algorithmName, operatorMode;
 };
 
 #endif

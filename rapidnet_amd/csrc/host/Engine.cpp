@@ -7,29 +7,29 @@ void Engine::check(int rc, const char *what) {
     if (rc != RN_OK) throw std::runtime_error(string(what) + ": " + rn_last_error(ctx));
 }
 
-Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device) : ctx(nullptr) {
+Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device, int operatorMode) : ctx(nullptr) {
     ptrMySmpcConfig = smpcConfig;
     ptrMyNetwork = new DwnNetwork(smpcConfig->getPathToNetwork());          // never deleted by the reference either
     ptrMyScenarioTree = new ScenarioTree(smpcConfig->getPathToScenarioTree());
-    create(precision, device);
+    create(precision, device, operatorMode);
 }
 
-Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device) : ctx(nullptr) {
+Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device, int operatorMode) : ctx(nullptr) {
     ptrMyNetwork = network; ptrMyScenarioTree = scenarioTree; ptrMySmpcConfig = smpcConfig;
-    create(precision, device);
+    create(precision, device, operatorMode);
 }
 
-Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *id128, int cutStage) : ctx(nullptr) {
+Engine::Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *id128, int cutStage, int operatorMode) : ctx(nullptr) {
     ptrMySmpcConfig = smpcConfig;
     ptrMyNetwork = new DwnNetwork(smpcConfig->getPathToNetwork());
     ptrMyScenarioTree = new ScenarioTree(smpcConfig->getPathToScenarioTree());
-    create(precision, device, rank, nranks, id128, cutStage);
+    create(precision, device, operatorMode, rank, nranks, id128, cutStage);
 }
 
 Engine::Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks,
-               const void *id128, int cutStage) : ctx(nullptr) {
+               const void *id128, int cutStage, int operatorMode) : ctx(nullptr) {
     ptrMyNetwork = network; ptrMyScenarioTree = scenarioTree; ptrMySmpcConfig = smpcConfig;
-    create(precision, device, rank, nranks, id128, cutStage);
+    create(precision, device, operatorMode, rank, nranks, id128, cutStage);
 }
 
 uint_t Engine::getNumLocalNodes() {
@@ -43,7 +43,15 @@ std::vector<int> Engine::getGlobalNodes() {
     return g;
 }
 
-void Engine::create(int precision, int device, int rank, int nranks, const void *id128, int cutStage) {
+void Engine::setOperatorMode(int mode) { check(rn_set_operator_mode(ctx, mode), "rn_set_operator_mode"); }
+int Engine::getOperatorMode() {
+    int active = RN_OPS_DENSE;
+    check(rn_get_operator_mode(ctx, nullptr, &active), "rn_get_operator_mode");
+    return active;
+}
+void Engine::setOperator(int op, uint_t node, const real_t *host, size_t n) { check(rn_set_operator(ctx, op, node, host, n), "rn_set_operator"); }
+
+void Engine::create(int precision, int device, int operatorMode, int rank, int nranks, const void *id128, int cutStage) {
     myRank = rank; numRanks = nranks;
     priceUncertaintyFlag = true; demandUncertaintyFlag = true;
     const string alg = ptrMySmpcConfig->getOptimisationAlgorithm();   // Engine.cu:151-163
@@ -67,6 +75,11 @@ void Engine::create(int precision, int device, int rank, int nranks, const void 
     if (rc != RN_OK) throw std::runtime_error(string("rn_create_sharded: ") + rn_last_error(nullptr));
     check(rn_set_parameters(ctx, ptrMySmpcConfig->getStepSize(), ptrMySmpcConfig->getPenaltyState(), ptrMySmpcConfig->getPenaltySafety()),
           "rn_set_parameters");
+    if (operatorMode < 0) {   // the configuration's optional key (absent: auto)
+        const string m = ptrMySmpcConfig->getOperatorMode();
+        operatorMode = m == "dense" ? RN_OPS_DENSE : (m == "structured" ? RN_OPS_STRUCTURED : RN_OPS_AUTO);
+    }
+    check(rn_set_operator_mode(ctx, operatorMode), "rn_set_operator_mode");
     // SmpcController::allocateApgAlgorithm (SmpcController.cu:124-151): per-iteration storage for maxIterations, allocated once
     check(rn_reserve_iterations(ctx, (int)ptrMySmpcConfig->getMaxIterations()), "rn_reserve_iterations");
     if (!apgFlag)   // SmpcController::allocateGlobalFbeAlgorithm / allocateNamaAlgorithm / allocateLbfgsBuffer (SmpcController.cu:234-330)

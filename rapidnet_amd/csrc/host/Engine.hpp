@@ -17,8 +17,13 @@ class Engine {
 public:
     // reference: Engine(SmpcConfiguration*) news its own network and tree from the paths in the configuration
     // (Engine.cu:126-132).  precision: RN_F64 (default) or RN_F32; device: HIP device ordinal.
-    explicit Engine(SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0);
-    Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0);
+    // operatorMode: how the per-node operator blocks of the factor step (Engine.cu:166-189, :721-745) are kept.  RN_OPS_AUTO: never
+    // materialised while they are the factor step's own -- block = shared matrix x stage diagonal x power of p_i, applied as shared-operator
+    // products: identical iterates, 49 instead of 339 ms per 500-iteration control step on the 493-scenario tree -- and dense from the
+    // first setOperator() on; RN_OPS_DENSE: the reference's storage (one dense block per node, streamed every iteration); RN_OPS_STRUCTURED:
+    // never any block.  -1 (default): the configuration file's optional "operatorMode" key ("auto" | "dense" | "structured"; absent: auto).
+    explicit Engine(SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0, int operatorMode = -1);
+    Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0, int operatorMode = -1);
     // Multi-GPU (new; the reference is single-GPU): rank `rank` of `nranks`, one process and one GPU per rank.  The engine is
     // given the FULL network / tree / configuration exactly as above; the library keeps this rank's subtrees plus the
     // replicated crown (rn_create_sharded: partition below `cutStage`, 0 = the most balanced cut), creates the RCCL
@@ -26,9 +31,14 @@ public:
     // exchange is a test's job) and all-reduces the cut parents' children sums once per APG iteration.  Everything else --
     // factorStep, updateStateControl, eliminateInputDistubanceCoupling, the controller -- is called as on one GPU; node-major
     // buffers are local (getNumLocalNodes() nodes; getGlobalNodes() maps them to nodes of the full tree).
-    Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *ncclUniqueId128, int cutStage = 0);
+    Engine(SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks, const void *ncclUniqueId128, int cutStage = 0, int operatorMode = -1);
     Engine(DwnNetwork *network, ScenarioTree *scenarioTree, SmpcConfiguration *smpcConfig, int precision, int device, int rank, int nranks,
-           const void *ncclUniqueId128, int cutStage = 0);
+           const void *ncclUniqueId128, int cutStage = 0, int operatorMode = -1);
+    void setOperatorMode(int mode);                  // RN_OPS_AUTO / _DENSE / _STRUCTURED; before factorStep()
+    int getOperatorMode();                           // what the engine runs: RN_OPS_DENSE or RN_OPS_STRUCTURED
+    // a per-node block handed in by the caller (the reference: write through getMatPhi() / getPtrMatPhi()[node] ..., Engine.cuh:170-230);
+    // RN_OP_PHI, _PSI, _D, _F, col-major nv x (2nx | nu); after factorStep()
+    void setOperator(int opId, uint_t node, const real_t *host, size_t n);
     int getRank() { return myRank; }
     int getNumRanks() { return numRanks; }
     uint_t getNumLocalNodes();                       // nodes this rank holds (= the tree's node count on one GPU)
@@ -75,7 +85,7 @@ public:
     ~Engine();
 
 private:
-    void create(int precision, int device, int rank = 0, int nranks = 1, const void *id128 = nullptr, int cutStage = 0);
+    void create(int precision, int device, int operatorMode, int rank = 0, int nranks = 1, const void *id128 = nullptr, int cutStage = 0);
     int myRank = 0, numRanks = 1;
     void check(int rc, const char *what);
     DwnNetwork *ptrMyNetwork;

@@ -16,10 +16,10 @@ SmpcController::SmpcController(Forecaster *f, Engine *e, SmpcConfiguration *c)
     economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
 
-SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
+SmpcController::SmpcController(string pathToConfigFile, int operatorMode) : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
     ptrMySmpcConfig = new SmpcConfiguration(pathToConfigFile);          // SmpcController.cu:78-81
     ptrMyForecaster = new Forecaster(ptrMySmpcConfig->getPathToForecaster());
-    ptrMyEngine = new Engine(ptrMySmpcConfig);
+    ptrMyEngine = new Engine(ptrMySmpcConfig, RN_F64, 0, operatorMode);
     stepSize = ptrMySmpcConfig->getStepSize();
     vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
     vecValueFbe.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0); vecTau.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
@@ -27,11 +27,11 @@ SmpcController::SmpcController(string pathToConfigFile) : factorStepFlag(false),
     economicKpi = smoothKpi = safeKpi = networkKpi = 0;
 }
 
-SmpcController::SmpcController(string pathToConfigFile, int rank, int nranks, const void *id128, int device, int precision, int cutStage)
+SmpcController::SmpcController(string pathToConfigFile, int rank, int nranks, const void *id128, int device, int precision, int cutStage, int operatorMode)
     : factorStepFlag(false), simulatorFlag(true), ownsObjects(true) {
     ptrMySmpcConfig = new SmpcConfiguration(pathToConfigFile);
     ptrMyForecaster = new Forecaster(ptrMySmpcConfig->getPathToForecaster());
-    ptrMyEngine = new Engine(ptrMySmpcConfig, precision, device, rank, nranks, id128, cutStage);
+    ptrMyEngine = new Engine(ptrMySmpcConfig, precision, device, rank, nranks, id128, cutStage, operatorMode);
     stepSize = ptrMySmpcConfig->getStepSize();
     vecPrimalInfs.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);
     vecValueFbe.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0); vecTau.assign(ptrMySmpcConfig->getMaxIterations() + 1, 0.0);

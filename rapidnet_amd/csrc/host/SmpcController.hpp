@@ -10,9 +10,11 @@
 class SmpcController {
 public:
     SmpcController(Forecaster *myForecaster, Engine *myEngine, SmpcConfiguration *mySmpcConfig);
-    explicit SmpcController(string pathToConfigFile);
+    // operatorMode: Engine.hpp (RN_OPS_AUTO / _DENSE / _STRUCTURED; -1 = the configuration file's optional "operatorMode" key, absent: auto)
+    explicit SmpcController(string pathToConfigFile, int operatorMode = -1);
     // Multi-GPU (new): rank `rank` of `nranks`, see Engine's sharded constructor.  Same configuration file on every rank.
-    SmpcController(string pathToConfigFile, int rank, int nranks, const void *ncclUniqueId128, int device = 0, int precision = RN_F64, int cutStage = 0);
+    SmpcController(string pathToConfigFile, int rank, int nranks, const void *ncclUniqueId128, int device = 0, int precision = RN_F64, int cutStage = 0,
+                   int operatorMode = -1);
     void initialiseSmpcController();                        // SmpcController.cu:476-487
     void controllerSmpc();                                  // :1593-1599
     uint_t controlAction(real_t *u);                        // :1607-1625  (1 = ok)

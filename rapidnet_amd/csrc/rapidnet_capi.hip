@@ -161,6 +161,8 @@ struct CtxBase {
     virtual int kernel_info(int *) = 0;
     virtual int sweep_phase(int) = 0;
     virtual int set_operator_mode(int) = 0;
+    virtual int get_operator_mode(int *, int *) = 0;
+    virtual int set_operator(int, int, const double *, size_t) = 0;
     virtual int set_warm_start(int) = 0;
     virtual int set_exchange_mode(int) = 0;
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
@@ -326,7 +328,11 @@ struct Ctx : CtxBase {
     T *d_LBLp = nullptr;
     bool aux_dirty = true;   // eb = e + B uhat and bw0 = B (prevU - prevUhat) must be refreshed before the next sweep
     T *d_RTp = nullptr, *d_Lp = nullptr, *d_Bp = nullptr, *d_BLp = nullptr, *d_ab = nullptr;
-    int structured = 0, warmStart = 0;
+    // Operator storage (rn_set_operator_mode).  opsMode is what the caller asked for, `structured` what the context runs: RN_OPS_AUTO
+    // (the default) is structured for as long as every block is the factor step's own -- block = shared matrix x stage diagonal x power
+    // of p_i, Engine.cu:721-745 -- and becomes dense the moment a caller hands in a block of its own (rn_set_operator: materialise_dense)
+    int opsMode = RN_OPS_AUTO, structured = 1, warmStart = 0;
+    struct SavedSystem { std::vector<double> B, Gd, L, Lhat, W, diag, xmin, xmax, xsafe, umin, umax, alpha1; } h_sys;   // the factor step's inputs (AUTO: for the dense re-factor)
     int optimistic = 1;      // multi-GPU: 1 = one collective per iteration + verification, 0 = exact two-collective path
     bool pendingFin = false; // optimistic exchange: the previous iteration's bookkeeping has not been launched yet (it rides in the next k_cut_partial_sums)
     bool carryTail = false;  // the cut payload carries 2 extra reals (rank-local dist^2 of the previous iteration)
@@ -692,6 +698,13 @@ struct Ctx : CtxBase {
                      s->vecXsafe && s->vecUmin && s->vecUmax && s->costAlpha1, RN_E_ARG, "rn_factor_step: null input");
         RN_HIP(hipSetDevice(device));
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd, N = d.N;
+        if (opsMode == RN_OPS_AUTO && s->matB != h_sys.B.data()) {   // (not when materialise_dense re-runs the step on the saved copy)
+            h_sys.B.assign(s->matB, s->matB + (size_t)nx * nu); h_sys.Gd.assign(s->matGd, s->matGd + (size_t)nx * nd);
+            h_sys.L.assign(s->matL, s->matL + (size_t)nu * nv); h_sys.Lhat.assign(s->matLhat, s->matLhat + (size_t)nu * nd);
+            h_sys.W.assign(s->costW, s->costW + (size_t)nu * nu); h_sys.diag.assign(s->matDiagPrecnd, s->matDiagPrecnd + (size_t)N * (2 * nx + nu));
+            h_sys.xmin.assign(s->vecXmin, s->vecXmin + nx); h_sys.xmax.assign(s->vecXmax, s->vecXmax + nx); h_sys.xsafe.assign(s->vecXsafe, s->vecXsafe + nx);
+            h_sys.umin.assign(s->vecUmin, s->vecUmin + nu); h_sys.umax.assign(s->vecUmax, s->vecUmax + nu); h_sys.alpha1.assign(s->costAlpha1, s->costAlpha1 + nu);
+        }
         // Rbar = L' W L  (Engine.cu:412-416), inverse once: Omega_i = Rbar^-1 / p_i (Engine.cu:707-714)
         std::vector<double> WL((size_t)nu * nv), Rbar((size_t)nv * nv), Lt((size_t)nv * nu), WLt((size_t)nv * nu);
         h_gemm(false, false, nu, nv, nu, s->costW, nu, s->matL, nu, WL.data());
@@ -2298,10 +2311,48 @@ struct Ctx : CtxBase {
         return RN_OK;
     }
     int set_operator_mode(int mode) override {
-        RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_operator_mode: 0 (dense per-node blocks) or 1 (structured)");
-        RN_CHECK(!factored || mode == structured, RN_E_STATE, "rn_set_operator_mode must precede rn_factor_step");
-        structured = mode;
+        RN_CHECK(mode == RN_OPS_DENSE || mode == RN_OPS_STRUCTURED || mode == RN_OPS_AUTO, RN_E_ARG, "rn_set_operator_mode: RN_OPS_DENSE, RN_OPS_STRUCTURED or RN_OPS_AUTO");
+        const int want = mode == RN_OPS_DENSE ? 0 : 1;
+        RN_CHECK(!factored || want == structured, RN_E_STATE, "rn_set_operator_mode must precede rn_factor_step");
+        opsMode = mode; structured = want;
         return RN_OK;
+    }
+    int get_operator_mode(int *requested, int *active) override {
+        if (requested) *requested = opsMode;
+        if (active) *active = structured ? RN_OPS_STRUCTURED : RN_OPS_DENSE;
+        return RN_OK;
+    }
+    // RN_OPS_AUTO, a caller hands in a block of its own: from here on the context runs on dense per-node blocks -- the factor step once
+    // more on the saved inputs, this time expanding every block (Engine.cu:721-745) into d_A
+    int materialise_dense() {
+        RN_CHECK(factored && structured && opsMode == RN_OPS_AUTO && !h_sys.B.empty(), RN_E_STATE, "materialise_dense: not an RN_OPS_AUTO context after its factor step");
+        RN_HIP(hipStreamSynchronize(stream));
+        structured = 0; splitFirst = -1;      // (the streaming kernel's launch shape is decided by the factor step)
+        rn_system sy{h_sys.B.data(), h_sys.Gd.data(), h_sys.L.data(), h_sys.Lhat.data(), h_sys.W.data(), h_sys.diag.data(), h_sys.xmin.data(), h_sys.xmax.data(),
+                     h_sys.xsafe.data(), h_sys.umin.data(), h_sys.umax.data(), h_sys.alpha1.data()};
+        if (int rc = factor_step(&sy)) { structured = 1; return rc; }
+        if (algorithm == RN_ALG_NAMA) return set_algorithm(algorithm, lbfgsSize);   // (its paired sweep needs buffers of its own in dense mode)
+        return RN_OK;
+    }
+    // One node's block as the caller wants it (the counterpart of rn_get_operator; the reference's Engine hands out the device pointers of
+    // these arrays, Engine.cuh:170-230, so a caller may overwrite any block): Phi_i, Psi_i, D_i, Ftil_i -- the blocks solveStep multiplies
+    // with at SmpcController.cu:617-638.  Omega / Theta / G are K identical copies of shared matrices in the reference: not per-node here.
+    int set_operator(int op, int node, const double *host, size_t n) override {
+        RN_CHECK(factored, RN_E_STATE, "rn_set_operator before rn_factor_step");
+        RN_CHECK(host && node >= 0 && node < d.nodes, RN_E_ARG, "rn_set_operator: bad node");
+        RN_CHECK(op == RN_OP_PHI || op == RN_OP_PSI || op == RN_OP_D || op == RN_OP_F, RN_E_ARG,
+                 "rn_set_operator: only the per-node blocks Phi, Psi, D, F can be handed in (Omega, Theta, G are shared matrices scaled by p_i)");
+        const int nx = d.nx, nu = d.nu, nv = d.nv;
+        const bool xiCols = (op == RN_OP_PHI || op == RN_OP_D), top = (op == RN_OP_PHI || op == RN_OP_PSI);
+        const int cols = xiCols ? 2 * nx : nu, c0 = xiCols ? 0 : 2 * nx, r0 = top ? 0 : nv;
+        RN_CHECK(n == (size_t)nv * cols, RN_E_ARG, "rn_set_operator: size");
+        RN_CHECK(opsMode != RN_OPS_STRUCTURED, RN_E_STATE, "rn_set_operator: the context was created with RN_OPS_STRUCTURED (no per-node blocks); use RN_OPS_AUTO or RN_OPS_DENSE");
+        RN_HIP(hipSetDevice(device));
+        if (structured) { if (int rc = materialise_dense()) return rc; }
+        std::vector<double> blk((size_t)ny * LD);
+        if (int rc = download(blk.data(), d_A + (size_t)node * strideA, (size_t)ny * LD)) return rc;
+        for (int c = 0; c < cols; c++) for (int r = 0; r < nv; r++) blk[(size_t)(c0 + c) * LD + r0 + r] = host[r + (size_t)c * nv];
+        return upload(d_A + (size_t)node * strideA, blk.data(), (size_t)ny * LD);
     }
     int set_cut_moments(const double *E, const double *P, size_t nParents) override {
         RN_CHECK(cutStage > 0, RN_E_STATE, "rn_set_cut_children_moments: set the cut stage first");
@@ -2397,6 +2448,8 @@ int rn_get_kernel_info(rn_ctx *ctx, int info[8]) { RN_GUARD(ctx); return ctx->im
 int rn_get_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->counters(out); }
 int rn_set_cut_children_moments(rn_ctx *ctx, const double *E, const double *P, size_t n) { RN_GUARD(ctx); return ctx->impl->set_cut_moments(E, P, n); }
 int rn_set_operator_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_operator_mode(mode); }
+int rn_get_operator_mode(rn_ctx *ctx, int *requested, int *active) { RN_GUARD(ctx); return ctx->impl->get_operator_mode(requested, active); }
+int rn_set_operator(rn_ctx *ctx, int op, int node, const double *h, size_t n) { RN_GUARD(ctx); return ctx->impl->set_operator(op, node, h, n); }
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
 int rn_set_exchange_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_exchange_mode(mode); }
 int rn_measure_hbm(rn_ctx *ctx, size_t bytes, int reps, double *r, double *c) { RN_GUARD(ctx); return ctx->impl->measure_hbm(bytes, reps, r, c); }

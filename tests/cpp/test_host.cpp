@@ -20,6 +20,7 @@
 #include "../../include/rapidnet_debug.h"   // test hooks (leak injection, in-process communicator stand-in)
 
 static int g_failures = 0;
+static int g_ops = -1;   // operator mode of the controllers under test (-1: the default of the class surface)
 #define CHECK(cond)                                                                      \
     do {                                                                                 \
         if (!(cond)) { std::cerr << "FAILED " << #cond << " (" << __FILE__ << ":" << __LINE__ << ")\n"; g_failures++; } \
@@ -38,6 +39,13 @@ static bool closeRef(const real_t *a, const jsonlite::Value &ref, size_t n, cons
 static bool closeAbs(const real_t *a, const double *ref, size_t n, double tol, const char *what) {
     for (size_t i = 0; i < n; i++)
         if (!(std::fabs(a[i] - ref[i]) < tol)) { std::cerr << what << "[" << i << "] = " << a[i] << " vs " << ref[i] << "\n"; return false; }
+    return true;
+}
+// max-norm relative agreement of two vectors
+static bool closeRel(const real_t *a, const real_t *b, size_t n, double tol, const char *what) {
+    double d = 0, m = 1e-300;
+    for (size_t i = 0; i < n; i++) { d = std::max(d, std::fabs((double)a[i] - (double)b[i])); m = std::max(m, std::fabs((double)b[i])); }
+    if (!(d <= tol * m)) { std::cerr << what << ": max |a - b| = " << d << " against max |b| = " << m << "\n"; return false; }
     return true;
 }
 template <typename T> static bool sameAsJson(T *arr, const jsonlite::Value &ref, const char *what) {
@@ -115,7 +123,7 @@ static void testLoaders(const string &dir) {
 // reaches the protected step methods exactly as the reference's TestSmpcController does (TestSmpcController.cuh:80)
 class TestSmpcController : public SmpcController {
 public:
-    explicit TestSmpcController(const string &cfg) : SmpcController(cfg) {}
+    explicit TestSmpcController(const string &cfg) : SmpcController(cfg, g_ops) {}
     void run(const string &dir) {
         jsonlite::Document j(dir + "/smpcTest.json");
         const uint_t nx = getDwnNetwork()->getNumTanks(), nu = getDwnNetwork()->getNumControls(), nodes = getScenarioTree()->getNumNodes();
@@ -165,7 +173,7 @@ public:
 // TestSmpcController.cu:403-1040 against smpcFbeTest.json / smpcNamaTest.json, same tolerance rule, same order
 class TestFbeNamaController : public SmpcController {
 public:
-    explicit TestFbeNamaController(const string &cfg) : SmpcController(cfg) {}
+    explicit TestFbeNamaController(const string &cfg) : SmpcController(cfg, g_ops) {}
     void run(const string &dir) {
         const bool fbe = getEngine()->getGlobalFbeFlag();
         CHECK(fbe != getEngine()->getNamaFlag() && !getEngine()->getApgFlag());
@@ -263,7 +271,7 @@ public:
 static void testEngine(const string &dir) {   // Testing::testEngineTesting
     SmpcConfiguration cfg(dir + "/controllerConfig.json");
     Forecaster fc(dir + "/forecastor.json");
-    Engine eng(&cfg);
+    Engine eng(&cfg, RN_F64, 0, g_ops);
     fc.predictDemand(1); fc.predictPrices(1);
     eng.factorStep();
     eng.updateStateControl(cfg.getCurrentX(), cfg.getPrevU(), cfg.getPrevDemand());
@@ -315,7 +323,7 @@ static void testEngine(const string &dir) {   // Testing::testEngineTesting
 
 // main.cu:27-63: two closed-loop control steps with the in-built simulator, control written to a stream
 static void testClosedLoop(const string &dir) {
-    SmpcController ctl(dir + "/controllerConfig.json");
+    SmpcController ctl(dir + "/controllerConfig.json", g_ops);
     std::fstream out((dir + "/controlOutput.tmp").c_str(), std::fstream::out);
     std::vector<real_t> u(ctl.getSmpcConfiguration()->getNU());
     for (uint_t t = 0; t < 2; t++) {
@@ -388,7 +396,7 @@ static void testClosedLoop(const string &dir) {
 // closed loop of main.cu:45-63 for `steps` control steps, every quantity the loop carries printed with 17 digits (one JSON
 // object per step) for tests/test_gpu_closed_loop.py, which runs the CPU oracle through the same steps
 static void dumpClosedLoop(const string &dir, uint_t steps, bool disturbance) {
-    SmpcController ctl(dir + "/controllerConfig.json");
+    SmpcController ctl(dir + "/controllerConfig.json", g_ops);
     ctl.setSimulatorDisturbance(disturbance);
     std::fstream out((dir + "/controlOutput.tmp").c_str(), std::fstream::out);
     SmpcConfiguration *cfg = ctl.getSmpcConfiguration();
@@ -430,7 +438,7 @@ static void testNullSpace(const string &dir) {
     fc.predictDemand(1); fc.predictPrices(1);
     std::vector<real_t> xRef, uRef;
     for (int pass = 0; pass < 2; pass++) {
-        Engine eng(&cfg);
+        Engine eng(&cfg, RN_F64, 0, g_ops);
         DwnNetwork *net = eng.getDwnNetwork();
         const uint_t ne = net->getNumMixNodes(), nu = net->getNumControls(), nd = net->getNumDemands(), nv = cfg.getNV();
         if (pass == 1) {
@@ -469,7 +477,7 @@ static void testWarmStart(const string &dir) {
     for (int warm = 0; warm < 2; warm++) {
         SmpcConfiguration cfg(dir + "/controllerConfig.json");
         Forecaster fc(dir + "/forecastor.json");
-        Engine eng(&cfg);
+        Engine eng(&cfg, RN_F64, 0, g_ops);
         eng.setWarmStart(warm == 1);
         eng.factorStep();
         std::vector<real_t> u(cfg.getNU());
@@ -504,8 +512,8 @@ static void testWarmStart(const string &dir) {
 // tail and verdict vote -- and the reassembled x, u, duals must equal the unsharded controller's at 1e-9.
 class ShardedController : public SmpcController {
 public:
-    ShardedController(const string &cfg, int rank, int world) : SmpcController(cfg, rank, world, nullptr) {}
-    explicit ShardedController(const string &cfg) : SmpcController(cfg) {}
+    ShardedController(const string &cfg, int rank, int world) : SmpcController(cfg, rank, world, nullptr, 0, RN_F64, 0, g_ops) {}
+    explicit ShardedController(const string &cfg) : SmpcController(cfg, g_ops) {}
     using SmpcController::getVector;
     using SmpcController::algorithmApg;
 };
@@ -640,9 +648,66 @@ static void testSharded(const string &dir, int world) {
     delete ref.getEngine();
 }
 
+// What a drop-in caller gets: SmpcController(path) on the reference's own configuration file (no "operatorMode" key) runs the
+// structured form (RN_OPS_AUTO), the iterates are the dense form's, and handing in a block (Engine::setOperator, the counterpart of writing
+// through the reference's getMatPhi() pointers, Engine.cuh:170-230) switches the engine to dense storage with that block in use.
+static void testOperatorMode(const string &dir) {
+    SmpcController a(dir + "/controllerConfig.json"), dn(dir + "/controllerConfig.json", RN_OPS_DENSE);
+    CHECK(a.getSmpcConfiguration()->getOperatorMode() == "auto");
+    for (SmpcController *c : {&a, &dn}) {
+        c->getForecaster()->predictDemand(1);
+        c->getForecaster()->predictPrices(1);
+        c->initialiseSmpcController();
+    }
+    int req = -1, act = -1;
+    CHECK(rn_get_operator_mode(a.getEngine()->getContext(), &req, &act) == RN_OK && req == RN_OPS_AUTO && act == RN_OPS_STRUCTURED);
+    CHECK(dn.getEngine()->getOperatorMode() == RN_OPS_DENSE);
+    std::cout << "default: auto -> " << (act == RN_OPS_STRUCTURED ? "structured" : "dense") << "\n";
+    const uint_t nu = a.getSmpcConfiguration()->getNU(), nx = a.getSmpcConfiguration()->getNX(), nv = a.getSmpcConfiguration()->getNV();
+    std::vector<real_t> ua(nu), ud(nu);
+    CHECK(a.controlAction(ua.data()) == 1 && dn.controlAction(ud.data()) == 1);
+    CHECK(closeRel(ua.data(), ud.data(), nu, 1e-9, "u0: auto vs dense"));
+    // hand the factor step's own block of one node back in: the engine materialises the dense blocks and nothing changes ...
+    const uint_t node = a.getScenarioTree()->getNumNodes() / 2;
+    std::vector<real_t> phi((size_t)2 * nx * nv);
+    a.getEngine()->getOperator(RN_OP_PHI, node, phi.data(), phi.size());
+    a.getEngine()->setOperator(RN_OP_PHI, node, phi.data(), phi.size());
+    CHECK(a.getEngine()->getOperatorMode() == RN_OPS_DENSE);
+    std::cout << "after setOperator: " << (a.getEngine()->getOperatorMode() == RN_OPS_DENSE ? "dense" : "structured") << "\n";
+    CHECK(a.controlAction(ua.data()) == 1);
+    CHECK(closeRel(ua.data(), ud.data(), nu, 1e-9, "u0: materialised vs dense"));
+    // ... and a block of the caller's own IS used by the next sweep, exactly as in a dense engine given the same block
+    for (real_t &v : phi) v *= 1.5;
+    a.getEngine()->setOperator(RN_OP_PHI, node, phi.data(), phi.size());
+    dn.getEngine()->setOperator(RN_OP_PHI, node, phi.data(), phi.size());
+    std::vector<real_t> back(phi.size());
+    a.getEngine()->getOperator(RN_OP_PHI, node, back.data(), back.size());
+    CHECK(closeRel(back.data(), phi.data(), phi.size(), 1e-15, "block read back"));
+    std::vector<real_t> u2(nu), u3(nu);
+    CHECK(a.controlAction(u2.data()) == 1 && dn.controlAction(u3.data()) == 1);
+    CHECK(closeRel(u2.data(), u3.data(), nu, 1e-9, "u0 with the caller's block: materialised vs dense"));
+    real_t diff = 0;
+    for (uint_t i = 0; i < nu; i++) diff = std::max(diff, std::fabs(u2[i] - ud[i]));
+    CHECK(diff > 0);      // the block matters
+    // an engine that was told never to keep blocks refuses one
+    SmpcController st(dir + "/controllerConfig.json", RN_OPS_STRUCTURED);
+    st.getForecaster()->predictDemand(1); st.getForecaster()->predictPrices(1);
+    st.initialiseSmpcController();
+    CHECK(rn_set_operator(st.getEngine()->getContext(), RN_OP_PHI, (int)node, phi.data(), phi.size()) == RN_E_STATE);
+    CHECK(rn_set_operator(a.getEngine()->getContext(), RN_OP_OMEGA, (int)node, phi.data(), (size_t)nv * nv) == RN_E_ARG);
+}
+
 int main(int argc, char **argv) {
-    if (argc < 3) { std::cerr << "usage: test_host <loaders|engine|controller|closedloop> <fixture dir>\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: test_host <loaders|engine|controller|fbe|nama|closedloop|warmstart|nullspace|sharded> <fixture dir> [args] [ops=auto|dense|structured]\n"; return 2; }
     const string mode = argv[1], dir = argv[2];
+    // last argument "ops=...": the operator mode every controller of this run is constructed with (default: what the class surface gives a
+    // caller who says nothing -- the configuration file's key, absent in the reference's files: auto)
+    if (argc > 3 && string(argv[argc - 1]).rfind("ops=", 0) == 0) {
+        const string m = string(argv[argc - 1]).substr(4);
+        g_ops = m == "dense" ? RN_OPS_DENSE : (m == "structured" ? RN_OPS_STRUCTURED : (m == "auto" ? RN_OPS_AUTO : -2));
+        if (g_ops == -2) { std::cerr << "unknown operator mode " << m << "\n"; return 2; }
+        argc--;
+    }
     try {
         if (mode == "loaders") testLoaders(dir);
         else if (mode == "engine") testEngine(dir);
@@ -658,6 +723,7 @@ int main(int argc, char **argv) {
             t.run(dir);
         } else if (mode == "closedloop") testClosedLoop(dir);
         else if (mode == "closedloop_dump") dumpClosedLoop(dir, argc > 3 ? (uint_t)std::atoi(argv[3]) : 3, argc > 4 && std::atoi(argv[4]) != 0);
+        else if (mode == "opsmode") testOperatorMode(dir);
         else if (mode == "nullspace") testNullSpace(dir);
         else if (mode == "warmstart") testWarmStart(dir);
         else if (mode == "sharded") testSharded(dir, argc > 3 ? std::atoi(argv[3]) : 2);
@@ -667,6 +733,6 @@ int main(int argc, char **argv) {
         return 3;
     }
     if (g_failures) { std::cerr << g_failures << " check(s) failed\n"; return 1; }
-    std::cout << mode << ": all checks passed\n";
+    std::cout << mode << ": all checks passed" << (g_ops >= 0 ? (g_ops == RN_OPS_DENSE ? " [dense]" : (g_ops == RN_OPS_STRUCTURED ? " [structured]" : " [auto]")) : "") << "\n";
     return 0;
 }

@@ -192,7 +192,9 @@ def test_dual_stage_launch_shapes(trips, pipe):
     for name, iters in (("medium", 24), ("small", 20)):
         p, o, s = make_pair(name, knobs={"dual_trips": trips, "dual_pipe": pipe})
         k = s.kernelInfo()
-        assert k["dual_stage"] == 1 and k["dual_trips"] == trips and k["dual_pipe"] == pipe, k
+        if k["dual_stage"]:      # (a shape the stage-tiled kernel does not take -- odd ny -- runs the flat kernel whatever the knobs say)
+            assert k["dual_trips"] == trips and k["dual_pipe"] == pipe, k
+        assert k["dual_stage"] == 1 or name != "medium", k
         hist, ohist = s.algorithmApg(iters), o.apg(iters)
         compare_all(s, o, REL_TOL, "%s trips=%d pipe=%d" % (name, trips, pipe))
         assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()

@@ -30,27 +30,45 @@ def test_loaders_cpp_on_synthetic_files(tmp_path):
     _run("loaders", str(tmp_path))
 
 
-@pytest.mark.gpu
-def test_engine_cpp():
-    _run("engine")
+# Every known-answer mode runs in BOTH operator modes (round 6): "dense" is the reference's storage model, "auto" what a drop-in
+# SmpcController(path) gets when the configuration file says nothing -- the structured form, never a per-node block -- and the
+# reference's own vectors must come out of either.
+OPS = ["ops=dense", "ops=auto"]
 
 
 @pytest.mark.gpu
-def test_controller_known_answers_cpp():
-    _run("controller")
+@pytest.mark.parametrize("ops", OPS + ["ops=structured"])
+def test_engine_cpp(ops):
+    _run("engine", REF_FIXTURE, ops)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ops", OPS)
+def test_controller_known_answers_cpp(ops):
+    out = _run("controller", REF_FIXTURE, ops)
+    assert "all checks passed [%s]" % ops[4:] in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ops", OPS)
 @pytest.mark.parametrize("mode", ["fbe", "nama"])
-def test_fbe_nama_known_answers_cpp(mode):
+def test_fbe_nama_known_answers_cpp(mode, ops):
     """Testing::testSmpcFbeController / testSmpcNamaController re-run on the reference's own vectors."""
-    out = _run(mode)
+    out = _run(mode, REF_FIXTURE, ops)
     assert "all checks passed" in out
 
 
 @pytest.mark.gpu
-def test_closed_loop_cpp():
-    _run("closedloop")
+@pytest.mark.parametrize("ops", OPS)
+def test_closed_loop_cpp(ops):
+    _run("closedloop", REF_FIXTURE, ops)
+
+
+@pytest.mark.gpu
+def test_default_of_the_class_surface_is_the_structured_form_cpp():
+    """a drop-in SmpcController(path) on the reference's own configuration file (no operatorMode key) runs the exact fast path"""
+    out = _run("opsmode")
+    assert "default: auto -> structured" in out and "after setOperator: dense" in out
 
 
 @pytest.mark.gpu
@@ -65,9 +83,10 @@ def test_warm_start_cpp():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ops", OPS)
 @pytest.mark.parametrize("name,world,kw,replayed", [("medium", 2, {}, 0), ("medium", 8, {}, 0), ("ragged", 3, {}, 0),
                                                     ("medium", 4, {"penalty_x": 20.0, "penalty_xs": 5.0}, 1)])
-def test_sharded_controllers_cpp(tmp_path, name, world, kw, replayed):
+def test_sharded_controllers_cpp(tmp_path, name, world, kw, replayed, ops):
     """Multi-GPU through the C++ class surface: `world` SmpcController(path, rank, world, id) objects of
     one process, one thread each, against the unsharded controller -- see testSharded in tests/cpp/test_host.cpp.  With the
     small penalties the soft-constraint thresholds trip, so the optimistic batch is replayed through the exact
@@ -75,7 +94,7 @@ def test_sharded_controllers_cpp(tmp_path, name, world, kw, replayed):
     from rapidnet_amd import synth
 
     synth.write_problem(synth.make_problem(name, max_iterations=40, **kw), str(tmp_path))
-    out = _run("sharded", str(tmp_path), world)
+    out = _run("sharded", str(tmp_path), world, ops)
     assert "sharded: %d ranks" % world in out and "all checks passed" in out
     # one algorithmApg + three control steps: all optimistic, or one replayed batch followed by the back-off's exact batches
     assert ("optimistic/exact/replayed %s" % ("1/3/1" if replayed else "4/0/0")) in out, out
