@@ -371,27 +371,42 @@ int rn_shard_info(rn_ctx *ctx, int info[7]);
 /* index in the FULL tree of every local node (rn_get returns local node-major arrays); identity for unsharded contexts */
 int rn_shard_global_nodes(rn_ctx *ctx, int *globalNode, size_t n);
 
-/* ---- one-shot exchange at the cut (opt-in transport for the per-iteration exchange) ------------------
+/* ---- transport of the per-iteration exchange at the cut ----------------------------------------------
  * The reference has no counterpart (single GPU).  What is exchanged is exactly what solveSumChildren computes at the cut
- * (Utilities.cu:168-201): the cut parents' children sums.  With transport 1 the kernel that produces a rank's partial sums
- * writes them straight into an inbox on every peer (xGMI peer mappings) as self-validating {32 payload bits, 32-bit sequence
- * tag} packets, and the crown kernel of every rank adds the n contributions in rank order (the same bits everywhere): no
- * collective launch and no launch boundary between the chain walks and the crown.  The per-BATCH collectives (dist^2 tail,
- * verdict + history) stay with the communicator, which therefore must exist.  Set-up, once per context:
- *   rn_peer_inbox_create   allocates this rank's inbox (uncached device memory) and returns its 64-byte hipIpcMemHandle_t;
- *   (the caller gathers the handles of all ranks, in rank order -- bench.py: torch.distributed / gloo)
- *   rn_peer_inbox_connect  maps the peers' inboxes (hipIpcOpenMemHandle);
- *   rn_set_exchange_transport(ctx, 1)   one-shot inside rn_apg_iterate batches; 0 (default): the collective.
- * A reader that waits longer than 2 s ($RAPIDNET_ONESHOT_TIMEOUT_MS) for a peer's packets gives up: the batch returns
- * RN_E_COMM (never a hang), and every rank of the job returns it for that batch (the flag rides in the per-batch MAX all-reduce).
- * rn_peer_inbox_connect is once per context.  (Tests wire the inboxes of contexts of one process: rapidnet_debug.h.) */
+ * (Utilities.cu:168-201): the cut parents' children sums, once per iteration.  Two transports carry it:
+ *   RN_EXCHANGE_COLLECTIVE  ncclAllReduce on the solver's stream (RCCL), one launch between the chain walks and the crown;
+ *   RN_EXCHANGE_ONESHOT     the kernel that produces a rank's partial sums writes them straight into an inbox on every peer (xGMI peer
+ *                           mappings) as self-validating {32 payload bits, 32-bit sequence tag} packets and the same workgroup adds the
+ *                           n contributions for its cut parent in rank order (the same bits on every rank): no collective launch, no
+ *                           launch boundary.  The per-BATCH collectives (dist^2 tail, verdict + history) stay with the communicator.
+ *   RN_EXCHANGE_AUTO        (the default) the context times both on its OWN iterations and keeps the faster: rn_exchange_autotune.
+ * Inboxes: with a communicator made by rn_comm_init / rn_create_sharded the library allocates this rank's inbox (uncached device
+ * memory), gathers the hipIpcMemHandle_t of all ranks over the communicator and maps the peers' inboxes by itself, unless the
+ * transport was fixed to RN_EXCHANGE_COLLECTIVE before; if any rank cannot, all ranks agree to do without (AUTO then has one
+ * candidate).  rn_peer_inbox_create / rn_peer_inbox_connect do the same with handles the caller distributes.  A reader that waits
+ * longer than 2 s ($RAPIDNET_ONESHOT_TIMEOUT_MS) for a peer's packets gives up: the batch returns RN_E_COMM (never a hang) on every
+ * rank (the flag rides in the per-batch MAX all-reduce).  rn_peer_inbox_connect is once per context.  $RAPIDNET_EXCHANGE =
+ * collective | oneshot | auto sets the default of contexts that were not told.  (Tests wire the inboxes of contexts of one process:
+ * rapidnet_debug.h.) */
+enum { RN_EXCHANGE_COLLECTIVE = 0, RN_EXCHANGE_ONESHOT = 1, RN_EXCHANGE_AUTO = 2 };
 int rn_peer_inbox_create(rn_ctx *ctx, void *ipcHandle64 /* 64 bytes out */);
 int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 bytes, rank order */, int nranks);
 int rn_set_exchange_transport(rn_ctx *ctx, int transport);
+/* The exchange chooses itself.  iterations > 0: every rank of the communicator calls this at the same point (after the factor step and
+ * the affine terms); each candidate transport runs `iterations` device-resident APG iterations of the context (after a warm-up run of
+ * half as many) from the current iterates, which are restored afterwards -- iterates, iteration count and batch counters are what they
+ * were; the ranks' times are combined by a MAX all-reduce, so every rank keeps the same transport.  A context whose transport is AUTO
+ * does this by itself in its first device-resident batch (min(max(n, 20), 100) iterations).  iterations == 0: report only.
+ * info = {transport in use (0 / 1), candidates timed (bit 0 collective, bit 1 one-shot), microseconds per iteration with the
+ * collective (max over ranks), with the one-shot exchange (max over ranks; -1: it failed on a rank; 0: not a candidate), this rank's
+ * own two figures, iterations per candidate, tunes run so far}. */
+int rn_exchange_autotune(rn_ctx *ctx, int iterations, double info[8]);
 /* The forward walk and the fused dual update of the nodes it has just walked in ONE launch (k_down_chain_dual: Hx stays in LDS between
- * the two; SmpcController.cu:676-747 + :759-864 per node) inside batches of >= 16 iterations; identical iterates.  Opt-in (default:
- * $RAPIDNET_FUSE_DOWN_DUAL, else off): 0.9 % faster per iteration on the 493-scenario tree, slower on small shards, and the default
- * keeps the dual update a kernel of its own (the one the roofline target names). */
+ * the two; SmpcController.cu:676-747 + :759-864 per node) inside batches of >= 16 iterations; identical iterates (bitwise).
+ * on = -1 (default): decided by the shape of the context -- on for unsharded trees with at least as many scenario chains as the device
+ * has compute units (the 493-scenario tree: 0.9 % faster per iteration, 5 % in structured mode), off for small trees and shards (where
+ * it measured slower); 0 / 1: off / on whenever the shape allows it.  $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 sets the default of contexts
+ * that were not told.  While rn_profile_enable is on the dual update always runs as a launch of its own. */
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on);
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red

@@ -23,7 +23,8 @@ OPS_DENSE, OPS_STRUCTURED, OPS_AUTO = 0, 1, 2
 OPS_MODES = {"dense": OPS_DENSE, "structured": OPS_STRUCTURED, "auto": OPS_AUTO}
 # include/rapidnet_debug.h, RN_KNOB_*
 KNOBS = {k: i for i, k in enumerate(("dual_trips", "dual_pipe", "vlv_wide", "slab_pipe", "slab_frag", "unscaled_walk", "stream_two_per_cu",
-                                     "stream_split", "nama_pair", "ls_sequential", "value_mfma"))}
+                                     "stream_split", "nama_pair", "ls_sequential", "value_mfma", "tune_bias_us"))}
+EXCHANGE_COLLECTIVE, EXCHANGE_ONESHOT, EXCHANGE_AUTO = 0, 1, 2
 
 # every symbol include/rapidnet.h (the boundary) and include/rapidnet_debug.h (test hooks, rn_debug_*) declare
 SYMBOLS = [
@@ -41,7 +42,7 @@ SYMBOLS = [
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
     "rn_debug_set_allreduce", "rn_debug_local_group_create", "rn_debug_local_group_join", "rn_debug_local_group_destroy",
     "rn_guard_check", "rn_device_memory_info", "rn_reserve_iterations", "rn_profile_read_collective", "rn_debug_inject_allocation", "rn_guard_report", "rn_debug_guard_poke",
-    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_set_fused_walk_dual", "rn_debug_set_knob",
+    "rn_fbe_counters", "rn_peer_inbox_create", "rn_peer_inbox_connect", "rn_debug_peer_inbox_connect_local", "rn_debug_peer_seq", "rn_set_exchange_transport", "rn_exchange_autotune", "rn_set_fused_walk_dual", "rn_debug_set_knob",
 ]
 
 
@@ -213,6 +214,7 @@ def load():
     lib.rn_debug_peer_inbox_connect_local.argtypes = [C.POINTER(vp), ip]
     lib.rn_debug_peer_seq.argtypes = [vp, C.c_uint]
     lib.rn_set_exchange_transport.argtypes = [vp, ip]
+    lib.rn_exchange_autotune.argtypes = [vp, ip, dp]
     lib.rn_set_fused_walk_dual.argtypes = [vp, ip]
     lib.rn_debug_set_knob.argtypes = [vp, ip, ip]
     lib.rn_profile_read_collective.argtypes = [vp, dp, dp]
@@ -555,12 +557,20 @@ class Solver:
         self._check(self.lib.rn_debug_peer_seq(self.h, int(seq) & 0xFFFFFFFF))
 
     def setExchangeTransport(self, transport):
-        """0: the cut payload is all-reduced by the communicator (default); 1: one-shot peer writes (needs connected inboxes)"""
+        """EXCHANGE_COLLECTIVE (0): the cut payload is all-reduced by the communicator; EXCHANGE_ONESHOT (1): one-shot peer writes (needs
+        connected inboxes); EXCHANGE_AUTO (2, the default): the context times both in its first batch and keeps the faster"""
         self._check(self.lib.rn_set_exchange_transport(self.h, int(transport)))
 
+    def exchangeAutotune(self, iterations=0):
+        """rn_exchange_autotune: iterations > 0 tunes now (collective: every rank calls it), 0 reports the last result"""
+        out = np.zeros(8)
+        self._check(self.lib.rn_exchange_autotune(self.h, int(iterations), out.ctypes.data))
+        return {"transport": int(out[0]), "candidates": int(out[1]), "collective_us": float(out[2]), "oneshot_us": float(out[3]),
+                "own_collective_us": float(out[4]), "own_oneshot_us": float(out[5]), "iterations": int(out[6]), "tunes": int(out[7])}
+
     def setFusedWalkDual(self, on):
-        """1: forward walk + dual update in one launch inside batches of >= 16 iterations (identical iterates; opt-in)"""
-        self._check(self.lib.rn_set_fused_walk_dual(self.h, int(bool(on))))
+        """1 / 0: forward walk + dual update in one launch inside batches of >= 16 iterations (identical iterates) on / off; -1: by shape (default)"""
+        self._check(self.lib.rn_set_fused_walk_dual(self.h, int(on)))
 
     def debugSetKnob(self, knob, value):
         """rn_debug_set_knob (include/rapidnet_debug.h): force a launch-shape choice the library otherwise makes by problem size; before factorStep.

@@ -202,6 +202,8 @@ struct CtxBase {
     virtual int peer_inbox_connect_local(CtxBase **, int) = 0;
     virtual unsigned long long *peer_inbox_ptr() = 0;
     virtual int set_exchange_transport(int) = 0;
+    virtual int exchange_autotune_api(int, double *) = 0;
+    virtual int exchange_prepare_api() = 0;
     virtual int set_fused_walk_dual(int) = 0;
     virtual int set_knob(int, int) = 0;
     virtual int debug_peer_seq(unsigned int) = 0;
@@ -423,6 +425,7 @@ struct Ctx : CtxBase {
 
     ~Ctx() override {
         g_liveContexts--;
+        if (commJob) { std::lock_guard<std::mutex> lk(commJob->m); commJob->abandoned = true; }   // a helper still inside ncclCommInitRank destroys what it gets
         if (comm && g_nccl.CommDestroy) g_nccl.CommDestroy(comm);
         (void)hipSetDevice(device);
         if (guardMode && stream) {   // guard mode: a context never goes away with an overwritten red zone unnoticed
@@ -589,6 +592,11 @@ struct Ctx : CtxBase {
         d = *dims; device = dev;
         g_liveContexts++;
         for (int &k : knob) k = -1;
+        if (const char *e = std::getenv("RAPIDNET_EXCHANGE")) {   // default transport of new contexts: collective | oneshot | auto
+            const std::string v(e);
+            if (v == "collective" || v == "rccl") { transportReq = RN_EXCHANGE_COLLECTIVE; tuned = true; }
+            else if (v == "oneshot") { transportReq = RN_EXCHANGE_ONESHOT; tuned = true; }      // (takes effect once the inboxes are connected: exchange_prepare)
+        }
         { const char *e = std::getenv("RAPIDNET_GUARD"); guardMode = e && std::atoi(e) != 0; }
         RN_CHECK(d.nx > 0 && d.nu > 0 && d.nv > 0 && d.nd > 0 && d.N > 0 && d.K > 0 && d.nodes > 0, RN_E_ARG, "rn_create: non-positive dimension");
         RN_CHECK(d.nv <= d.nu, RN_E_ARG, "rn_create: nv must not exceed nu");
@@ -671,7 +679,7 @@ struct Ctx : CtxBase {
         DA(d_ybuf[0], n * ny) DA(d_ybuf[1], n * ny) DA(d_wbuf[0], n * ny) DA(d_wbuf[1], n * ny)
         DA(d_tmp, n * (size_t)std::max(2 * nx, std::max(nu, nv)))
         DA(d_cut, (size_t)nodes * (nv + 2 * nx))  // upper bound on cut parents
-        DA(d_state, 1) DA(d_partials, std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
+        DA(d_tune, 8) DA(d_state, 1) DA(d_partials, std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) DA(d_partials2, ELT_MAX_BLOCKS) DA(d_dist2, 2)
 #undef DA
         std::vector<double> sq(nodes);
         for (int i = 0; i < nodes; i++) sq[i] = std::sqrt(h_prob[i]);
@@ -1279,7 +1287,8 @@ struct Ctx : CtxBase {
         // sharded (foldCrown = 2): one more workgroup per replicated crown node, which writes that node while the chains are walked
         const int downGrid = a.K + (foldCrown == 2 ? h_stageCum[cs] : 0);
         const size_t fuseLds = (size_t)d.N * ny * sizeof(T);      // Hx of the chain's N - cs nodes and of up to cs crown nodes
-        if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024) {
+        // (every workgroup leaves one entry in d_partials: trees with more chains than it holds take the two launches)
+        if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024 && downGrid <= std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) {
             if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
             else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
             fuseDone = true; mainPartials = downGrid;
@@ -1471,14 +1480,12 @@ struct Ctx : CtxBase {
     // exceeded, the batch is replayed from a checkpoint with the exact two-collective path.  Results are exact either way.
     int apg_iterate_optimistic(int n, double *primalInfs) {
         const int first = h_it;
-        const size_t bytes = (size_t)ntot() * sizeof(T);
         for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         if (int rc = ensure_tables(h_it + n)) return rc;
         // checkpoint
         const size_t tail = cut_tail_offset();
         if (int rc = batch_open(d_cut + tail)) return fail_batch(rc);  // checkpoint of (y, y+, w), the payload's dist^2 tail and the verdict flag cleared: one launch
-        T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
-        const bool s_ready = acc_ready;
+        const IterSave saved = save_iterates();
         carryTail = true; inBatch = true;
         const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
@@ -1528,23 +1535,35 @@ struct Ctx : CtxBase {
             violated = votes > 0 ? 1 : 0;
         } else RN_HIP(hipStreamSynchronize(stream));
         if (transport == 1 && peerReady) { if (int rc = check_comm_fail()) return fail_batch(rc); }
-        if (violated) {   // replay the batch exactly
-            fallbacks++;
-            p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
-            RN_HIP(hipMemcpyAsync(p_xi, d_ck[0], bytes, hipMemcpyDeviceToDevice, stream));
-            RN_HIP(hipMemcpyAsync(p_upd, d_ck[1], bytes, hipMemcpyDeviceToDevice, stream));
-            RN_HIP(hipMemcpyAsync(p_acc, d_ck[2], bytes, hipMemcpyDeviceToDevice, stream));
-            h_it = first;
-            RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
-            RN_HIP(hipStreamSynchronize(stream));
-            const int keep = optimistic;
-            optimistic = 0; inReplay = true; optHold = RN_OPT_BACKOFF;
-            const int rc = apg_iterate(n, primalInfs);
-            optimistic = keep; inReplay = false;
-            return rc;
-        }
+        if (violated) return replay_exact(saved, n, primalInfs);
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
+    }
+    // The iterate state a batch starts from, as far as it is not in the checkpoint buffers (d_ck: y, y+, w -- written by batch_open):
+    // which buffer plays which role, and the iteration count.  restore_iterates puts a context back there (the replay of a tripped batch;
+    // the timing runs of the exchange auto-tuner).
+    struct IterSave { T *xi, *upd, *acc, *other; bool ready; int it; };
+    IterSave save_iterates() const { return IterSave{p_xi, p_upd, p_acc, p_acc_other, acc_ready, h_it}; }
+    int restore_iterates(const IterSave &sv) {
+        const size_t bytes = (size_t)ntot() * sizeof(T);
+        p_xi = sv.xi; p_upd = sv.upd; p_acc = sv.acc; p_acc_other = sv.other; p_acc_view = p_acc; acc_ready = sv.ready;
+        RN_HIP(hipMemcpyAsync(p_xi, d_ck[0], bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(p_upd, d_ck[1], bytes, hipMemcpyDeviceToDevice, stream));
+        RN_HIP(hipMemcpyAsync(p_acc, d_ck[2], bytes, hipMemcpyDeviceToDevice, stream));
+        h_it = sv.it;
+        RN_HIP(hipMemcpyAsync(&d_state->it, &sv.it, sizeof(int), hipMemcpyHostToDevice, stream));
+        RN_HIP(hipStreamSynchronize(stream));   // (sv.it is the caller's)
+        return RN_OK;
+    }
+    // an optimistic batch whose verdict says "a threshold was exceeded": the same n iterations once more from the checkpoint, through the exact path
+    int replay_exact(const IterSave &sv, int n, double *primalInfs) {
+        fallbacks++;
+        if (int rc = restore_iterates(sv)) return fail_batch(rc);
+        const int keep = optimistic;
+        optimistic = 0; inReplay = true; optHold = RN_OPT_BACKOFF;
+        const int rc = apg_iterate(n, primalInfs);
+        optimistic = keep; inReplay = false;
+        return rc;
     }
     int batch_open(T *tail) {
         const long long n = ntot();
@@ -1560,12 +1579,10 @@ struct Ctx : CtxBase {
     // is replayed from its checkpoint through the exact path -- the result is exact either way.
     int apg_iterate_optimistic_local(int n, double *primalInfs) {
         const int first = h_it;
-        const size_t bytes = (size_t)ntot() * sizeof(T);
         for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
         if (int rc = ensure_tables(h_it + n)) return rc;
         if (int rc = batch_open(nullptr)) return fail_batch(rc);       // checkpoint of (y, y+, w) + the verdict flag cleared: one launch
-        T *const s_xi = p_xi, *const s_upd = p_upd, *const s_acc = p_acc, *const s_other = p_acc_other;
-        const bool s_ready = acc_ready;
+        const IterSave saved = save_iterates();
         const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
@@ -1604,21 +1621,7 @@ struct Ctx : CtxBase {
             RN_HIP(hipMemcpyAsync(&violated, &d_state->violated, sizeof(int), hipMemcpyDeviceToHost, stream));
             RN_HIP(hipStreamSynchronize(stream));
         }
-        if (violated) {   // replay the batch exactly
-            fallbacks++;
-            p_xi = s_xi; p_upd = s_upd; p_acc = s_acc; p_acc_other = s_other; p_acc_view = p_acc; acc_ready = s_ready;
-            RN_HIP(hipMemcpyAsync(p_xi, d_ck[0], bytes, hipMemcpyDeviceToDevice, stream));
-            RN_HIP(hipMemcpyAsync(p_upd, d_ck[1], bytes, hipMemcpyDeviceToDevice, stream));
-            RN_HIP(hipMemcpyAsync(p_acc, d_ck[2], bytes, hipMemcpyDeviceToDevice, stream));
-            h_it = first;
-            RN_HIP(hipMemcpyAsync(&d_state->it, &first, sizeof(int), hipMemcpyHostToDevice, stream));
-            RN_HIP(hipStreamSynchronize(stream));
-            const int keep = optimistic;
-            optimistic = 0; inReplay = true; optHold = RN_OPT_BACKOFF;
-            const int rc = apg_iterate(n, primalInfs);
-            optimistic = keep; inReplay = false;
-            return rc;
-        }
+        if (violated) return replay_exact(saved, n, primalInfs);
         if (primalInfs && n > 0) RN_HIP(hipMemcpy(primalInfs, d_hist + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return RN_OK;
     }
@@ -1633,17 +1636,34 @@ struct Ctx : CtxBase {
     PeerTable h_peer{};   // handed to the kernels by value (SweepArgs::peer)
     std::vector<void *> ipcOpened;
     bool peerReady = false, inBatch = false;
-    int transport = 0;            // 0: the cut payload is all-reduced by the collective; 1: one-shot peer writes (inside rn_apg_iterate batches)
-    // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual; opt-in: RAPIDNET_FUSE_DOWN_DUAL=1):
-    // the optimistic batches ask for it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened
+    // Transport of the per-iteration exchange at the cut.  transportReq is what the caller asked for (RN_EXCHANGE_AUTO unless told:
+    // rn_set_exchange_transport, $RAPIDNET_EXCHANGE), `transport` what the batches run: 0 = the communicator's all-reduce on the solver's
+    // stream, 1 = one-shot peer writes.  AUTO is resolved by exchange_autotune -- by the first device-resident batch, or when the caller
+    // asks (rn_exchange_autotune): both candidates run the context's own iterations, the ranks agree on the faster one.
+    int transportReq = RN_EXCHANGE_AUTO, transport = 0;
+    bool tuned = false, inTune = false, oneShotBroken = false;
+    double tuneInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rn_exchange_autotune: {chosen, candidates, us/it collective (max over ranks), us/it one-shot (max), own collective, own one-shot, iterations, tunes run}
+    double *d_tune = nullptr;    // 8 doubles: the ranks' agreement on the timings (allocated with the context: a control step never allocates)
+    // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual): the optimistic batches ask for
+    // it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened.
+    // Default BY SHAPE (round 6): on where one workgroup per chain fills the chip -- at least as many chains as CUs, unsharded:
+    // the whole 493-scenario tree -6 us per iteration (0.9 %), +5.4 % iterations/s in structured mode -- off on small trees and shards
+    // (62 workgroups of a 1/8 shard cannot keep as many bytes in flight as the stage-tiled kernel's grid: +2 us;
+    // profiles/r05_ab_fused_walk_dual.txt, profiles/r06_ab_fuse_by_shape.txt).  rn_set_fused_walk_dual(ctx, 0 / 1) or
+    // $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 (read when the context runs its first batch) force it either way; while the per-launch profiling
+    // of rn_profile_enable is on, the dual update always runs as a launch of its own (the kernel north_star's roofline target names).
     bool fuseReq = false, fuseDone = false, fuseMat = false;
     DualArgs<T> fuseArgs{};
     double fuseLn = 0.0;
-    int fuseEnv = -1;      // rn_set_fused_walk_dual, or $RAPIDNET_FUSE_DOWN_DUAL read when the context runs its first batch
-    int set_fused_walk_dual(int on) override { RN_CHECK(on == 0 || on == 1, RN_E_ARG, "rn_set_fused_walk_dual: 0 or 1"); fuseEnv = on; return RN_OK; }
+    int fuseMode = -2;     // -2: not decided yet ($RAPIDNET_FUSE_DOWN_DUAL, else by shape), -1: by shape, 0 / 1: forced
+    int set_fused_walk_dual(int on) override { RN_CHECK(on >= -1 && on <= 1, RN_E_ARG, "rn_set_fused_walk_dual: 0, 1 or -1 (by shape)"); fuseMode = on; return RN_OK; }
+    bool fuse_by_shape() const {
+        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
+        return cutStage <= 0 && K >= numCUs;
+    }
     bool fuse_want() {
-        if (fuseEnv < 0) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseEnv = e ? (std::atoi(e) != 0) : 0; }
-        return fuseEnv != 0 && dualU != 0 && !prof;
+        if (fuseMode == -2) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseMode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }
+        return (fuseMode == 1 || (fuseMode == -1 && fuse_by_shape())) && dualU != 0 && !prof;
     }
     unsigned int peerSeq = 0;     // sequence number of the last one-shot exchange (the same on every rank: they issue the same exchanges)
     unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }
@@ -1710,9 +1730,127 @@ struct Ctx : CtxBase {
         return RN_OK;
     }
     int set_exchange_transport(int t) override {
-        RN_CHECK(t == 0 || t == 1, RN_E_ARG, "rn_set_exchange_transport: 0 (collective) or 1 (one-shot peer writes)");
-        RN_CHECK(t == 0 || peerReady, RN_E_STATE, "rn_set_exchange_transport: connect the peers' inboxes first (rn_peer_inbox_connect)");
-        transport = t;
+        RN_CHECK(t == RN_EXCHANGE_COLLECTIVE || t == RN_EXCHANGE_ONESHOT || t == RN_EXCHANGE_AUTO, RN_E_ARG,
+                 "rn_set_exchange_transport: RN_EXCHANGE_COLLECTIVE, RN_EXCHANGE_ONESHOT or RN_EXCHANGE_AUTO");
+        if (t == RN_EXCHANGE_ONESHOT && !peerReady) { if (int rc = exchange_prepare()) return rc; }   // (a real communicator: the library wires the inboxes itself)
+        RN_CHECK(t != RN_EXCHANGE_ONESHOT || peerReady, RN_E_STATE, "rn_set_exchange_transport: the peers' inboxes are not connected (rn_peer_inbox_connect, or a communicator over which the library can exchange the handles)");
+        transportReq = t;
+        transport = t == RN_EXCHANGE_ONESHOT ? 1 : 0;
+        tuned = t != RN_EXCHANGE_AUTO;
+        return RN_OK;
+    }
+    // ---- the exchange chooses itself (round 6) ----------------------------------------------------------------------------------
+    // all-reduce of raw integers over the library's own communicator (the IPC handles travel this way: every rank fills its own slot of a
+    // zeroed buffer, the sum is the gather)
+    int all_reduce_bytes(void *buf, size_t count, const char *what) {
+        RN_CHECK(comm != nullptr, RN_E_STATE, std::string(what) + ": no communicator");
+        const int rc = g_nccl.AllReduce(buf, buf, count, 1 /* ncclUint8 */, 0 /* ncclSum */, comm, stream);
+        RN_CHECK(rc == 0, RN_E_COMM, std::string(what) + " failed: " + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"));
+        return RN_OK;
+    }
+    // One-shot transport made available WITHOUT the caller's help: the inbox of this rank, its IPC handle gathered over the RCCL
+    // communicator, the peers' inboxes mapped.  Collective (every rank of the communicator calls it at the same point: rn_comm_init /
+    // rn_create_sharded / rn_set_exchange_transport(ONESHOT) do).  A rank that cannot create or map an inbox makes EVERY rank give the
+    // transport up (a MAX all-reduce of the failure flags): returns RN_OK with peerReady == false, and AUTO then has one candidate.
+    bool prepared = false;
+    int exchange_prepare() {
+        if (prepared || peerReady || oneShotBroken) return RN_OK;
+        if (comm == nullptr || nranks < 2 || nranks > PEER_MAX || cutStage <= 0) return RN_OK;   // stand-in communicators: the test wires the inboxes
+        prepared = true;
+        RN_HIP(hipSetDevice(device));
+        unsigned char handle[64] = {0};
+        int bad = peer_inbox_create(handle) != RN_OK ? 1 : 0;
+        unsigned char *d_h = nullptr;
+        const size_t hb = (size_t)64 * nranks + 8;      // + the failure flags' slot
+        if (hipMalloc((void **)&d_h, hb) != hipSuccess) { (void)hipGetLastError(); d_h = nullptr; bad = 1; }
+        std::vector<unsigned char> all(hb, 0);
+        if (d_h) {
+            std::memcpy(all.data() + (size_t)64 * rank, handle, 64);
+            all[(size_t)64 * nranks] = (unsigned char)(bad ? 1 : 0);      // (sum over <= 16 ranks: no overflow)
+            if (hipMemcpyAsync(d_h, all.data(), hb, hipMemcpyHostToDevice, stream) != hipSuccess) bad = 1;
+        }
+        // every rank MUST issue the same collectives whatever happened to it: a rank without a buffer contributes through a fallback slot
+        int rc = RN_OK;
+        if (d_h) rc = all_reduce_bytes(d_h, hb, "ncclAllReduce(inbox handles)");
+        else { err = "exchange_prepare: no device memory for the handle exchange"; rc = RN_E_HIP; }
+        if (rc == RN_OK && (hipMemcpyAsync(all.data(), d_h, hb, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) { (void)hipGetLastError(); rc = RN_E_HIP; }
+        if (d_h) (void)hipFree(d_h);
+        if (rc != RN_OK) { oneShotBroken = true; return rc; }      // the communicator itself failed: the caller must know
+        if (all[(size_t)64 * nranks] == 0) {
+            if (peer_inbox_connect(all.data(), nranks) != RN_OK) { (void)hipGetLastError(); bad = 1; }
+        } else bad = 1;
+        // second agreement: did every rank map every peer?
+        double flag = bad ? 1.0 : 0.0;
+        RN_HIP(hipMemcpyAsync(d_tune, &flag, sizeof flag, hipMemcpyHostToDevice, stream));
+        if (int rc2 = all_reduce(d_tune, 1, true, "ncclAllReduce(inbox set-up verdict)", 2 /* ncclMax */)) { oneShotBroken = true; peerReady = false; return rc2; }
+        RN_HIP(hipMemcpyAsync(&flag, d_tune, sizeof flag, hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        if (flag != 0.0) { peerReady = false; oneShotBroken = true; }      // somebody could not: nobody uses the transport (err keeps this rank's reason, if it was this rank)
+        else if (transportReq == RN_EXCHANGE_ONESHOT) transport = 1;
+        return RN_OK;
+    }
+    // Times the candidates on THIS context's own iterations and keeps the faster: `iters` device-resident iterations per candidate (after
+    // a warm-up run of half as many) from the current iterate state, which is restored afterwards -- iterates, iteration count, batch
+    // counters: a caller cannot tell that the runs happened, except by the clock.  The ranks' times are combined by a MAX all-reduce, so
+    // every rank takes the same decision.  Collective: every rank calls it at the same point (rn_apg_iterate does, in its first batch).
+    int exchange_autotune(int iters) {
+        RN_CHECK(factored && affine_ready, RN_E_STATE, "rn_exchange_autotune before the factor step / affine terms");
+        RN_CHECK(!poisoned, RN_E_STATE, "rn_exchange_autotune: an earlier batch failed half-way; call rn_apg_reset first");
+        RN_CHECK(iters >= 1, RN_E_ARG, "rn_exchange_autotune: iterations >= 1");
+        RN_HIP(hipSetDevice(device));
+        tuned = true;
+        const bool sharded = has_comm() && cutStage > 0 && nranks > 1 && optimistic;
+        if (sharded && !peerReady) { if (int rc = exchange_prepare()) return rc; }
+        const bool canOne = sharded && peerReady && !oneShotBroken;
+        tuneInfo[1] = 1.0 + (canOne ? 2.0 : 0.0); tuneInfo[6] = 0; tuneInfo[2] = tuneInfo[3] = tuneInfo[4] = tuneInfo[5] = 0.0;
+        if (!canOne) { transport = 0; tuneInfo[0] = 0; return RN_OK; }     // one candidate: nothing to time
+        for (int i = 0; i < 3; i++) if (!d_ck[i]) { if (int rc = dalloc(&d_ck[i], (size_t)ntot())) return rc; }
+        // what the timing runs must leave as they found it (the iterates themselves are in the batch's own checkpoint)
+        const IterSave sv = save_iterates();
+        const long kOpt = optBatches, kExact = exactBatches, kFall = fallbacks; const int kHold = optHold;
+        double own[2] = {0, 0};
+        int failed[2] = {0, 0};
+        inTune = true;
+        for (int cand = 0; cand < 2; cand++) {
+            transport = cand;
+            for (int pass = 0; pass < 2 && !failed[cand]; pass++) {
+                const int n = pass == 0 ? std::max(iters / 2, 8) : iters;
+                optHold = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = apg_iterate_optimistic(n, nullptr);     // ends with a synchronisation
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (rc != RN_OK) {      // (a one-shot reader's time-out is every rank's RN_E_COMM: all ranks come here together)
+                    failed[cand] = 1; poisoned = false;
+                    (void)hipMemsetAsync(&d_state->commFail, 0, sizeof(int), stream);
+                }
+                if (pass == 1 && rc == RN_OK) own[cand] = us / n;
+                if (int rc2 = restore_iterates(sv)) { inTune = false; return fail_batch(rc2); }
+            }
+        }
+        inTune = false;
+        optBatches = kOpt; exactBatches = kExact; fallbacks = kFall; optHold = kHold;
+        if (knob[RN_KNOB_TUNE_BIAS_US] != -1) own[1] += (double)knob[RN_KNOB_TUNE_BIAS_US];      // test of the selection: this rank's one-shot time, biased
+        // every rank the same figures: MAX over the ranks of {time collective, time one-shot, failed collective, failed one-shot}
+        double h[4] = {own[0], own[1], (double)failed[0], (double)failed[1]};
+        RN_HIP(hipMemcpyAsync(d_tune, h, sizeof h, hipMemcpyHostToDevice, stream));
+        transport = 0;
+        if (int rc = all_reduce(d_tune, 4, true, "ncclAllReduce(exchange timings)", 2 /* ncclMax */)) return rc;
+        RN_HIP(hipMemcpyAsync(h, d_tune, sizeof h, hipMemcpyDeviceToHost, stream));
+        RN_HIP(hipStreamSynchronize(stream));
+        RN_CHECK(h[2] == 0.0, RN_E_COMM, "rn_exchange_autotune: the collective exchange failed on a rank (" + err + ")");
+        if (h[3] != 0.0) oneShotBroken = true;
+        transport = (h[3] == 0.0 && h[1] < h[0]) ? 1 : 0;
+        tuneInfo[0] = transport; tuneInfo[2] = h[0]; tuneInfo[3] = h[3] != 0.0 ? -1.0 : h[1]; tuneInfo[4] = own[0]; tuneInfo[5] = own[1]; tuneInfo[6] = iters; tuneInfo[7] += 1.0;
+        return RN_OK;
+    }
+    int exchange_prepare_api() override { return transportReq == RN_EXCHANGE_COLLECTIVE ? RN_OK : exchange_prepare(); }
+    int exchange_autotune_api(int iters, double *out) override {
+        RN_CHECK(iters >= 0, RN_E_ARG, "rn_exchange_autotune: iterations >= 0");
+        if (iters > 0) {
+            RN_CHECK(transportReq == RN_EXCHANGE_AUTO, RN_E_STATE, "rn_exchange_autotune: the transport was fixed by rn_set_exchange_transport");
+            if (int rc = exchange_autotune(iters)) return rc;
+        }
+        if (out) { for (int i = 0; i < 8; i++) out[i] = tuneInfo[i]; out[0] = transport; }
         return RN_OK;
     }
     // after a batch in one-shot mode: did a reader give up waiting?  (one 4-byte read-back; the stream has been synchronised)
@@ -1747,6 +1885,9 @@ struct Ctx : CtxBase {
         const bool wantOptSharded = has_comm() && cutStage > 0 && optimistic && n > 0;
         // single GPU: worth a checkpoint (3 vector copies) and a read-back per batch once the batch is long enough
         const bool wantOptLocal = !has_comm() && cutStage <= 0 && optimistic && n >= RN_OPT_LOCAL_MIN;
+        if (wantOptSharded && transportReq == RN_EXCHANGE_AUTO && !tuned && !inTune && !inReplay) {   // the exchange chooses itself, once
+            if (int rc = exchange_autotune(std::min(std::max(n, 20), 100))) return rc;
+        }
         if ((wantOptSharded || wantOptLocal) && optHold > 0 && !inReplay) optHold--;
         else if (wantOptSharded) { optBatches++; return apg_iterate_optimistic(n, primalInfs); }
         else if (wantOptLocal) { optBatches++; return apg_iterate_optimistic_local(n, primalInfs); }
@@ -2143,19 +2284,21 @@ struct Ctx : CtxBase {
     // blocking call is also the one every earlier multi-process rehearsal used.)
     double commTimeoutS = 120.0;
     struct CommJob { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; int rc = -1; void *comm = nullptr; };
+    std::shared_ptr<CommJob> commJob;     // a set-up whose helper thread has not come back
     int comm_init(int rk, int nr, const void *id, double timeoutSeconds = -1.0) override {
         RN_CHECK(nr >= 1 && rk >= 0 && rk < nr, RN_E_ARG, "rn_comm_init: bad rank");
-        RN_CHECK(comm == nullptr, RN_E_STATE, "rn_comm_init: the context already has a communicator");
-        if (id == nullptr) {               // id == NULL: bookkeeping only (tests emulate the exchange)
+        if (id == nullptr) {               // id == NULL: bookkeeping only (tests emulate the exchange); allowed at any time
             rank = rk; nranks = nr; optHold = 0;
             return RN_OK;
         }
+        RN_CHECK(comm == nullptr, RN_E_STATE, "rn_comm_init: the context already has a communicator");
         RN_CHECK(g_nccl.load(), RN_E_COMM, "rn_comm_init: cannot load librccl.so");
         RN_HIP(hipSetDevice(device));
         if (timeoutSeconds < 0) { timeoutSeconds = 120.0; if (const char *e = std::getenv("RAPIDNET_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) timeoutSeconds = v; } }
         commTimeoutS = timeoutSeconds;
         UniqueId128 u; std::memcpy(u.b, id, 128);
         auto job = std::make_shared<CommJob>();
+        commJob = job;                     // kept: rn_destroy tells a helper that is still inside RCCL that nobody waits for it any more
         const int dev = device;
         std::thread([job, u, nr, rk, dev] {
             void *c = nullptr;
@@ -2178,9 +2321,48 @@ struct Ctx : CtxBase {
             }
         }
         RN_CHECK(job->rc == 0 && job->comm, RN_E_COMM, std::string("ncclCommInitRank failed: ") + (job->rc == -2 ? "hipSetDevice on the helper thread" : (g_nccl.GetErrorString ? g_nccl.GetErrorString(job->rc) : "?")));
+        commJob.reset();
+        // The outcome must be the SAME on every rank.  A peer may have given up (its time-out) a moment before this rank's
+        // ncclCommInitRank completed: this rank then holds a communicator whose peer is gone, and its first collective would wait for
+        // ever.  So before the communicator is published every rank runs one tiny all-reduce with a BOUNDED wait (an event polled against
+        // the same time-out, with ncclCommGetAsyncError): a rank whose handshake does not finish aborts its communicator and returns
+        // RN_E_COMM like the peer that gave up.
+        {
+            void *c = job->comm;
+            bool ok = true; std::string why;
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ok = false; why = "hipEventCreate"; }
+            if (ok && hipMemsetAsync(d_tune, 0, sizeof(double), stream) != hipSuccess) { ok = false; why = "hipMemsetAsync"; }
+            if (ok) {
+                const int rc = g_nccl.AllReduce(d_tune, d_tune, 1, 8 /* ncclFloat64 */, 0 /* ncclSum */, c, stream);
+                if (rc != 0) { ok = false; why = std::string("ncclAllReduce: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "?"); }
+            }
+            if (ok && hipEventRecord(ev, stream) != hipSuccess) { ok = false; why = "hipEventRecord"; }
+            if (ok) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t q = hipEventQuery(ev);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) { ok = false; why = std::string("hipEventQuery: ") + hipGetErrorString(q); break; }
+                    int st = 0;
+                    if (g_nccl.GetAsyncError && g_nccl.GetAsyncError(c, &st) == 0 && st != 0 && st != NCCL_IN_PROGRESS) { ok = false; why = std::string("RCCL: ") + (g_nccl.GetErrorString ? g_nccl.GetErrorString(st) : "?"); break; }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) { ok = false; why = "a peer left between ncclCommInitRank and the first collective (time-out)"; break; }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+            }
+            (void)hipGetLastError();
+            if (ev) (void)hipEventDestroy(ev);
+            if (!ok) {
+                if (g_nccl.CommAbort) (void)g_nccl.CommAbort(c); else if (g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c);
+                err = "rn_comm_init: the communicator's handshake failed (" + why + "); the context has no communicator";
+                return RN_E_COMM;
+            }
+        }
         comm = job->comm;
         rank = rk; nranks = nr;
         optHold = 0;                       // every rank starts its batches aligned (the back-off counter decides which path a batch takes)
+        // the one-shot transport, set up by the library itself where the cut is already known (rn_create_sharded does it after the cut stage otherwise)
+        if (cutStage > 0 && transportReq != RN_EXCHANGE_COLLECTIVE) return exchange_prepare();
         return RN_OK;
     }
     // asynchronous errors of the communicator (a peer that died, a link that went down): asked once per batch, never inside one
@@ -2511,6 +2693,7 @@ int rn_create_sharded(const rn_dims *dims, const rn_tree *tree, const double *er
             if (!E) { zeros.assign((size_t)part.nCutParents * dims->nd, 0.0); E = zeros.data(); }
             rc = c->set_cut_moments(E, part.momP, (size_t)part.nCutParents);
         }
+        if (rc == RN_OK && id128) rc = c->exchange_prepare_api();    // AUTO / one-shot: this rank's inbox, the peers' mapped (collective; falls back by agreement)
         if (rc != RN_OK) { g_create_error = c->err; rn_destroy(ctx); ctx = nullptr; }
     }
     rn_partition_destroy(&part);
@@ -2545,6 +2728,7 @@ int rn_debug_peer_inbox_connect_local(rn_ctx **ctxs, int nranks) {
     return RN_OK;
 }
 int rn_set_exchange_transport(rn_ctx *ctx, int transport) { RN_GUARD(ctx); return ctx->impl->set_exchange_transport(transport); }
+int rn_exchange_autotune(rn_ctx *ctx, int iterations, double info[8]) { RN_GUARD(ctx); return ctx->impl->exchange_autotune_api(iterations, info); }
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_fused_walk_dual(on); }
 int rn_fbe_counters(rn_ctx *ctx, long out[4]) { RN_GUARD(ctx); return ctx->impl->fbe_counters(out); }
 int rn_guard_check(rn_ctx *ctx, long *badBytes) { RN_GUARD(ctx); return ctx->impl->guard_check(badBytes); }

@@ -92,6 +92,105 @@ def inprocess(name, world, cut, structured, precision, kw):
     print("oneshot inprocess ok: %s world %d cut %d structured %d %s, batches %s" % (name, world, cut, structured, precision, results[1][2][0]), flush=True)
 
 
+def auto_case(name, world, cut):
+    """RN_EXCHANGE_AUTO (the default of a sharded context): `world` shard contexts of one process with wired inboxes.
+    (A) nobody says anything: the first device-resident batch times both transports on the context's own iterations, the ranks agree on
+        one, and neither the iterates nor the batch counters show that it happened -- bitwise the run with the transport fixed;
+    (B) the selection: ONE rank's one-shot time is biased by +/- 10 s per iteration (rn_debug_set_knob): every rank must take the same
+        decision, and it must be the one the MAX over the ranks' times says -- collective with the slow rank, one-shot with the fast one."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.initialise(dh, ah)
+    ohist = o.apg(44)
+
+    def ranks(fixed=None, bias=None):
+        group = capi.local_group_create(world)
+        shards = []
+        for r in range(world):
+            kn = {"tune_bias_us": bias} if (bias is not None and r == 1) else None
+            s = capi.Solver(p["network"], p["tree"], p["config"], rank=r, nranks=world, cut_stage=cut, knobs=kn)
+            s.joinLocalGroup(group, r)
+            s.peerInboxCreate()
+            shards.append(s)
+        capi.peer_inbox_connect_local(shards)
+        if fixed is not None:
+            for s in shards:
+                s.setExchangeTransport(fixed)
+        return group, shards
+
+    def on_threads(shards, fn):
+        out, errs = [None] * world, []
+
+        def work(i):
+            try:
+                out[i] = fn(shards[i])
+            except Exception as e:   # noqa: BLE001
+                errs.append((i, e))
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        return out
+
+    def solve(s):
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        h = np.concatenate([s.apgIterate(20), s.apgIterate(4), s.apgIterate(20)])
+        return h, s.counters(), {nm: s.get(bid) for bid, nm, _ in VECS}, s.exchangeAutotune(0)
+
+    # (A)
+    runs = {}
+    for fixed in (None, 0):
+        group, shards = ranks(fixed)
+        runs[fixed] = on_threads(shards, solve)
+        for s in shards:
+            s.close()
+        capi.local_group_destroy(group)
+    infos = [r[3] for r in runs[None]]
+    assert all(i["tunes"] == 1 and i["candidates"] == 3 and i["iterations"] == 20 for i in infos), infos
+    assert len({i["transport"] for i in infos}) == 1 and len({(i["collective_us"], i["oneshot_us"]) for i in infos}) == 1, infos     # every rank: the same figures, the same choice
+    assert infos[0]["transport"] == (1 if infos[0]["oneshot_us"] < infos[0]["collective_us"] else 0), infos
+    assert all(i["tunes"] == 0 for i in (r[3] for r in runs[0]))
+    for a, b in zip(runs[None], runs[0]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1], (a[1], b[1])       # history and batch counters: as if the timing runs had not happened
+        for nm in a[2]:
+            assert np.array_equal(a[2][nm], b[2][nm]), nm
+        assert np.abs(a[0] - ohist).max() <= 1e-9 * np.abs(ohist).max()
+    # (B)
+    chosen = {}
+    for bias in (10_000_000, -10_000_000):
+        group, shards = ranks(None, bias)
+
+        def tune(s):
+            s.initialiseSmpcController(dh, ah)
+            s.apgReset()
+            s.apgIterate(3)                      # (a short batch first -- which tunes by itself: the explicit call below starts from a state that is not all zeros)
+            before = {nm: s.get(bid) for bid, nm, _ in VECS}
+            info = s.exchangeAutotune(16)
+            after = {nm: s.get(bid) for bid, nm, _ in VECS}
+            h = s.apgIterate(20)
+            return info, all(np.array_equal(before[k], after[k]) for k in before), h, s.counters()
+
+        res = on_threads(shards, tune)
+        assert all(r[1] for r in res)                                          # the iterates a getter sees are untouched by the tuner
+        assert len({r[0]["transport"] for r in res}) == 1, [r[0] for r in res]
+        assert len({(r[0]["collective_us"], r[0]["oneshot_us"]) for r in res}) == 1
+        assert res[0][0]["own_oneshot_us"] != res[1][0]["own_oneshot_us"]      # rank 1's own figure carries the bias, the agreed one is the MAX
+        chosen[bias] = res[0][0]["transport"]
+        assert np.abs(res[0][2] - ohist[3:23]).max() <= 1e-9 * np.abs(ohist).max()
+        assert res[0][3]["optimistic"] == 2 and res[0][3]["replayed"] == 0 and res[0][0]["tunes"] == 2, (res[0][3], res[0][0])
+        for s in shards:
+            s.close()
+        capi.local_group_destroy(group)
+    assert chosen == {10_000_000: 0, -10_000_000: 1}, chosen
+    print("oneshot auto ok: %s world %d cut %d: unbiased choice %d (collective %.1f us, one-shot %.1f us per iteration), biased %s" % (
+        name, world, cut, infos[0]["transport"], infos[0]["collective_us"], infos[0]["oneshot_us"], chosen), flush=True)
+
+
 def timeout_case():
     """a rank that never pushes: the waiting rank's batch returns RN_E_COMM after the time-out instead of hanging"""
     import time
@@ -243,6 +342,8 @@ if __name__ == "__main__":
     if mode == "inprocess":
         kw = {"penalty_x": 20.0, "penalty_xs": 5.0} if "trip" in sys.argv[5:] else {}
         inprocess(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), "structured" in sys.argv[5:], "f32" if "f32" in sys.argv[5:] else "f64", kw)
+    elif mode == "auto":
+        auto_case(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     elif mode == "timeout":
         timeout_case()
     elif mode == "latecomer":

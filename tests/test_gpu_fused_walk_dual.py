@@ -86,3 +86,35 @@ def test_the_switch_can_be_flipped_between_batches():
     for b in BUFS:
         assert np.array_equal(ref.get(b), s.get(b)), b
     ref.close(); s.close()
+
+
+def test_more_chains_than_partial_slots_take_the_two_launches(monkeypatch):
+    """k_down_chain_dual leaves one partial per workgroup (= per chain) in a buffer of 16 384 entries: a tree with more chains than
+    that must fall back to the two-launch form instead of writing past the buffer (round-5 advisor finding).  16 510 chains of a tiny
+    network, the fused form forced, under the guard (red zones around every buffer): same bits as the unfused run, no red-zone byte
+    touched, and the oracle's iterates."""
+    from oracle.oracle import Oracle
+
+    synth.CONFIGS.setdefault("manychains", (24, 3, 6, 4, 2, 4, [130, 127]))
+    p = synth.make_problem("manychains")
+    monkeypatch.setenv("RAPIDNET_GUARD", "1")
+    outs = []
+    for fused in (0, 1):
+        s = capi.Solver(p["network"], p["tree"], p["config"])
+        s.setFusedWalkDual(fused)
+        s.initialiseSmpcController(*synth.forecast_at(p["forecast"], 0))
+        s.apgReset()
+        hist = np.concatenate([s.apgIterate(20), s.apgIterate(16)])
+        outs.append((hist, {b: s.get(b) for b in BUFS}))
+        assert s.guardCheck() == 0
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for b in BUFS:
+        assert np.array_equal(outs[0][1][b], outs[1][1][b]), b
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.initialise(*synth.forecast_at(p["forecast"], 0))
+    oh = o.apg(36)
+    assert np.abs(outs[1][0] - oh).max() <= 1e-9 * np.abs(oh).max()
+    for b, nm in ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_UPD_XI, "updXi"), (capi.BUF_UPD_PSI, "updPsi")):
+        ref = o.get(nm)
+        assert np.abs(outs[1][1][b] - ref).max() <= 1e-9 * np.abs(ref).max(), nm

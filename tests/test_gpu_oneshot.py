@@ -37,6 +37,13 @@ def test_one_shot_exchange_in_process(args):
         assert "'replayed': 1" in out or "'replayed': 2" in out, out
 
 
+@pytest.mark.parametrize("args", [("medium", 2, 0), ("ragged", 3, 1)])
+def test_exchange_chooses_itself(args):
+    """RN_EXCHANGE_AUTO: both transports timed on the context's own iterations, one decision for all ranks, no trace in the iterates"""
+    out = run(("auto",) + args)
+    assert "oneshot auto ok" in out, out
+
+
 def test_one_shot_exchange_gives_up_instead_of_hanging():
     out = run(("timeout",), env_extra={"RAPIDNET_ONESHOT_TIMEOUT_MS": "300", "RAPIDNET_GROUP_TIMEOUT_S": "3"})
     assert "oneshot timeout ok" in out, out
