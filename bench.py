@@ -60,6 +60,9 @@ def parse():
                     "JSON line and the optional one-shot-exchange worker; rank 0's line is on stdout no later than this, whatever the optional parts do")
     ap.add_argument("--no-shard-ceiling", action="store_true", help="1 GPU: skip the `shard_ceiling` object (rank 0's shard of a 2 / 4 / 8-rank partition through the whole sharded path on this one GPU)")
     ap.add_argument("--no-quasi-newton", action="store_true", help="1 GPU: skip the `quasi_newton` object (global-FBE / NAMA loops, dense and structured)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="A/B runs: rn_debug_set_knob on every context of the run (dual_trips, dual_pipe, vlv_wide, slab_pipe, "
+                    "slab_frag, unscaled_walk, stream_two_per_cu, stream_split, nama_pair, ls_sequential, value_mfma); the JSON line lists them")
+    ap.add_argument("--tune-iterations", type=int, default=200, help="N > 1, second worker: iterations per candidate of rn_exchange_autotune")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="rehearsal only: with fewer GPUs than ranks the ranks share devices; RCCL refuses "
                     "that (duplicate GPU), so the exchange falls back to torch.distributed/gloo and the JSON line says so")
     return ap.parse_args()
@@ -91,7 +94,7 @@ def _pmc_medians(directory, counter):
     return {k: (statistics.median(v.values()), len(v)) for k, v in out.items()}
 
 
-def measure_traffic(args, extra_probe_args=(), launcher_env=False, limit=150.0):
+def measure_traffic(args, extra_probe_args=(), launcher_env=False, limit=150.0, precision=None):
     """HBM bytes per launch of k_stream_gemv and of the fused dual update FROM THE PMC COUNTERS OF THIS RUN, collected as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: FETCH_SIZE and WRITE_SIZE in separate passes
     (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-probe ...`, the program itself behind `--`),
@@ -116,8 +119,10 @@ def measure_traffic(args, extra_probe_args=(), launcher_env=False, limit=150.0):
         env = {k: v for k, v in env.items() if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE",
                                                                                                 "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "RAPIDNET_BENCH_FAULT"))}
     probe = ["python3", os.path.abspath(__file__), "--traffic-probe", "--workload", args.workload, "--steps", "40", "--warmup", "20"] + list(extra_probe_args)
-    if args.precision:
-        probe += ["--precision", args.precision]
+    if precision or args.precision:
+        probe += ["--precision", precision or args.precision]
+    for kv in args.knob:
+        probe += ["--knob", kv]
     med = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -155,6 +160,60 @@ def measure_traffic(args, extra_probe_args=(), launcher_env=False, limit=150.0):
                        "workload as the timed region runs them), median per dispatch, bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM) prescribes for "
                        "16-byte-per-lane streaming reads on gfx950"})
     return t, src
+
+
+def measure_mfma(args, limit=150.0):
+    """Matrix-unit use of the STRUCTURED operator mode's shared-operator products from the SQ counters of this run (SURVEY.md section 8(d):
+    "report MFMA utilisation" for the shared-operator model): one child run of this bench.py in structured mode under
+    `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES` (counters only; started before this process touches the GPU).
+    SQ_VALU_MFMA_BUSY_CYCLES sums, over the chip's 1 024 SIMDs, the cycles a SIMD's matrix pipe was busy: busy fraction = that / (1 024 x
+    launch duration x 2.4 GHz), median per launch; the durations are those of the counter-collecting run itself."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {"error": "rocprofv3 not available (or this run is itself being profiled)"}
+    tmp = tempfile.mkdtemp(prefix="rn_sq_", dir="/tmp")
+    probe = ["python3", os.path.abspath(__file__), "--traffic-probe", "--structured", "--workload", args.workload, "--steps", "40", "--warmup", "20"]
+    for kv in args.knob:
+        probe += ["--knob", kv]
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "--output-format", "csv", "-d", tmp, "-o", "sq", "--"] + probe,
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=limit)
+        if r.returncode != 0:
+            return {"error": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        busy, durs = {}, {}
+        short = lambda n: n.replace("void rn::", "").split("(")[0]
+        for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                if row.get("Counter_Name") == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    d = busy.setdefault(short(row["Kernel_Name"]), {})
+                    d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+        for path in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                durs.setdefault(short(row["Kernel_Name"]), []).append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
+    except Exception as e:   # noqa: BLE001 -- a missing profiler must not fail the benchmark
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out, tot_busy, tot_us = {}, 0.0, 0.0
+    for k, v in busy.items():
+        if not k.startswith(("k_gemm_", "k_value_mfma")) or len(v) < 4 or k not in durs:
+            continue
+        b, d_us = statistics.median(v.values()), statistics.median(durs[k])
+        floor_us = b / 1024.0 / 2400.0
+        out[k] = {"launches": len(v), "busy_cycles_per_launch": b, "launch_us": d_us, "mfma_floor_us": floor_us, "busy_frac": floor_us / d_us if d_us > 0 else None}
+        tot_busy += floor_us; tot_us += d_us
+    if not out:
+        return {"error": "no MFMA kernel in the counter files"}
+    return {"kernels": out, "busy_frac": tot_busy / tot_us if tot_us > 0 else None, "unit": "fraction of the 1 024 matrix pipes' cycles (2.4 GHz) inside the launches",
+            "how": "child run of this bench.py (--structured) under `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES`, medians per launch; "
+                   "dense peak of v_mfma_f64_16x16x4: one per 64 cycles and SIMD"}
 
 
 def spawn_ranks(args):
@@ -271,6 +330,37 @@ def _fake_worker(args, rank):
     if rank == 0:
         print(json.dumps(dict(line, complete=True)), flush=True)
     os._exit(0)
+
+
+def merge_exchange(out, alt):
+    """N > 1, rank 0's supervisor: the line of the first worker (communicator's all-reduce, RCCL defaults) and the result of the second (the context
+    chose its exchange itself, RCCL under the hint set): `value` is the better of the two, `exchange` says which it was and what each candidate took."""
+    out["alt_exchange"] = alt
+    first = {"value": out.get("value"), "ms_per_step": out.get("ms_per_step"), "exchange_us": out.get("exchange_us")}
+    ex = {"candidates": {"rccl_default": dict(first, what="ncclAllReduce on the solver's stream, RCCL's own defaults: the first worker's timed region")},
+          "chosen": "rccl_default", "value_rccl_default": out.get("value")}
+    if isinstance(alt, dict) and "error" not in alt and alt.get("value"):
+        t = alt.get("tune") or {}
+        ex["candidates"]["auto"] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"], "chosen_transport": alt.get("chosen"), "rccl_hints": alt.get("rccl_hints"),
+                                    "tune_us_per_iteration": {"collective_hinted": t.get("collective_us"), "one_shot": t.get("oneshot_us")},
+                                    "what": "second worker: RN_EXCHANGE_AUTO under the RCCL hint set; its timed region ran on the transport the tuner kept"}
+        if alt["value"] > (out.get("value") or 0.0):
+            ex["chosen"] = "auto:" + str(alt.get("chosen"))
+            out["value"], out["ms_per_step"] = alt["value"], alt["ms_per_step"]
+            if alt.get("timing_spread"):
+                out["timing_spread"] = alt["timing_spread"]
+            if alt.get("per_rank"):
+                out["per_rank"] = alt["per_rank"]
+            if isinstance(out.get("config"), dict):
+                out["config"]["ms_per_controlStep_500it"] = 500.0 * alt["ms_per_step"]
+                out["config"]["parallelism"] = str(out["config"].get("parallelism", "")).replace("1 RCCL all-reduce/iteration", "1 exchange/iteration (%s)" % ex["chosen"])
+    else:
+        ex["candidates"]["auto"] = {"error": (alt or {}).get("error", "no result") if isinstance(alt, dict) else "no result"}
+    sc = out.get("shard_ceiling_same_box")
+    if isinstance(sc, dict) and sc.get("ms_per_step") and out.get("ms_per_step"):
+        out["speedup_vs_shard_ceiling"] = sc["ms_per_step"] / out["ms_per_step"]
+    out["exchange"] = ex
+    return out
 
 
 def supervise(args):
@@ -440,6 +530,8 @@ def supervise(args):
         if decision.startswith("run"):
             limit = float(decision.split()[1])
             env = {k: v for k, v in os.environ.items() if k != "RAPIDNET_BENCH_FAULT"}
+            for hk, hv in RCCL_HINTS.items():
+                env.setdefault(hk, hv)           # (a value the caller exported wins)
             env["RAPIDNET_BENCH_STORE_PREFIX"] = "alt_exchange"      # the launcher's store is shared with step 1: keys of its own
             rc2, aline = run_worker(base + ["--alt-exchange-only"], env, '"alt_exchange"', min(limit, max(1.0, remaining() - 5.0)))
             if aline is not None:
@@ -458,8 +550,7 @@ def supervise(args):
             print("bench.py: rank 0's worker ended without a result line", file=sys.stderr, flush=True)
             os._exit(1)
         if alt is not None:
-            out = json.loads(line)
-            out["alt_exchange"] = alt
+            out = merge_exchange(json.loads(line), alt)
             with lock:
                 best[0] = json.dumps(out)
         emit()
@@ -469,6 +560,14 @@ def supervise(args):
             except OSError:
                 pass
     os._exit(0)
+
+
+# The documented RCCL hint set, tried as a candidate of its own: the per-iteration payload is 30 KB (17 cut parents x 223 doubles + 2), far
+# below the sizes RCCL's tuner is built around.  LL = the low-latency protocol (flag-in-data, no separate synchronisation), Tree = log-depth
+# instead of a ring over 8 point-to-point xGMI hops, one channel = one workgroup of the collective kernel instead of several that each carry a
+# sliver.  The library never sets NCCL_* itself; bench.py's SECOND worker -- whose communicator the auto-tuner times against the one-shot
+# exchange -- runs under them, the first (the plain headline) under RCCL's own defaults, and the line reports the better one as `value`.
+RCCL_HINTS = {"NCCL_PROTO": "LL", "NCCL_ALGO": "Tree", "NCCL_MAX_NCHANNELS": "1", "NCCL_MIN_NCHANNELS": "1"}
 
 
 def _cpu_model():
@@ -655,15 +754,28 @@ def main():
         _fake_worker(args, rank)        # test double (tests/test_bench_supervisor.py); never returns
     if args.traffic_probe:              # the run the PMC counters are collected on: iterations only
         args.no_cpu_baseline, args.dense_only, args.profile_steps, args.repeats, args.other_configs, args.no_traffic = True, True, 0, 0, "", True
-    measured_traffic, measured_source = ({}, None)
+    # PMC figures of THIS run, keyed by what they were measured on: (workload, precision) -> (traffic dict, source dict).  A figure is only
+    # ever attached to the config it was collected on (round 5 attached the fp64 traffic to the fp32 leg of the same workload).
+    head_precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
+    measured, mfma_structured = {}, None
     if world == 1 and args.gpus == 1 and not args.no_traffic and not args.structured and not args.force_shard and args.emulate_world == 0:
-        measured_traffic, measured_source = measure_traffic(args)   # child processes; nothing in this process has touched the GPU yet
+        measured[(args.workload, head_precision)] = measure_traffic(args)   # child processes; nothing in this process has touched the GPU yet
+        for spec in (args.other_configs.split(",") if not args.traffic_probe else []):      # the same workload in the other precision rides along: its own passes
+            w_, _, pr_ = spec.partition(":")
+            if w_ == args.workload and pr_ in ("f32", "f64") and pr_ != head_precision:
+                measured[(w_, pr_)] = measure_traffic(args, precision=pr_)
+        if not (args.dense_only or args.traffic_probe):
+            mfma_structured = measure_mfma(args)
     if world > 1 and os.environ.get("RAPIDNET_BENCH_TRAFFIC_JSON"):      # rank 0's worker: what its supervisor measured before starting it
         try:
             handed = json.loads(os.environ["RAPIDNET_BENCH_TRAFFIC_JSON"])
-            measured_traffic, measured_source = handed.get("traffic") or {}, handed.get("source")
+            measured[(args.workload, head_precision)] = (handed.get("traffic") or {}, handed.get("source"))
         except ValueError:
             pass
+    knobs = {}
+    for kv in args.knob:
+        k_, _, v_ = kv.partition("=")
+        knobs[k_.strip()] = int(v_)
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
@@ -775,15 +887,20 @@ def main():
             import torch
         def make_local():
             if not sharded:
-                return capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
+                return capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured, knobs=knobs)
             if world == 1:    # debug modes: rank 0's shard (or the whole tree) through the sharded code path with a one-rank communicator
-                s_ = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured)
+                s_ = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured, knobs=knobs)
                 s_.commInit(0, 1, None)
                 s_.setCutStage(cut_stage, (debug_part["momE"], debug_part["momP"]))
                 return s_
             # the real thing: partition + cut stage + children moments in ONE call of the C-ABI -- WITHOUT a communicator yet
-            return capi.Solver(problem["network"], problem["tree"], problem["config"], precision=precision, device=device, structured=structured,
-                               rank=rank, nranks=world, cut_stage=cut_stage, unique_id=None)
+            s_ = capi.Solver(problem["network"], problem["tree"], problem["config"], precision=precision, device=device, structured=structured,
+                             rank=rank, nranks=world, cut_stage=cut_stage, unique_id=None, knobs=knobs)
+            # the headline worker runs the communicator's all-reduce and NOTHING else: fixed before rn_comm_init, so the library never
+            # creates an inbox or maps a peer in this process.  The second worker (alt) leaves the default, RN_EXCHANGE_AUTO.
+            if not alt:
+                s_.setExchangeTransport(capi.EXCHANGE_COLLECTIVE)
+            return s_
 
         dh, ah = synth.forecast_at(problem["forecast"], 0)
         s = None
@@ -840,6 +957,20 @@ def main():
         beat("factor step + affine terms (%s)" % workload)
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
+        tune_info = None
+        if alt and sharded and world > 1 and not fallback_reason[0]:
+            # every rank the same sequence of gloo collectives whatever happens to it (a one-shot reader's time-out raises on every rank of the batch)
+            beat("rn_exchange_autotune (%s)" % workload, 300.0)
+            ok, err = True, ""
+            try:
+                tune_info = s.exchangeAutotune(args.tune_iterations)
+            except capi.RapidNetError as e:
+                ok, err = False, str(e)
+            all_ok, why = agree(ok, err, "rn_exchange_autotune")
+            if not all_ok:
+                s.close()
+                raise AgreedFailure("rn_exchange_autotune failed (%s)" % why)
+            s.apgReset()
         theta = [1.0, 1.0]
         n_cut = 0
         if sharded and fallback_reason[0]:
@@ -928,12 +1059,14 @@ def main():
             spread = {"regions": len(allr), "steps_per_region": steps, "ms_per_step_median": 1e3 * float(np.median(allr)) / steps,
                       "ms_per_step_min": 1e3 * allr[0] / steps, "ms_per_step_max": 1e3 * allr[-1] / steps,
                       "value_median": steps / float(np.median(allr)), "note": "region 1 is the contract's timed region (`value`); all regions max over ranks"}
-        # opt-in variant in the SAME context (same buffers: two contexts of one process differ by up to 5 % through the placement of their
-        # buffers alone): the forward walk and the dual update in one launch (rn_set_fused_walk_dual), `repeats` regions, then off again
+        # the other form of the forward walk + dual update in the SAME context (same buffers: two contexts of one process differ by up to 5 %
+        # through the placement of their buffers alone).  Since round 6 the library decides by shape (rn_set_fused_walk_dual, -1): one launch
+        # (k_down_chain_dual) on unsharded trees with at least as many chains as CUs -- this workload -- two launches otherwise.  Timed here:
+        # the two-launch form forced, `repeats` regions, then back to the default.
         fused = None
         if fused_ab and not sharded and rep:
             try:
-                s.setFusedWalkDual(1)
+                s.setFusedWalkDual(0)
                 iterate(40)
                 frep = []
                 for _ in range(len(rep)):
@@ -942,15 +1075,17 @@ def main():
                     iterate(steps)
                     barrier()
                     frep.append(time.perf_counter() - t0)
-                s.setFusedWalkDual(0)
+                s.setFusedWalkDual(-1)
                 iterate(40)
                 s.synchronize()
-                fm, um = float(np.median(frep)), float(np.median(rep))
-                fused = {"value": steps / fm, "ms_per_step": 1e3 * fm / steps, "ms_per_step_min": 1e3 * min(frep) / steps, "ms_per_step_max": 1e3 * max(frep) / steps, "regions": len(frep),
-                         "same_context_two_launches": {"ms_per_step": 1e3 * um / steps, "regions": len(rep)}, "speedup": um / fm,
-                         "what": "rn_set_fused_walk_dual(ctx, 1): k_down_chain + k_dual_stage as one launch (k_down_chain_dual, Hx kept in LDS), identical iterates, timed in "
-                                 "the headline's own context right behind its regions; opt-in -- the default keeps the dual update a kernel of its own (north_star's "
-                                 "roofline target names it)"}
+                tm, um = float(np.median(frep)), float(np.median(rep))
+                fused = {"default": "by shape: one launch (k_down_chain_dual) here", "value": steps / um, "ms_per_step": 1e3 * um / steps, "regions": len(rep),
+                         "two_launches_same_context": {"value": steps / tm, "ms_per_step": 1e3 * tm / steps, "ms_per_step_min": 1e3 * min(frep) / steps,
+                                                       "ms_per_step_max": 1e3 * max(frep) / steps, "regions": len(frep)},
+                         "speedup": tm / um,
+                         "what": "rn_set_fused_walk_dual: k_down_chain + k_dual_stage as one launch (k_down_chain_dual, Hx kept in LDS) against the two launches, identical "
+                                 "iterates, same context, interleaved with the headline's regions; the per-launch profiling pass (roofline, kernel_classes) always runs "
+                                 "the two-launch form, so the dual update's figures there are those of the kernel north_star names"}
             except Exception as e:   # noqa: BLE001 -- reported, never fatal for the headline
                 fused = {"error": "%s: %s" % (type(e).__name__, e)}
         # one whole control step (SmpcController::controlAction: state upload, affine terms, 500 iterations, u0 back)
@@ -998,7 +1133,8 @@ def main():
             # collected on this workload with exactly the kernel sources this run executes; traffic_source says which
             traffic, traffic_source = {}, {"measured_in_this_run": False, "file": None}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if measured_traffic and workload == args.workload and (not sharded or (world > 1 and rank == 0)):   # N > 1: rank 0's shard, measured by its supervisor
+            measured_traffic, measured_source = measured.get((workload, precision), ({}, None))
+            if measured_traffic and (not sharded or (world > 1 and rank == 0)):   # N > 1: rank 0's shard, measured by its supervisor
                 traffic, traffic_source = measured_traffic, measured_source
             elif os.path.exists(tpath) and workload == "barcelona493" and precision == "f64" and not sharded:
                 try:
@@ -1031,78 +1167,26 @@ def main():
                             "frac": achieved / 8000.0, "traffic": traffic.get("k_stream_gemv_bytes_per_launch"), "traffic_source": traffic_source,
                             "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": 1e6 * avg_s, "launches_per_step": 1,
                             "dual_update": dual}
+                # the kernel north_star's 60 % names, as FLAT keys (a record that keeps scalars only keeps these)
+                roofline.update({"dual_update_frac": dual["frac"], "dual_update_us": dual["avg_launch_us"], "dual_update_traffic": dual["traffic"],
+                                 "dual_update_bytes": dual_bytes, "dual_update_kernel": dual_kernel})
                 if read_ceiling:   # read-only stream vs a read-only probe; the dual update (5 read + 2 write streams) vs the copy probe
                     roofline.update({"measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling})
                     dual.update({"measured_copy_ceiling": copy_ceiling, "frac_of_measured_ceiling": dual["achieved"] / copy_ceiling})
-        # N > 1, last pass of the run (alt=True): the SAME context, the same protocol, with the one-shot exchange at the cut instead of
-        # the per-iteration ncclAllReduce (rn_set_exchange_transport(ctx, 1): peer-written packets, gathered by the crown kernels;
-        # the per-batch collectives stay with RCCL).  Never the headline `value`; a failure is reported, not fatal.
         alt_res = None
         if alt and sharded and world > 1:
+            # the second worker of a rank: this context was left on RN_EXCHANGE_AUTO and tuned before its warm-up (tune_info); everything above --
+            # warm-up, the contract's timed region, the repeats -- ran on the transport the ranks agreed on
             if fallback_reason[0]:
                 alt_res = {"error": "not run: no RCCL communicator in this run (%s)" % fallback_reason[0]}
+            elif tune_info is None or "error" in tune_info:
+                alt_res = {"error": (tune_info or {}).get("error", "rn_exchange_autotune did not run")}
             else:
-                beat("one-shot exchange: inbox set-up (%s)" % workload)
-                ok, err, handle = True, "", None
-                try:
-                    handle = s.peerInboxCreate()
-                except capi.RapidNetError as e:
-                    ok, err = False, str(e)
-                handles = [None] * world
-                dist.all_gather_object(handles, handle)
-                if ok and all(h is not None for h in handles):
-                    try:
-                        s.peerInboxConnect(handles)
-                    except capi.RapidNetError as e:
-                        ok, err = False, str(e)
-                elif ok:
-                    ok, err = False, "a peer could not create its inbox"
-                all_ok, why = agree(ok, err, "one-shot set-up")
-                if not all_ok:
-                    alt_res = {"error": "set-up failed: %s" % why}
-                else:
-                    # Every rank runs the SAME sequence of gloo collectives whatever happens to it: a reader's time-out (RN_E_COMM) raises
-                    # on the rank(s) it happened on -- since round 5 on every rank of the batch, the flag rides in the per-batch MAX
-                    # all-reduce -- and a rank that skipped a barrier its peers are in would hang the job until the supervisor's limit.
-                    def guarded(fn):
-                        try:
-                            fn()
-                            return True, ""
-                        except capi.RapidNetError as e:
-                            return False, str(e)
-
-                    def warm():
-                        s.setExchangeTransport(1)
-                        s.apgReset()
-                        for _ in range(4):
-                            iterate(20)
-                        iterate(warmup)
-                        s.synchronize()
-
-                    beat("one-shot exchange: warm-up (%s)" % workload)
-                    ok, err = guarded(warm)
-                    all_ok, why = agree(ok, err, "one-shot warm-up")
-                    dt_alt = None
-                    if all_ok:
-                        beat("one-shot exchange: timed region (%s)" % workload)
-                        dist.barrier()
-                        t0 = time.perf_counter()
-                        ok, err = guarded(lambda: (iterate(steps), s.synchronize()))
-                        dist.barrier()                      # reached by every rank, failed or not
-                        dt_alt = time.perf_counter() - t0
-                        all_ok, why = agree(ok, err, "one-shot timed region")
-                    if all_ok:
-                        dt_alt = max_over_ranks(dt_alt)
-                        alt_res = {"kind": "one-shot exchange at the cut: peer-written {payload, tag} packets gathered by the cut parents' own workgroups (rn_set_exchange_transport 1); per-batch collectives over RCCL",
-                                   "value": steps / dt_alt, "unit": "iterations/s", "ms_per_step": 1e3 * dt_alt / steps,
-                                   "same_context_rccl": {"value": steps / dt, "ms_per_step": 1e3 * dt / steps},
-                                   "speedup_vs_rccl_same_context": dt / dt_alt}
-                    else:
-                        alt_res = {"error": "timed region failed: %s" % why}
-                    try:
-                        s.setExchangeTransport(0)
-                    except capi.RapidNetError:
-                        pass
+                alt_res = {"kind": "RN_EXCHANGE_AUTO: rn_exchange_autotune timed the communicator's all-reduce and the one-shot peer-write exchange on this context's own "
+                                   "iterations (%d per candidate, max over ranks) and kept the faster; the timed region ran on it" % tune_info["iterations"],
+                           "chosen": "one-shot" if tune_info["transport"] == 1 else "collective", "tune": tune_info,
+                           "rccl_hints": {k: os.environ[k] for k in RCCL_HINTS if k in os.environ},
+                           "value": steps / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / steps, "timing_spread": spread, "per_rank": per_rank}
         batch_counters = s.counters()   # optimistic / exact batches of rn_apg_iterate, replays (0 unless a soft constraint tripped)
         res = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "spread": spread, "nodes": s.nodes, "per_rank": per_rank, "ms_per_controlStep_500it_derived": 500 * 1e3 * dt / steps, "batch_counters": batch_counters,
                "ms_per_controlStep_500it_measured": ctrl_ms, "roofline": roofline, "kernel_classes": classes,
@@ -1110,10 +1194,10 @@ def main():
         s.close()
         return res
 
-    if args.alt_exchange_only:      # the second worker of a rank (supervise): RCCL timed region, then the one-shot one, in the same context
+    if args.alt_exchange_only:      # the second worker of a rank (supervise): the context chooses its exchange itself, then the contract's timed region on it
         res = {"error": "not run"}
         try:
-            res = run_mode(False, args.steps, args.warmup, 0, repeats=0, control_step=False, fatal=False, alt=True)["alt_exchange"]
+            res = run_mode(False, args.steps, args.warmup, 0, repeats=min(args.repeats, 3), control_step=False, fatal=False, alt=True)["alt_exchange"]
         except AgreedFailure as e:
             res = {"error": "AgreedFailure: %s" % e}
         if rank == 0:
@@ -1179,12 +1263,22 @@ def main():
                                               "exchange": "torch.distributed fallback: " + fallback_reason[0] if fallback_reason[0] else "ncclAllReduce on the solver's stream"},
             "roofline": roofline, "kernel_classes": classes, "batch_counters": head["batch_counters"],
         }
+        if knobs:
+            out["knobs"] = knobs
+        if sharded and isinstance(classes.get("collective"), dict):
+            # N > 1: the per-iteration exchange between hipEvents on the solver's stream (the collective of one iteration; wire + wait for the slowest peer)
+            out["exchange_us"] = classes["collective"].get("per_step_us")
         if not args.structured and struct is not None:   # the exact shared-operator reformulation (RN_OPS_STRUCTURED), same workload, same iterates
             out["structured_mode"] = {k: struct[k] for k in ("value", "ms_per_step", "ms_per_controlStep_500it_derived",
                                                                "ms_per_controlStep_500it_measured", "roofline", "kernel_classes")}
-            out["structured_mode"]["operator_storage"] = "none: shared-operator MFMA GEMMs (rn_set_operator_mode(RN_OPS_STRUCTURED)), see DESIGN.md"
+            out["structured_mode"]["operator_storage"] = ("none: shared-operator MFMA GEMMs -- what RN_OPS_AUTO, the default of the C-ABI and of the C++ class surface, runs "
+                                                          "(the headline `value` stays on the dense blocks: the reference's storage model and the roofline this record tracks)")
             if struct.get("spread"):
                 out["structured_mode"]["timing_spread"] = struct["spread"]
+            if mfma_structured is not None:      # matrix-unit use of the shared-operator products from this run's own SQ counters
+                out["structured_mode"]["mfma"] = mfma_structured
+                if isinstance(mfma_structured.get("busy_frac"), float):
+                    out["structured_mode"]["mfma_busy_frac"] = mfma_structured["busy_frac"]
             if struct.get("fused_walk_dual"):      # rn_set_fused_walk_dual in the structured context (same-context A/B, as for the dense headline)
                 out["structured_mode"]["fused_walk_dual"] = {k: v for k, v in struct["fused_walk_dual"].items() if k != "what"}
         if struct_error:
@@ -1272,6 +1366,39 @@ def main():
                 qn = quasi_newton(problem, device)
             except Exception as e:   # noqa: BLE001
                 qn = {"error": "%s: %s" % (type(e).__name__, e)}
+    same_box = None
+    if sharded and world > 1 and not args.structured and not args.traffic_probe:
+        # the ceiling of THIS box: rank 0 runs its own shard once more with a one-rank communicator (every launch and collective of the sharded path,
+        # no wire, no peer to wait for) while the other ranks wait at the barrier below; speedup_vs_shard_ceiling = that time / the measured time
+        beat("shard ceiling on this box (rank 0)", 300.0)
+        if rank == 0:
+            sc_s = None
+            try:
+                part0 = capi.partition_tree(problem["tree"], 0, world, cut_stage)
+                sc_s = capi.Solver(problem["network"], part0["tree"], problem["config"], precision=precision, device=device, knobs=knobs)
+                sc_s.setExchangeTransport(capi.EXCHANGE_COLLECTIVE)
+                sc_s.commInit(0, 1, capi.comm_unique_id())
+                sc_s.setCutStage(cut_stage, (part0["momE"], part0["momP"]))
+                sc_s.initialiseSmpcController(dh, ah)
+                sc_s.apgReset()
+                for _ in range(4):
+                    sc_s.apgIterate(20, history=False)
+                sc_s.synchronize()
+                regs = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    sc_s.apgIterate(args.steps, history=False)
+                    sc_s.synchronize()
+                    regs.append(1e3 * (time.perf_counter() - t0) / args.steps)
+                same_box = {"world": world, "local_nodes": int(sc_s.nodes), "ms_per_step": float(np.median(regs)), "ms_per_step_min": min(regs), "ms_per_step_max": max(regs),
+                            "what": "rank 0's shard through the whole sharded path with a one-rank RCCL communicator on rank 0's own GPU, right after the headline: "
+                                    "a rank's time without the wire and without peers to wait for"}
+            except Exception as e:   # noqa: BLE001 -- reported, never fatal
+                same_box = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                if sc_s is not None:
+                    sc_s.close()
+        dist.barrier()
     beat("closing: rank 0's CPU baseline, then the last barrier", 1300.0)      # every rank the same limit (rank 0 times the CPU legs meanwhile)
     if rank == 0:
         if replay is not None:
@@ -1280,6 +1407,10 @@ def main():
             out["configs"] = entries
         if ceiling is not None:
             out["shard_ceiling"] = ceiling
+        if same_box is not None:
+            out["shard_ceiling_same_box"] = same_box
+            if same_box.get("ms_per_step"):
+                out["speedup_vs_shard_ceiling"] = same_box["ms_per_step"] / out["ms_per_step"]      # 1.0 = the exchange and the peers cost nothing
         if qn is not None:
             out["quasi_newton"] = qn
         if args.worker:

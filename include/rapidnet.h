@@ -394,8 +394,9 @@ int rn_peer_inbox_connect(rn_ctx *ctx, const void *ipcHandles /* nranks x 64 byt
 int rn_set_exchange_transport(rn_ctx *ctx, int transport);
 /* The exchange chooses itself.  iterations > 0: every rank of the communicator calls this at the same point (after the factor step and
  * the affine terms); each candidate transport runs `iterations` device-resident APG iterations of the context (after a warm-up run of
- * half as many) from the current iterates, which are restored afterwards -- iterates, iteration count and batch counters are what they
- * were; the ranks' times are combined by a MAX all-reduce, so every rank keeps the same transport.  A context whose transport is AUTO
+ * half as many) from the current iterates, which are restored afterwards -- the dual iterates (y, y+, w), the iteration count and the
+ * batch counters are what they were (the output buffers x, u, v, z, res hold the tuner's last iteration until the next batch writes
+ * them); the ranks' times are combined by a MAX all-reduce, so every rank keeps the same transport.  A context whose transport is AUTO
  * does this by itself in its first device-resident batch (min(max(n, 20), 100) iterations).  iterations == 0: report only.
  * info = {transport in use (0 / 1), candidates timed (bit 0 collective, bit 1 one-shot), microseconds per iteration with the
  * collective (max over ranks), with the one-shot exchange (max over ranks; -1: it failed on a rank; 0: not a candidate), this rank's

@@ -169,14 +169,15 @@ def auto_case(name, world, cut):
             s.initialiseSmpcController(dh, ah)
             s.apgReset()
             s.apgIterate(3)                      # (a short batch first -- which tunes by itself: the explicit call below starts from a state that is not all zeros)
-            before = {nm: s.get(bid) for bid, nm, _ in VECS}
+            state = (capi.BUF_XI, capi.BUF_PSI, capi.BUF_UPD_XI, capi.BUF_UPD_PSI, capi.BUF_ACC_XI, capi.BUF_ACC_PSI)      # the iterate state: y, y+, w
+            before = {b: s.get(b) for b in state}
             info = s.exchangeAutotune(16)
-            after = {nm: s.get(bid) for bid, nm, _ in VECS}
+            after = {b: s.get(b) for b in state}
             h = s.apgIterate(20)
             return info, all(np.array_equal(before[k], after[k]) for k in before), h, s.counters()
 
         res = on_threads(shards, tune)
-        assert all(r[1] for r in res)                                          # the iterates a getter sees are untouched by the tuner
+        assert all(r[1] for r in res)                                          # the iterate state (y, y+, w) is untouched by the tuner
         assert len({r[0]["transport"] for r in res}) == 1, [r[0] for r in res]
         assert len({(r[0]["collective_us"], r[0]["oneshot_us"]) for r in res}) == 1
         assert res[0][0]["own_oneshot_us"] != res[1][0]["own_oneshot_us"]      # rank 1's own figure carries the bias, the agreed one is the MAX

@@ -184,6 +184,38 @@ def test_soft_constraint_branch():
     assert c["optimistic"] == 1 and c["replayed"] == 1 and c["hold"] == hold - 1 and c["exact"] >= 1
 
 
+@pytest.mark.parametrize("penalty_x,penalty_xs,min_both", [(2.0, 1.0, 20), (0.5, 0.2, 30)])
+def test_both_soft_constraint_thresholds_trip_at_once(penalty_x, penalty_xs, min_both):
+    """BOTH halves of the soft-constraint prox active in the same iteration (SmpcController.cu:793-820: dist_x > gamma_x / lambda AND
+    dist_s > gamma_s / lambda).  This is the one branch where the oracle is NOT the reference's arithmetic: the reference computes the second
+    half from devVecDiffXi after the first half has overwritten it (:800, :814, :818); the oracle -- and the HIP path -- apply the prox of
+    gamma dist(., C) to each half with its own distance (oracle/apg_oracle.c:52-54).  The reference's fixtures never
+    reach it.  Here it is reached on purpose: the oracle's own per-iteration distances say in how many of the 30 iterations both thresholds
+    were exceeded together, and the HIP path -- device-resident batch (optimistic, tripped, replayed through the exact fix-up kernels) and
+    step-wise prox -- must reproduce the oracle on it."""
+    p, o, s = make_pair("medium", penalty_x=penalty_x, penalty_xs=penalty_xs)
+    lam = p["config"]["stepSize"][0]
+    probe = Oracle(p["network"], p["tree"], p["config"])
+    probe.initialise(*synth.forecast_at(p["forecast"], 0))
+    probe.apg_reset()
+    th, both = [1.0, 1.0], 0
+    for _ in range(30):
+        th = probe.apg_continue(1, th)
+        dx, ds = probe.dist()
+        both += int(dx > penalty_x / lam and ds > penalty_xs / lam)
+    assert both >= min_both, "only %d of 30 iterations exceed both thresholds at once" % both
+    hist, ohist = s.algorithmApg(30), o.apg(30)
+    compare_all(s, o, REL_TOL, "both thresholds")
+    assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
+    assert s.counters()["replayed"] == 1
+    dxs, dss = s.proxDistances()
+    dxo, dso = o.dist()
+    assert abs(dxs - dxo) <= 1e-9 * dxo and abs(dss - dso) <= 1e-9 * dso and dxo > penalty_x / lam and dso > penalty_xs / lam
+    s.proximalFunG(); o.prox()      # the step-wise entry point on the same branch
+    assert relmax(s.get(capi.BUF_DUAL_XI), o.get("dualXi")) < REL_TOL and relmax(s.get(capi.BUF_DUAL_PSI), o.get("dualPsi")) < REL_TOL
+    s.close()
+
+
 @pytest.mark.parametrize("trips,pipe", [(1, 1), (2, 1), (3, 2), (5, 2), (8, 1)])
 def test_dual_stage_launch_shapes(trips, pipe):
     """k_dual_stage with every tile / pipelining shape (the defaults pick one by problem size): vectors per thread 1 .. 8,
