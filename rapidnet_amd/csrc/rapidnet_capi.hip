@@ -1644,6 +1644,7 @@ struct Ctx : CtxBase {
     bool tuned = false, inTune = false, oneShotBroken = false;
     double tuneInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rn_exchange_autotune: {chosen, candidates, us/it collective (max over ranks), us/it one-shot (max), own collective, own one-shot, iterations, tunes run}
     double *d_tune = nullptr;    // 8 doubles: the ranks' agreement on the timings (allocated with the context: a control step never allocates)
+    T *d_ckView = nullptr;       // the tuner's copy of the accelerated dual a getter would show (allocated when the one-shot transport becomes a candidate)
     // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual): the optimistic batches ask for
     // it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened.
     // Default BY SHAPE (round 6): on where one workgroup per chain fills the chip -- at least as many chains as CUs, unsharded:
@@ -1787,6 +1788,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipStreamSynchronize(stream));
         if (flag != 0.0) { peerReady = false; oneShotBroken = true; }      // somebody could not: nobody uses the transport (err keeps this rank's reason, if it was this rank)
         else if (transportReq == RN_EXCHANGE_ONESHOT) transport = 1;
+        if (peerReady && transportReq == RN_EXCHANGE_AUTO && !d_ckView) { if (int rc3 = dalloc(&d_ckView, (size_t)ntot())) return rc3; }   // the tuner will run: its buffer now, not inside a control step
         return RN_OK;
     }
     // Times the candidates on THIS context's own iterations and keeps the faster: `iters` device-resident iterations per candidate (after
@@ -1808,6 +1810,13 @@ struct Ctx : CtxBase {
         // what the timing runs must leave as they found it (the iterates themselves are in the batch's own checkpoint)
         const IterSave sv = save_iterates();
         const long kOpt = optBatches, kExact = exactBatches, kFall = fallbacks; const int kHold = optHold;
+        // ... and what RN_BUF_ACC_* shows: after a batch that is w_t, in the buffer the timing runs are about to reuse (the checkpoint holds w_{t+1}, the next input)
+        T *const view = p_acc_view;
+        const size_t vbytes = (size_t)ntot() * sizeof(T);
+        if (view != sv.acc) {
+            if (!d_ckView) { if (int rc = dalloc(&d_ckView, (size_t)ntot())) return rc; }
+            RN_HIP(hipMemcpyAsync(d_ckView, view, vbytes, hipMemcpyDeviceToDevice, stream));
+        }
         double own[2] = {0, 0};
         int failed[2] = {0, 0};
         inTune = true;
@@ -1829,6 +1838,7 @@ struct Ctx : CtxBase {
         }
         inTune = false;
         optBatches = kOpt; exactBatches = kExact; fallbacks = kFall; optHold = kHold;
+        if (view != sv.acc) { RN_HIP(hipMemcpyAsync(view, d_ckView, vbytes, hipMemcpyDeviceToDevice, stream)); p_acc_view = view; }
         if (knob[RN_KNOB_TUNE_BIAS_US] != -1) own[1] += (double)knob[RN_KNOB_TUNE_BIAS_US];      // test of the selection: this rank's one-shot time, biased
         // every rank the same figures: MAX over the ranks of {time collective, time one-shot, failed collective, failed one-shot}
         double h[4] = {own[0], own[1], (double)failed[0], (double)failed[1]};

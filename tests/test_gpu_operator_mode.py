@@ -1,0 +1,125 @@
+"""Operator storage on the boundary (round 6): RN_OPS_AUTO -- the default of the C-ABI and of the C++ class surface -- runs the exact
+structured form (no per-node block is ever stored) for as long as every block is the factor step's own, and switches to dense storage
+the moment a caller hands in a block of its own (rn_set_operator: the counterpart of writing through the reference's getMatPhi() /
+getPtrMatPhi()[node] device pointers, Engine.cuh:170-230).  Checked against the CPU oracle, whose per-node blocks (Phi, D, Psi, Ftil:
+the arrays solveStep multiplies with at SmpcController.cu:617-638) can be overwritten the same way."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from rapidnet_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-9
+VECS = ((capi.BUF_X, "x"), (capi.BUF_U, "u"), (capi.BUF_V, "v"), (capi.BUF_UPD_XI, "updXi"), (capi.BUF_UPD_PSI, "updPsi"), (capi.BUF_DUAL_XI, "dualXi"),
+        (capi.BUF_RES_PSI, "resPsi"))
+OPS = ((capi.OP_PHI, "Phi"), (capi.OP_D, "D"), (capi.OP_PSI, "Psi"), (capi.OP_F, "Ftil"))
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    assert a.shape == b.shape and np.isfinite(a).all()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def solver(p, mode, precision="f64"):
+    s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode=mode, precision=precision)
+    s.initialiseSmpcController(*synth.forecast_at(p["forecast"], 0))
+    return s
+
+
+@pytest.mark.parametrize("name", ["medium", "ragged", "barcelona31"])
+def test_auto_is_the_structured_form_until_a_block_is_handed_in(name):
+    p = synth.make_problem(name)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.initialise(*synth.forecast_at(p["forecast"], 0))
+    a, d = solver(p, "auto"), solver(p, "dense")
+    assert a.operatorMode() == ("auto", "structured") and d.operatorMode() == ("dense", "dense")
+    ha, hd, ho = a.algorithmApg(30), d.algorithmApg(30), o.apg(30)
+    for bid, nm in VECS:
+        assert relmax(a.get(bid), o.get(nm)) < REL_TOL and relmax(d.get(bid), o.get(nm)) < REL_TOL, nm
+    assert np.abs(ha - ho).max() <= REL_TOL * np.abs(ho).max() and np.abs(hd - ho).max() <= REL_TOL * np.abs(ho).max()
+    # the factor step's own block handed back in: dense storage from here on, and the very bits of a context that was dense from the start
+    node = a.nodes // 2
+    a.setOperator(capi.OP_PSI, node, a.getOperator(capi.OP_PSI, node))
+    assert a.operatorMode() == ("auto", "dense")
+    h2a, h2d = a.algorithmApg(30), d.algorithmApg(30)
+    assert np.array_equal(h2a, h2d)
+    for bid, _ in VECS:
+        assert np.array_equal(a.get(bid), d.get(bid))
+    a.close(); d.close()
+
+
+@pytest.mark.parametrize("name,precision,tol", [("medium", "f64", REL_TOL), ("small", "f64", REL_TOL), ("medium", "f32", 2e-4)])
+def test_blocks_of_the_callers_own_against_the_oracle(name, precision, tol):
+    """every kind of per-node block (Phi, D, Psi, Ftil) overwritten on a few nodes -- crown, chain, leaf -- in the oracle and, through
+    rn_set_operator, in an auto context and a dense one: same iterates as the oracle, and not those of the unmodified problem"""
+    p = synth.make_problem(name)
+    o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
+    o.initialise(*synth.forecast_at(p["forecast"], 0))
+    base = solver(p, "auto", precision)
+    hbase = base.algorithmApg(25)
+    a, d = solver(p, "auto", precision), solver(p, "dense", precision)
+    nx, nu, nv, n = o.nx, o.nu, o.nv, o.nodes
+    rng = np.random.default_rng(5)
+    dims = {"Phi": nv * 2 * nx, "D": nv * 2 * nx, "Psi": nv * nu, "Ftil": nv * nu}
+    for k, (op, oname) in enumerate(OPS):
+        for node in sorted({0, 1 + k, n // 2 + k, n - 1 - k}):
+            blocks = o.buf(oname).reshape(n, dims[oname])          # a view: written through
+            mine = np.array(blocks[node], dtype=np.float64) * (1.0 + 0.3 * rng.standard_normal(dims[oname]))
+            blocks[node] = mine
+            mine = np.array(blocks[node], dtype=np.float64)        # (fp32 oracle: what it really holds)
+            for s in (a, d):
+                s.setOperator(op, node, mine)
+                assert relmax(s.getOperator(op, node), mine) < (1e-15 if precision == "f64" else 1e-7)
+    assert a.operatorMode() == ("auto", "dense")
+    ha, hd, ho = a.algorithmApg(25), d.algorithmApg(25), o.apg(25)
+    for bid, nm in VECS:
+        assert relmax(a.get(bid), o.get(nm)) < tol and relmax(d.get(bid), o.get(nm)) < tol, nm
+    assert np.abs(ha - ho).max() <= tol * np.abs(ho).max() and np.array_equal(ha, hd)
+    assert np.abs(ha - hbase).max() > 1e-6 * np.abs(hbase).max()      # the blocks matter
+    # a new factor step recomputes every block: back to the unmodified problem's iterates (and an auto context stays dense: it was told once)
+    a.factorStep()
+    assert np.abs(a.algorithmApg(25) - hbase).max() <= (1e-9 if precision == "f64" else 2e-4) * np.abs(hbase).max()
+    for s in (base, a, d):
+        s.close()
+
+
+def test_what_cannot_be_handed_in():
+    p = synth.make_problem("small")
+    st = solver(p, "structured")
+    blk = st.getOperator(capi.OP_PHI, 1)
+    with pytest.raises(capi.RapidNetError, match="RN_OPS_STRUCTURED"):
+        st.setOperator(capi.OP_PHI, 1, blk)
+    a = solver(p, "auto")
+    with pytest.raises(capi.RapidNetError, match="shared matrices"):
+        a.setOperator(capi.OP_OMEGA, 1, a.getOperator(capi.OP_OMEGA, 1))
+    with pytest.raises(capi.RapidNetError, match="size"):
+        a.setOperator(capi.OP_PHI, 1, blk[:-1])
+    assert a.operatorMode() == ("auto", "structured")          # a refused call changes nothing
+    fresh = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="auto")
+    with pytest.raises(capi.RapidNetError, match="before rn_factor_step"):
+        fresh.setOperator(capi.OP_PHI, 1, blk)
+    for s in (st, a, fresh):
+        s.close()
+
+
+@pytest.mark.parametrize("alg", ["globalFbeAlgorithm", "namaAlgorithm"])
+def test_quasi_newton_loops_after_the_switch_to_dense(alg):
+    """an auto context running global FBE / NAMA is handed a block: the loops carry on in dense storage (NAMA with its paired Hessian sweep,
+    whose buffers only exist in dense mode) and give the iterates of a context that was dense from the start"""
+    p = synth.make_problem("medium")
+    runs = []
+    for mode in ("auto", "dense"):
+        s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode=mode)
+        s.setAlgorithm(alg, 5)
+        s.initialiseSmpcController(*synth.forecast_at(p["forecast"], 0))
+        node = s.nodes // 3
+        s.setOperator(capi.OP_D, node, 1.2 * s.getOperator(capi.OP_D, node))
+        run = s.algorithmGlobalFbe if alg == "globalFbeAlgorithm" else s.algorithmNama
+        h, v, t = run(8)
+        runs.append((h, v, t, s.get(capi.BUF_X), s.fbeCounters()))
+        s.close()
+    assert np.array_equal(runs[0][2], runs[1][2]) and np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][3], runs[1][3])
+    if alg == "namaAlgorithm":
+        assert runs[0][4]["sweep_pairs"] == runs[1][4]["sweep_pairs"] > 0

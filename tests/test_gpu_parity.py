@@ -205,14 +205,24 @@ def test_both_soft_constraint_thresholds_trip_at_once(penalty_x, penalty_xs, min
         both += int(dx > penalty_x / lam and ds > penalty_xs / lam)
     assert both >= min_both, "only %d of 30 iterations exceed both thresholds at once" % both
     hist, ohist = s.algorithmApg(30), o.apg(30)
-    compare_all(s, o, REL_TOL, "both thresholds")
+    # xi and psi are the two halves of ONE dual vector (and of its residual): the error of a half is measured against the whole vector's scale -- with
+    # penalties this small the input bounds are never active, psi stays at rounding noise (1e-21) and a norm of its own would compare noise with noise
+    scale = {}
+    for fam, names in (("y", ("xi", "psi", "accXi", "accPsi", "updXi", "updPsi")), ("z", ("dualXi", "dualPsi", "primalXi", "primalPsi", "resXi", "resPsi"))):
+        m = max(float(np.abs(o.get(nm)).max()) for nm in names)
+        scale.update({nm: m for nm in names})
+    for bid, nm in PAIRS:
+        ref = o.get(nm)
+        err = float(np.abs(s.get(bid) - ref).max())
+        assert err <= REL_TOL * max(float(np.abs(ref).max()), scale.get(nm, 0.0)), (nm, err, float(np.abs(ref).max()), scale.get(nm))
     assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
     assert s.counters()["replayed"] == 1
     dxs, dss = s.proxDistances()
     dxo, dso = o.dist()
     assert abs(dxs - dxo) <= 1e-9 * dxo and abs(dss - dso) <= 1e-9 * dso and dxo > penalty_x / lam and dso > penalty_xs / lam
     s.proximalFunG(); o.prox()      # the step-wise entry point on the same branch
-    assert relmax(s.get(capi.BUF_DUAL_XI), o.get("dualXi")) < REL_TOL and relmax(s.get(capi.BUF_DUAL_PSI), o.get("dualPsi")) < REL_TOL
+    zs = max(float(np.abs(o.get("dualXi")).max()), float(np.abs(o.get("dualPsi")).max()))
+    assert np.abs(s.get(capi.BUF_DUAL_XI) - o.get("dualXi")).max() <= REL_TOL * zs and np.abs(s.get(capi.BUF_DUAL_PSI) - o.get("dualPsi")).max() <= REL_TOL * zs
     s.close()
 
 
