@@ -269,11 +269,6 @@ int rn_get_kernel_info(rn_ctx *ctx, int info[8]);
  * grid-stride read-only GB/s and copy GB/s (read + written bytes), best of `reps` passes over `bytes`.
  * bench.py reports them beside the 8 TB/s spec peak as the practical denominator. */
 int rn_measure_hbm(rn_ctx *ctx, size_t bytes, int reps, double *readGBs, double *copyGBs);
-/* read-only probes in the solver's access shapes (tools/probe_hbm.py).  shape 0: n workgroups of 256 threads, each
- * streaming its own contiguous pieceBytes ("one node"; chunks start strideBytes apart).  shape 1: n persistent workgroups
- * in lockstep -- in every step workgroup w reads piece w of a contiguous n*pieceBytes window (pieceBytes <= 8192);
- * strideBytes = total bytes to read.  `unroll` (1, 2, 4, 8) = steps in flight per thread. */
-int rn_measure_hbm_shape(rn_ctx *ctx, int shape, size_t pieceBytes, size_t strideBytes, int n, int unroll, int reps, double *readGBs);
 /* the context's stream as a hipStream_t (void* to keep HIP types out of this header) */
 void *rn_stream(rn_ctx *ctx);
 
@@ -305,11 +300,7 @@ int rn_set_cut_stage(rn_ctx *ctx, int stage);
  * Single-GPU contexts use the same switch: with 1 (default) a batch of >= 16 iterations runs the prox as a pure projection,
  * the bookkeeping of iteration t (history entry, distance check) rides in a launch of iteration t+1 instead of a decision
  * launch of its own, and the batch is replayed from a checkpoint through the exact path if a distance ever exceeded its
- * threshold; with 0 every iteration decides before the next one starts.  Results are identical.
- *   2 (opt-in): mode 1, and between the iterations of a batch the accelerated dual w (SmpcController.cu:535-557) is not stored:
- *     the sweep and the dual update of the next iteration form it from the two dual iterates on the fly with the roundings a
- *     stored w would have (bitwise the iterates of mode 1; the last iteration of a batch stores it, so every getter sees what it
- *     always saw).  One write stream less in the fused dual update, one more small read in the sweep. */
+ * threshold; with 0 every iteration decides before the next one starts.  Results are identical. */
 int rn_set_exchange_mode(rn_ctx *ctx, int mode);
 /* static tree data a shard cannot derive from its local children: for every cut parent i (stage-1 nodes of the cut, in
  * stage order) E_i = sum over ALL children c of p_c * errorDemand_c (nd reals) and P_i = sum_c p_c.  They replace the

@@ -36,7 +36,7 @@ SYMBOLS = [
     "rn_device_pointer", "rn_profile_enable", "rn_profile_reset", "rn_profile_read", "rn_algorithmic_bytes", "rn_stream",
     "rn_comm_unique_id", "rn_comm_init", "rn_comm_init_timeout", "rn_comm_check", "rn_comm_library", "rn_set_cut_stage", "rn_get_history_parts", "rn_get_counters", "rn_debug_sweep_phase",
     "rn_debug_cut_buffer", "rn_set_cut_children_moments", "rn_set_operator_mode", "rn_get_operator_mode", "rn_set_operator", "rn_set_warm_start", "rn_set_exchange_mode",
-    "rn_measure_hbm", "rn_measure_hbm_shape", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
+    "rn_measure_hbm", "rn_set_algorithm", "rn_fbe_reset", "rn_algorithm_fbe_nama", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe",
     "rn_update_fixed_point_residual_nama", "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs", "rn_compute_value_fbe",
     "rn_line_search_lbfgs_update", "rn_line_search_ame_lbfgs_update", "rn_lbfgs_state", "rn_lbfgs_column",
     "rn_get_range", "rn_set_range", "rn_get_kernel_info", "rn_default_cut_stage", "rn_partition_create", "rn_partition_destroy", "rn_create_sharded", "rn_shard_info", "rn_shard_global_nodes",
@@ -180,7 +180,6 @@ def load():
     lib.rn_debug_sweep_phase.argtypes = [vp, ip]
     lib.rn_debug_cut_buffer.argtypes = [vp, ip, dp, C.c_size_t]
     lib.rn_measure_hbm.argtypes = [vp, C.c_size_t, ip, dp, dp]
-    lib.rn_measure_hbm_shape.argtypes = [vp, ip, C.c_size_t, C.c_size_t, ip, ip, ip, dp]
     lib.rn_set_algorithm.argtypes = [vp, ip, ip]
     for f in ("rn_fbe_reset", "rn_compute_hessian_oracle", "rn_compute_gradient_fbe", "rn_update_fixed_point_residual_nama",
               "rn_compute_lbfgs_direction", "rn_update_lbfgs_buffer", "rn_two_loop_recursion_lbfgs"):
@@ -363,8 +362,7 @@ class Solver:
         return u0
 
     def setExchangeMode(self, optimistic=True):
-        """False / 0: exact, True / 1: optimistic batches (default), 2: optimistic batches that keep the accelerated dual out of
-        memory between their iterations (include/rapidnet.h, rn_set_exchange_mode)."""
+        """False / 0: exact, True / 1: optimistic batches (default) (include/rapidnet.h, rn_set_exchange_mode)."""
         self._check(self.lib.rn_set_exchange_mode(self.h, int(optimistic)))
 
     def setWarmStart(self, on=True):
@@ -594,13 +592,6 @@ class Solver:
         r, c = C.c_double(0), C.c_double(0)
         self._check(self.lib.rn_measure_hbm(self.h, int(nbytes), int(reps), C.addressof(r), C.addressof(c)))
         return r.value, c.value
-
-    def measureHbmShape(self, shape, piece_bytes, n, unroll=4, reps=3, stride_or_total=None):
-        """read-only GB/s of a probe in one of the solver's access shapes (0: chunk per workgroup, 1: lockstep pieces)."""
-        r = C.c_double(0)
-        self._check(self.lib.rn_measure_hbm_shape(self.h, int(shape), int(piece_bytes), int(stride_or_total or piece_bytes), int(n),
-                                                  int(unroll), int(reps), C.addressof(r)))
-        return r.value
 
     def devicePointer(self, buffer_id):
         """(raw device address, element count, 'f64' | 'f32') of a buffer kept in the reference's node-major layout (X, U, V, UHAT, E,

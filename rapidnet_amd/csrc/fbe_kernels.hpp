@@ -8,7 +8,9 @@
 #ifndef RAPIDNET_FBE_KERNELS_HPP_
 #define RAPIDNET_FBE_KERNELS_HPP_
 
-#include "kernels.hpp"
+#include "common.hpp"
+#include "k_dual.hpp"
+#include "k_slab.hpp"
 
 namespace rn {
 
@@ -73,6 +75,7 @@ __global__ void __launch_bounds__(ELT_THREADS) k_dots(DotArgs<T> g) {
     dots_block_reduce(acc, g.partials);
 }
 // second stage: out[j] = sum over blocks of partials[b][j], fixed order
+template <int PLAIN = 0>   // (a template so that one translation unit owns its code: instantiations/*.inc)
 __global__ void __launch_bounds__(ELT_THREADS) k_dots_finish(const double *partials, int nblocks, int cnt, double *out) {
     __shared__ double sh[ELT_THREADS];
     for (int j = 0; j < cnt; j++) {
@@ -710,6 +713,7 @@ __global__ void __launch_bounds__(VALUE_THREADS) k_ls_value(const T *u, const T 
 }
 // the fold of both partial arrays: workgroup j folds one (candidate, quantity) column in k_dots_finish's order
 // out[candidate][LS_SCAL] = {<w, res>, <res, res>, dist^2 box, dist^2 safety, quad, lin}
+template <int PLAIN = 0>   // (a template so that one translation unit owns its code: instantiations/*.inc)
 __global__ void __launch_bounds__(ELT_THREADS) k_ls_finish(const double *evalPartials, int nbEval, const double *valPartials, int nbVal, double *out) {
     __shared__ double sh[ELT_THREADS];
     const int c = blockIdx.x / LS_SCAL, q = blockIdx.x % LS_SCAL;
@@ -849,6 +853,7 @@ __global__ void __launch_bounds__(64 * VM_WAVES) k_value_mfma(const T *u, const 
 
 // updatePrimalInfeasibity inside the loops: fold k_absmax's partials (first-index ties, as the host fold of rn_update_primal_infeasibility)
 // into out[0..4) = (v_xi, -v_xi, v_psi, -v_psi): the form a MAX all-reduce over the ranks can combine (largest magnitude and its sign)
+template <int PLAIN = 0>   // (a template so that one translation unit owns its code: instantiations/*.inc)
 __global__ void __launch_bounds__(ELT_THREADS) k_inf_fold(const Partial *partials, int nblocks, double *out) {
     double tx2 = 0, ts2 = 0;
     Partial p;

@@ -23,8 +23,22 @@
 
 #include "../../include/rapidnet.h"
 #include "../../include/rapidnet_debug.h"
+#include "kernels.hpp"
 #include "fbe_kernels.hpp"
 #include "partition.hpp"
+
+// Every kernel this file launches is compiled in ONE of the units k_stream.hip ... k_fbe.hip; here the instantiations are only declared.
+// (RN_NO_EXTERN_TEMPLATES: the one-unit build tools/gen_instantiations.py uses to find out what is launched.)
+#ifndef RN_NO_EXTERN_TEMPLATES
+#define RN_LINKAGE extern
+#include "instantiations/stream.inc"
+#include "instantiations/walks.inc"
+#include "instantiations/slab.inc"
+#include "instantiations/dual.inc"
+#include "instantiations/misc.inc"
+#include "instantiations/fbe.inc"
+#undef RN_LINKAGE
+#endif
 
 #ifndef RN_FIXUP_BLOCKS
 #define RN_FIXUP_BLOCKS 64
@@ -168,7 +182,6 @@ struct CtxBase {
     virtual int set_cut_moments(const double *, const double *, size_t) = 0;
     virtual int cut_buffer(int, double *, size_t) = 0;
     virtual int measure_hbm(size_t, int, double *, double *) = 0;
-    virtual int measure_hbm_shape(int, size_t, size_t, int, int, int, double *) = 0;
     // global FBE / NAMA
     virtual int set_algorithm(int, int) = 0;
     virtual int fbe_reset() = 0;
@@ -373,7 +386,6 @@ struct Ctx : CtxBase {
     bool moments_set = false;
     // logical views (see DESIGN.md "iterate buffers")
     T *p_xi = nullptr, *p_upd = nullptr, *p_acc = nullptr, *p_acc_other = nullptr, *p_acc_view = nullptr;
-    bool lazyIn = false;   // the launches being enqueued derive the accelerated dual from (p_upd, p_xi) instead of reading p_acc
     bool acc_ready = false;
     IterState *d_state = nullptr;
     Partial *d_partials = nullptr, *d_partials2 = nullptr;   // main pass / fix-up pass
@@ -577,7 +589,6 @@ struct Ctx : CtxBase {
         a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B; a.structured = structured; a.ab = d_ab;
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
         a.w = p_acc;
-        if (lazyIn) { a.wy1 = p_upd; a.wy0 = p_xi; a.wLn = (T)h_lam[h_it]; }   // w_t is not in memory: derived from y_t, y_{t-1}
         a.my = d_my; a.my2 = d_my2; a.splitFirst = (splitFirst >= 0 && !structured) ? splitFirst : d.nodes; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
         a.x = d_x; a.u = d_u; a.hx = d_hx;
         a.distTail = (carryTail && a.cutSums) ? d_cut + cut_tail_offset() : nullptr;
@@ -881,11 +892,8 @@ struct Ctx : CtxBase {
         // k_stream_gemv, one launch = the whole tree: A_i (2nv x ny, unpadded) read once + y_i read + m1,m2,a_i written
         const double s = sizeof(T), n = d.nodes;
         if (bwd) *bwd = structured ? 0.0 : n * ((double)2 * d.nv * ny + ny + 2.0 * d.nv + d.nx) * s;
-        // fused dual update: Hx, w, y+prev read, y+, w_next written (+ the two scaled-bound streams unless they are regenerated);
-        // inner iterations of a device-resident batch (k_dual_stage LAZY): Hx, y_t, y_{t-1} read, y_{t+1} written -- the count for
-        // the batches bench.py times (the first and the last launch of a batch move the same or more: never over-counted)
-        const bool lazyBatches = lazy_w();
-        if (dual) *dual = ((RN_DUAL_REGEN ? 5.0 : 7.0) - (lazyBatches ? 1.0 : 0.0)) * (double)ntot() * s;
+        // fused dual update: Hx, w, y+prev read, y+, w_next written (+ the two scaled-bound streams unless they are regenerated)
+        if (dual) *dual = (RN_DUAL_REGEN ? 5.0 : 7.0) * (double)ntot() * s;
         return RN_OK;
     }
     int synchronize() override { RN_HIP(hipSetDevice(device)); RN_HIP(hipStreamSynchronize(stream)); return RN_OK; }
@@ -969,7 +977,7 @@ struct Ctx : CtxBase {
         const int grid = d.nodes + (d.nodes - a.splitFirst);      // two workgroups for every block of the split round
         const StreamRhs2<T> none{nullptr, nullptr, nullptr};
         if (second) {
-            RN_CHECK(a.splitFirst >= d.nodes && a.wy1 == nullptr && 2 * lds <= 64 * 1024, RN_E_STATE, "k_stream_gemv with two right-hand sides: unsplit launches with w in memory only");
+            RN_CHECK(a.splitFirst >= d.nodes && 2 * lds <= 64 * 1024, RN_E_STATE, "k_stream_gemv with two right-hand sides: unsplit launches only");
             switch (NL) {
                 case 1: hipLaunchKernelGGL((k_stream_gemv<T, 1, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
                 case 2: hipLaunchKernelGGL((k_stream_gemv<T, 2, false, 2>), dim3(grid), dim3(STREAM_THREADS), 2 * lds, stream, a, G, node0, sp, *second); break;
@@ -1296,7 +1304,7 @@ struct Ctx : CtxBase {
         {
             // inner iterations of an optimistic batch whose dual update is the stage-tiled kernel reading w: the walk leaves the primal values and
             // the dual update scales them (k_down_chain UNSC / k_dual_stage SCALE: the walk requests no preconditioner entries; bitwise the same Hx)
-            const bool unsc = allowPending && !a.writePrimal && phase == 0 && !hessianInput && foldCrown && dualU != 0 && !lazy_w() && a.hx == d_hx && unscaled_on();
+            const bool unsc = allowPending && !a.writePrimal && phase == 0 && !hessianInput && foldCrown && dualU != 0 && a.hx == d_hx && unscaled_on();
             if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true, RN_DOWN_PF_UNSC>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
             else hipLaunchKernelGGL((k_down_chain<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         }
@@ -1363,9 +1371,7 @@ struct Ctx : CtxBase {
     }
     // main pass of the fused dual update (prox as a pure projection, residual, dual update, arg-max partials, next
     // extrapolation); `flat` forces the grid-stride kernel (eltBlocks partials), which the exact multi-GPU path folds
-    // lazy (k_dual_stage only; see dual_slot_use): 0 = w read, w_next stored; 1 = w derived, w_next not stored; 2 = w derived,
-    // w_t and w_next stored (always the materialising last iteration of a batch); 3 = w read, w_next not stored
-    void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false, int lazy = 0) {
+    void launch_dual_main(const DualArgs<T> &a, bool materialize, bool flat = false) {
         if (flat || dualU == 0) {
             if (hxUnscaled) hx_scale_now();
             if (materialize) hipLaunchKernelGGL((k_dual_fused<T, true, false>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
@@ -1376,38 +1382,23 @@ struct Ctx : CtxBase {
         mainPartials = dualBlocks;
         DualStageShape g = dshape;
         g.lnNext = h_lam[h_it + 1];   // ensure_tables(h_it + n) has run: the table covers every iteration of the batch
-        if (hxUnscaled && lazy == 0 && !materialize) {   // unscaled walk: Hx = sqrt(p_i) d_k * (primal value) is formed here
-            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
-            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, 0, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+        if (hxUnscaled && !materialize) {   // unscaled walk: Hx = sqrt(p_i) d_k * (primal value) is formed here
+            if (dualU == 1) hipLaunchKernelGGL((k_dual_stage<T, false, 1, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
+            else hipLaunchKernelGGL((k_dual_stage<T, false, 2, true>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g);
             hxUnscaled = false;
             return;
         }
         if (hxUnscaled) hx_scale_now();
-#define RN_LAUNCH_DSTAGE(MAT, PIPE, LAZY) hipLaunchKernelGGL((k_dual_stage<T, MAT, PIPE, LAZY>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g)
-#define RN_LAUNCH_DSTAGE_P(PIPE)                                                                                          \
-        switch (lazy) {                                                                                                \
-            case 1: RN_LAUNCH_DSTAGE(false, PIPE, 1); break;   /* inner iteration of a lazy batch */                      \
-            case 3: RN_LAUNCH_DSTAGE(false, PIPE, 3); break;   /* its first iteration */                                  \
-            case 2: RN_LAUNCH_DSTAGE(true, PIPE, 2); break;    /* its last iteration */                                   \
-            default: if (materialize) RN_LAUNCH_DSTAGE(true, PIPE, 0); else RN_LAUNCH_DSTAGE(false, PIPE, 0);                \
-        }
-        if (dualU == 1) { RN_LAUNCH_DSTAGE_P(1) } else { RN_LAUNCH_DSTAGE_P(2) }
-#undef RN_LAUNCH_DSTAGE_P
+#define RN_LAUNCH_DSTAGE(MAT, PIPE) hipLaunchKernelGGL((k_dual_stage<T, MAT, PIPE>), dim3(dualBlocks), dim3(ELT_THREADS), 0, stream, a, g)
+        if (dualU == 1) { if (materialize) RN_LAUNCH_DSTAGE(true, 1); else RN_LAUNCH_DSTAGE(false, 1); }
+        else { if (materialize) RN_LAUNCH_DSTAGE(true, 2); else RN_LAUNCH_DSTAGE(false, 2); }
 #undef RN_LAUNCH_DSTAGE
-    }
-    // exchange mode 2 (opt-in): inner iterations of a device-resident batch
-    // do not store the accelerated dual (k_dual_stage LAZY); possible whenever the stage-tiled kernel is the batch's dual update.
-    // Bitwise the iterates of mode 1.  Measured: the dual update gets 2 us (wide fp32 network: 38 us)
-    // shorter, the streaming kernel -- which then reads two dual vectors in its prologue -- as much longer: not the default.
-    bool lazy_w() const {
-        return dualU != 0 && optimistic == 2;
     }
     int main_partials() const { return mainPartials; }
     DualArgs<T> dual_args() const {
         DualArgs<T> a{};
         a.hx = d_hx; a.w = p_acc; a.yprev = p_upd; a.lo = d_lo; a.hi = d_hi;
         a.ynew = p_xi; a.wnext = p_acc_other; a.z = d_z; a.res = d_res;
-        if (lazyIn) { a.w = p_xi; a.lnCur = (T)h_lam[h_it]; a.wview = p_acc; }   // w_t derived from y_t (yprev) and y_{t-1} (p_xi)
         a.n = ntot(); a.nx = d.nx; a.ny = ny;
         a.lambda = (T)stepSize; a.invLambda = (T)(1.0 / stepSize);
         a.lamNext = d_lam; a.thrX = penX / stepSize; a.thrS = penXs / stepSize;
@@ -1459,7 +1450,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
-        poisoned = false; lazyIn = false; carryTail = false; pendingFin = false; hxUnscaled = false;
+        poisoned = false; carryTail = false; pendingFin = false; hxUnscaled = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
@@ -1487,25 +1478,19 @@ struct Ctx : CtxBase {
         if (int rc = batch_open(d_cut + tail)) return fail_batch(rc);  // checkpoint of (y, y+, w), the payload's dist^2 tail and the verdict flag cleared: one launch
         const IterSave saved = save_iterates();
         carryTail = true; inBatch = true;
-        const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
-            // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
-            lazyIn = lazy && k > 0;
-            fuseReq = !lazy && fuse_want(); fuseDone = false;
+            fuseReq = fuse_want(); fuseDone = false;
             if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
-            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { lazyIn = false; carryTail = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { carryTail = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
             fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
-            const bool storesW = !lazy || k == n - 1;
-            if (!fuseDone) launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
+            if (!fuseDone) launch_dual_main(a, k == n - 1, false);
             prof_end(e2);
-            lazyIn = false;
             // bookkeeping of this iteration: folded into the next iteration's k_cut_partial_sums; the last one of the
             // batch gets a launch of its own
             if (k == n - 1) {
@@ -1515,7 +1500,7 @@ struct Ctx : CtxBase {
                 prof_end(e3);
             } else pendingFin = true;
             std::swap(p_xi, p_upd);
-            if (storesW) { p_acc_view = p_acc; std::swap(p_acc, p_acc_other); }
+            p_acc_view = p_acc; std::swap(p_acc, p_acc_other);
             h_it++;
         }
         carryTail = false; inBatch = false;
@@ -1583,25 +1568,19 @@ struct Ctx : CtxBase {
         if (int rc = ensure_tables(h_it + n)) return rc;
         if (int rc = batch_open(nullptr)) return fail_batch(rc);       // checkpoint of (y, y+, w) + the verdict flag cleared: one launch
         const IterSave saved = save_iterates();
-        const bool lazy = lazy_w();
         for (int k = 0; k < n; k++) {
             if (!acc_ready) {
                 hipLaunchKernelGGL(k_extrapolate<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, p_acc, p_xi, p_upd, (T)h_lam[h_it], ntot());
                 acc_ready = true;
             }
-            // the accelerated dual stays out of memory between the iterations of the batch: iteration k > 0 derives it from the two
-            // iterates (sweep and dual update alike), only the last one stores it (w_t for the getters, w_{t+1} for the next batch)
-            lazyIn = lazy && k > 0;
-            fuseReq = !lazy && fuse_want(); fuseDone = false;
+            fuseReq = fuse_want(); fuseDone = false;
             if (fuseReq) { fuseArgs = dual_args(); fuseMat = k == n - 1; fuseLn = h_lam[h_it + 1]; }
-            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { lazyIn = false; pendingFin = false; fuseReq = false; return fail_batch(rc); }
+            if (int rc = launch_sweep(0, nullptr, k == n - 1, nullptr, true)) { pendingFin = false; fuseReq = false; return fail_batch(rc); }
             fuseReq = false;
             DualArgs<T> a = dual_args();
             hipEvent_t e2 = prof_begin(2);
-            const bool storesW = !lazy || k == n - 1;
-            if (!fuseDone) launch_dual_main(a, k == n - 1, false, !lazy ? 0 : (k == n - 1 ? (k > 0 ? 2 : 0) : (k > 0 ? 1 : 3)));
+            if (!fuseDone) launch_dual_main(a, k == n - 1, false);
             prof_end(e2);
-            lazyIn = false;
             if (k == n - 1) {   // the last iteration's bookkeeping gets a launch of its own
                 hipEvent_t e3 = prof_begin(3);
                 hipLaunchKernelGGL(k_finalize_optimistic<T>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, main_partials(), d_state, (T *)nullptr,
@@ -1609,7 +1588,7 @@ struct Ctx : CtxBase {
                 prof_end(e3);
             } else pendingFin = true;
             std::swap(p_xi, p_upd);
-            if (storesW) { p_acc_view = p_acc; std::swap(p_acc, p_acc_other); }
+            p_acc_view = p_acc; std::swap(p_acc, p_acc_other);
             h_it++;
         }
         RN_HIP(hipGetLastError());
@@ -1881,7 +1860,7 @@ struct Ctx : CtxBase {
         return RN_OK;
     }
     int set_exchange_mode(int mode) override {
-        RN_CHECK(mode >= 0 && mode <= 2, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic, 2 optimistic without the stored accelerated dual");
+        RN_CHECK(mode == 0 || mode == 1, RN_E_ARG, "rn_set_exchange_mode: 0 exact, 1 optimistic");
         optimistic = mode; optHold = 0;
         return RN_OK;
     }
@@ -1919,12 +1898,12 @@ struct Ctx : CtxBase {
             prof_end(e2);
             hipEvent_t e3 = prof_begin(3);
             if (exactSharded) {   // tree-global distances: sum the ranks' dist^2 (2 doubles) before deciding
-                hipLaunchKernelGGL(k_reduce_dist, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
+                hipLaunchKernelGGL(k_reduce_dist<>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_dist2);
                 if (int rc = all_reduce(d_dist2, 2, true, "ncclAllReduce(dist)")) return fail_batch(rc);
-                hipLaunchKernelGGL(k_decide_from, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
+                hipLaunchKernelGGL(k_decide_from<>, dim3(1), dim3(1), 0, stream, d_dist2, d_state, a.thrX, a.thrS);
                 if (last) hipLaunchKernelGGL((k_dual_fused<T, true, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
                 else hipLaunchKernelGGL((k_dual_fused<T, false, true>), dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
+                hipLaunchKernelGGL(k_finalize<>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, d_hist, d_histParts, histCap);
             } else {   // single GPU: the (small) fix-up launch also decides and does the bookkeeping (kernels.hpp, decideHere)
                 a.finalizedEarly = 1;
                 a.decideHere = 1; a.itHost = h_it; a.nMain = main_partials(); a.mainPartials = d_partials; a.partials = d_partials2;
@@ -1959,7 +1938,7 @@ struct Ctx : CtxBase {
         // (the last element: one-shot exchange, "a reader of this rank gave up waiting" -- the MAX makes it every rank's verdict, so all
         //  ranks return RN_E_COMM for the batch together instead of the late one alone)
         if (int rc = all_reduce(d_histGlob, (size_t)4 * n + 2, true, "ncclAllReduce(verdict + primal infeasibilities)", 2 /* ncclMax */)) return rc;
-        hipLaunchKernelGGL(k_batch_close_unpack, dim3(1), dim3(ELT_THREADS), 0, stream, (const double *)d_histGlob, d_hist, first, n, d_state);
+        hipLaunchKernelGGL(k_batch_close_unpack<>, dim3(1), dim3(ELT_THREADS), 0, stream, (const double *)d_histGlob, d_hist, first, n, d_state);
         if (int rc = comm_check()) return rc;
         RN_HIP(hipGetLastError());
         return RN_OK;
@@ -1970,7 +1949,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
-        poisoned = true; lazyIn = false; carryTail = false; pendingFin = false; inBatch = false; hxUnscaled = false;
+        poisoned = true; carryTail = false; pendingFin = false; inBatch = false; hxUnscaled = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }
@@ -2042,7 +2021,7 @@ struct Ctx : CtxBase {
         DualArgs<T> a = dual_args();
         a.w = p_acc_view;
         hipLaunchKernelGGL(k_prox_clamp<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
+        hipLaunchKernelGGL(k_decide<>, dim3(1), dim3(ELT_THREADS), 0, stream, d_partials, eltBlocks, d_state, a.thrX, a.thrS);
         hipLaunchKernelGGL(k_prox_soft<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, a);
         RN_HIP(hipGetLastError());
         return RN_OK;
@@ -2439,13 +2418,13 @@ struct Ctx : CtxBase {
         for (int r = 0; r < reps + 1; r++) {   // first pass = warm-up
             float ms = 0;
             (void)hipEventRecord(e0, stream);
-            hipLaunchKernelGGL(k_bw_read, dim3(blocks), dim3(256), 0, stream, (const nat_d2 *)a, n, sink);
+            hipLaunchKernelGGL(k_bw_read<>, dim3(blocks), dim3(256), 0, stream, (const nat_d2 *)a, n, sink);
             (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
             if (r > 0 && ms > 0) bestR = std::max(bestR, (double)bytes / (ms * 1e-3) / 1e9);
             (void)hipEventRecord(e0, stream);
             // copy: 4 workgroups per CU measured best for a read + write stream (tools/probes/probe_stream.hip: 6.2 TB/s with
             // 1 024 workgroups, 5.2-5.4 with 4 096 or 8 192 on a 1 GiB vector)
-            hipLaunchKernelGGL(k_bw_copy, dim3(numCUs * 4), dim3(256), 0, stream, (const nat_d2 *)a, (nat_d2 *)b, n);
+            hipLaunchKernelGGL(k_bw_copy<>, dim3(numCUs * 4), dim3(256), 0, stream, (const nat_d2 *)a, (nat_d2 *)b, n);
             (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
             if (r > 0 && ms > 0) bestC = std::max(bestC, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
         }
@@ -2453,53 +2432,6 @@ struct Ctx : CtxBase {
         (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
         RN_HIP(hipGetLastError());
         *readGBs = bestR; *copyGBs = bestC;
-        return RN_OK;
-    }
-    // read-only probes in the solver's shapes.  shape 0: n workgroups, each streaming its own contiguous pieceBytes
-    // (chunks start strideBytes apart).  shape 1: n persistent workgroups in lockstep, `steps` pieces of pieceBytes per
-    // batch, ceil(total/steps) batches; strideBytes = total bytes to read.
-    int measure_hbm_shape(int shape, size_t pieceBytes, size_t strideBytes, int n, int unroll, int reps, double *readGBs) override {
-        RN_CHECK((shape == 0 || shape == 1) && pieceBytes >= 1024 && pieceBytes % 32 == 0 && n >= 1 && reps >= 1 && readGBs, RN_E_ARG, "rn_measure_hbm_shape: bad argument");
-        RN_HIP(hipSetDevice(device));
-        size_t bytes, alloc; int steps = 0, batches = 0;
-        if (shape == 0) {
-            RN_CHECK(strideBytes >= pieceBytes && strideBytes % 32 == 0, RN_E_ARG, "rn_measure_hbm_shape: stride < chunk");
-            bytes = pieceBytes * (size_t)n; alloc = strideBytes * (size_t)n;
-        } else {
-            RN_CHECK(pieceBytes <= 8192, RN_E_ARG, "rn_measure_hbm_shape: lockstep pieces are at most 8192 B (256 threads x 32 B)");
-            steps = 48;
-            batches = (int)std::max<size_t>(1, strideBytes / (pieceBytes * (size_t)n * steps));
-            bytes = alloc = pieceBytes * (size_t)n * steps * batches;
-        }
-        void *a = nullptr; double *sink = nullptr;
-        RN_HIP(hipMalloc(&a, alloc));
-        if (hipMalloc((void **)&sink, 65536 * sizeof(double)) != hipSuccess) { (void)hipFree(a); err = "rn_measure_hbm_shape: out of memory"; return RN_E_HIP; }
-        (void)hipMemsetAsync(a, 0, alloc, stream);
-        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        double best = 0;
-        const long long c16 = (long long)(pieceBytes / 16), s16 = (long long)(strideBytes / 16);
-        const size_t plds = 0;
-        for (int r = 0; r < reps + 1; r++) {
-            float ms = 0;
-            (void)hipEventRecord(e0, stream);
-            if (shape == 0) {
-                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_chunks<1>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
-                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_chunks<2>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
-                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_chunks<4>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
-                else hipLaunchKernelGGL(k_bw_read_chunks<8>, dim3(n), dim3(256), plds, stream, (const nat_d2 *)a, c16, s16, sink);
-            } else {
-                if (unroll <= 1) hipLaunchKernelGGL(k_bw_read_lockstep<1>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
-                else if (unroll <= 2) hipLaunchKernelGGL(k_bw_read_lockstep<2>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
-                else if (unroll <= 4) hipLaunchKernelGGL(k_bw_read_lockstep<4>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
-                else hipLaunchKernelGGL(k_bw_read_lockstep<8>, dim3(n), dim3(256), 0, stream, (const nat_d2 *)a, (int)c16, steps, batches, sink);
-            }
-            (void)hipEventRecord(e1, stream); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
-            if (r > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
-        }
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        (void)hipFree(a); (void)hipFree(sink);
-        RN_HIP(hipGetLastError());
-        *readGBs = best;
         return RN_OK;
     }
     int set_operator_mode(int mode) override {
@@ -2645,7 +2577,6 @@ int rn_set_operator(rn_ctx *ctx, int op, int node, const double *h, size_t n) { 
 int rn_set_warm_start(rn_ctx *ctx, int on) { RN_GUARD(ctx); return ctx->impl->set_warm_start(on); }
 int rn_set_exchange_mode(rn_ctx *ctx, int mode) { RN_GUARD(ctx); return ctx->impl->set_exchange_mode(mode); }
 int rn_measure_hbm(rn_ctx *ctx, size_t bytes, int reps, double *r, double *c) { RN_GUARD(ctx); return ctx->impl->measure_hbm(bytes, reps, r, c); }
-int rn_measure_hbm_shape(rn_ctx *ctx, int shape, size_t pb, size_t sb, int n, int u, int reps, double *r) { RN_GUARD(ctx); return ctx->impl->measure_hbm_shape(shape, pb, sb, n, u, reps, r); }
 int rn_set_algorithm(rn_ctx *ctx, int alg, int m) { RN_GUARD(ctx); return ctx->impl->set_algorithm(alg, m); }
 int rn_fbe_reset(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->fbe_reset(); }
 int rn_compute_hessian_oracle(rn_ctx *ctx) { RN_GUARD(ctx); return ctx->impl->hessian_oracle(); }

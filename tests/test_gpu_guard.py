@@ -86,25 +86,6 @@ def test_fp32_and_soft_branch_under_guard(guard):
     guard["contexts"] = 4
 
 
-def test_lazy_dual_under_guard(guard):
-    """exchange mode 2 (the accelerated dual derived on the fly): batches of 1 / 5 / 20 iterations, same bits as mode 1"""
-    p = synth.make_problem("medium")
-    dh, ah = synth.forecast_at(p["forecast"], 0)
-    out = []
-    for mode in (1, 2):
-        s = capi.Solver(p["network"], p["tree"], p["config"])
-        s.initialiseSmpcController(dh, ah)
-        s.setExchangeMode(mode)
-        s.apgReset()
-        for n in (1, 5, 20, 16):
-            s.apgIterate(n, history=False)
-        out.append([s.get(b) for b, _ in par.PAIRS])
-        s.close()
-    for a, b in zip(*out):
-        assert np.isfinite(a).all() and np.array_equal(a, b)
-    guard["contexts"] = 2
-
-
 @pytest.mark.parametrize("name,world,cut,structured,kw,trips", [("medium", 3, 2, False, {}, False), ("ragged", 3, 1, False, {}, False),
                                                                 ("medium", 2, 1, True, {"penalty_x": 20.0, "penalty_xs": 5.0}, True)])
 def test_sharded_batches_under_guard(guard, name, world, cut, structured, kw, trips):

@@ -24,7 +24,7 @@ for step in "$@"; do
              timeout -k 10 420 python bench.py --gpus 2 --steps 10 --warmup 2 --profile-steps 10 --repeats 1 --cpu-iterations 3 --allow-oversubscribe --no-traffic --other-configs "" --time-budget 300 > $O/n2.json 2> $O/n2.err; echo "rc=$?"
              grep "supervisor" $O/n2.err | tail -20; tail -c 600 $O/n2.json ;;
     guard)   # whole test files under the buffer guard (RAPIDNET_GUARD=1: red zones + NaN poison) in one process
-             timeout -k 10 1000 python tools/guard_suite.py -m gpu tests/test_gpu_slab_kernels.py tests/test_gpu_sharded_batched.py tests/test_gpu_fbe_nama.py tests/test_gpu_lazy_dual.py \
+             timeout -k 10 1000 python tools/guard_suite.py -m gpu tests/test_gpu_slab_kernels.py tests/test_gpu_sharded_batched.py tests/test_gpu_fbe_nama.py \
                  tests/test_gpu_random_shapes.py tests/test_gpu_parity.py tests/test_golden_synthetic.py tests/test_gpu_closed_loop.py tests/test_reference_barcelona30.py \
                  tests/test_nonuniform_trees.py tests/test_gpu_fullsize.py tests/test_gpu_oneshot.py tests/test_gpu_comm_timeout.py tests/test_gpu_device_pointer.py tests/test_gpu_fused_walk_dual.py \
                  tests/test_gpu_unscaled_walk.py tests/test_gpu_operator_mode.py > $O/guard_suite.log 2>&1; rc=$?

@@ -1,7 +1,6 @@
 #!/bin/bash
-# device ISA of one kernel: bash tools/isa.sh <mangled-name-prefix> [out.s]   (e.g. _ZN2rn10k_gemm_vlvIdE)
-cd /root/repo/rapidnet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Wno-unused-function -Wno-pass-failed -o /tmp/k.s rapidnet_capi.hip 2>&1 | grep -v "warning\|^$" | head -5
-L=$(grep -n "^$1.*:" /tmp/k.s | head -1 | cut -d: -f1); E=$(awk -v s=$L 'NR>=s && /\.Lfunc_end/{print NR; exit}' /tmp/k.s)
-sed -n "${L},${E}p" /tmp/k.s > ${2:-/tmp/one.s}; echo "lines $L-$E -> ${2:-/tmp/one.s}"
-grep -n "v_mfma" ${2:-/tmp/one.s} | awk -F: '{print $1}' | tr '\n' ' ' | head -c 500; echo
-grep "\.vgpr_count\|\.sgpr_spill_count\|\.vgpr_spill_count" /tmp/k.s | head -0
+# device ISA of one kernel: bash tools/isa.sh <unit> <mangled-name-prefix> [out.s]   (e.g. k_slab _ZN2rn10k_gemm_vlvIdE)
+cd /root/repo/rapidnet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Wno-unused-function -Wno-pass-failed -o /tmp/k.s $1.hip 2>&1 | grep -v "warning\|^$" | head -5
+L=$(grep -n "^$2.*:" /tmp/k.s | head -1 | cut -d: -f1); E=$(awk -v s=$L 'NR>=s && /\.Lfunc_end/{print NR; exit}' /tmp/k.s)
+sed -n "${L},${E}p" /tmp/k.s > ${3:-/tmp/one.s}; echo "lines $L-$E -> ${3:-/tmp/one.s}"
+grep -n "v_mfma" ${3:-/tmp/one.s} | awk -F: '{print $1}' | tr '\n' ' ' | head -c 500; echo

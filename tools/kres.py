@@ -6,10 +6,8 @@ import sys
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from rapidnet_amd import build
 
-src = build._hip_deps()[0]
-cmd = [build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-Wno-pass-failed",
-       "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/kres.so", src, "-ldl"] + ["-D" + d for d in sys.argv[1:] if d.startswith("RN_")]
-out = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
+build.build_hip(force=True, verbose=True, defines=[d for d in sys.argv[1:] if d.startswith("RN_")], out="/tmp/kres.so")
+out = build.build_hip.remarks
 cur, rows = None, {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
