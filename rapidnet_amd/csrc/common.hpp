@@ -163,6 +163,11 @@ struct SweepArgs {
     T *qa;            // [node][nx]   a_i = F_i' xi_i
     T *sk;            // [node][nv+nx] s_i = beta_i + sum_children rho_c ; kappa_i
     T *rkq;           // [node][nv+2nx] rho_i, kappa_i, q_i (kept for chain tops and crown nodes)
+    // structured mode, LINEAR form of the leaf-to-root recursion (lin != 0; k_up_chain_lin, k_walks.hpp): the running sums are taken of the
+    // INPUTS of the shared-operator products instead of their outputs, so that no product sits in front of the recursion at all
+    int lin;
+    T *sk2;           // [node][nv+nx+nu]  Bs_i | q_i + kappa_i | Bu_i : the v product's input ([Rinv | T1 | T2] applied to it)
+    T *rkq2;          // [node][nv+2nx+nu] Bs_i | kappa_i | q_i | Bu_i  (chain tops and crown nodes: what a parent sums)
     T *v, *lvb;       // [node][nv] ; [node][nu+nx] = [L v_i ; B L v_i]
     const T *eb;      // [node][nx] e_i + B uhat_i (per control step)
     const T *bw0;     // [nx] B (prevU - prevUhat)
@@ -372,6 +377,11 @@ __device__ __forceinline__ void store_policy(T v, T *dst, int policy) {   // pol
 }
 template <typename T>
 __device__ __forceinline__ void stream_out(T v, T *dst) { store_policy(v, dst, RN_STREAM_OUT_POLICY); }
+template <typename T>
+__device__ __forceinline__ T lin_b_elem(T sp, T d, T y) {   // b_i = G_i' psi_i, one element: sqrt(p_i) (d_u y), as k_gemm_prep_m2 forms it
+#pragma clang fp contract(off)
+    return sp * d * y;
+}
 template <typename T>
 __device__ __forceinline__ T stream_qa_elem(T sp, T d0, T y0, T d1, T y1) {   // roundings spelled out (fp32: contraction is otherwise the compiler's choice)
 #pragma clang fp contract(off)

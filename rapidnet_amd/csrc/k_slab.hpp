@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
     }
     RN_KT(1);
     if (foldRoot == 1 && blockIdx.x == 0) {
-        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        if (a.lin) up_crown_node_lin<T>(a, 0, 0, threadIdx.x, blockDim.x); else up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
         __threadfence_block();                   // same workgroup reads sk of node 0 back below (same CU, same L1)
         __syncthreads();
     }
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(RN_WIDE_THREADS) k_gemm_vlv_wide(GemmArgs<T> g
     RN_KT(0);
     RN_KT(1);
     if (foldRoot == 1 && blockIdx.x == 0) {     // the root's leaf-to-root step (see k_gemm_vlv); foldRoot = 2 never comes here
-        up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        if (a.lin) up_crown_node_lin<T>(a, 0, 0, threadIdx.x, blockDim.x); else up_crown_node<T>(a, 0, 0, threadIdx.x, blockDim.x);
         __threadfence_block();
         __syncthreads();
     }

@@ -477,6 +477,148 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
         }
     }
 }
+// ------------------------------------------------------------------------------------------------------
+// Structured operator mode, LINEAR form of the leaf-to-root recursion (round 6; unsharded contexts).
+// In structured mode every per-node product is (shared matrix) x (diagonal) x (power of p_i):  m2_i = Bbt a_i + L' b_i  with
+// a_i = F_i' xi_i, b_i = G_i' psi_i element-wise functions of the dual, and the recursion only ever ADDS such terms up the tree:
+//   rho_i = beta_i + m2_i + sum_c rho_c  =  Bs_i + Bbt q_i + L' Bu_i,     Bs_i = beta_i + sum_c Bs_c,  q_i = a_i + sum_c q_c,  Bu_i = b_i + sum_c Bu_c
+// (q_i is the recursion's own q; SmpcController.cu:629-672).  So the shared matrices can be applied AFTER the sums:
+//   v_i = -(Rinv rho_i + T1 kappa_i) / (2 p_i) = -[Rinv | T1 | T2] [Bs_i ; q_i + kappa_i ; Bu_i] / (2 p_i),      T1 = Rinv Bbt, T2 = Rinv L'
+// and the product m2 = [Bbt | L'] [a; b] of ALL nodes -- a launch of its own in front of the chain walks (k_gemm_prep_m2, 21 us on the
+// 493-scenario tree) -- disappears: the walk forms a_i, b_i from the dual as it goes, and the v product's K grows from nv + nx to
+// nv + nx + nu.  Same sums in another association: iterates agree with the dense form to rounding, as the structured mode always has.
+// k_up_chain_lin: one workgroup per scenario chain; component t of [Bs (nv) | kappa, q (nx) | Bu (nu)] belongs to thread t (the few
+// components beyond the workgroup's 256 threads to a second trip).  One more workgroup does the previous iteration's bookkeeping.
+constexpr int LIN_PF = 12;     // stages per batch of loads of the branches that need the dual, the preconditioner row and sqrt(p) per stage (five arrays: registers)
+template <typename T>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain_lin(SweepArgs<T> a, FinArgs fin) {
+    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }
+    const int s = blockIdx.x;
+    const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, top = a.chainStage;
+    const int W = nv + nx + nu, W2 = nv + 2 * nx + nu;
+    const size_t nodeTop = (size_t)a.tr.stageCum[top] + s;
+    const T *__restrict__ w = a.w;
+    const T *__restrict__ dy = a.tr.dy;
+    for (int t = threadIdx.x; t < W; t += CHAIN_THREADS) {
+        if (t < nv) {                                   // Bs_i = beta_i + Bs_child
+            T acc = 0;
+            for (int k = a.N - 1; k >= top; k -= UP_PF) {
+                T b[UP_PF];
+#pragma unroll
+                for (int j = 0; j < UP_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    b[j] = a.beta[(nodeTop + (size_t)(kk - top) * a.K) * nv + t];
+                }
+#pragma unroll
+                for (int j = 0; j < UP_PF; j++)
+                    if (k - j >= top) {
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
+                        acc += b[j];
+                        a.sk2[node * W + t] = acc;
+                    }
+            }
+            a.rkq2[nodeTop * W2 + t] = acc;
+        } else if (t < nv + nx) {                       // kappa_i = kappa_c + q_c ; q_i = a_i + q_c ; the product's input is q_i + kappa_i
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int k = a.N - 1; k >= top; k -= LIN_PF) {
+                T w0[LIN_PF], w1[LIN_PF], d0[LIN_PF], d1[LIN_PF], sp[LIN_PF];
+#pragma unroll
+                for (int j = 0; j < LIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    w0[j] = w[node * ny + j0]; w1[j] = w[node * ny + nx + j0];
+                    d0[j] = dy[(size_t)kk * ny + j0]; d1[j] = dy[(size_t)kk * ny + nx + j0];
+                    sp[j] = a.tr.sqrtp[node];
+                }
+#pragma unroll
+                for (int j = 0; j < LIN_PF; j++)
+                    if (k - j >= top) {
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
+                        kap += q;
+                        q += stream_qa_elem(sp[j], d0[j], w0[j], d1[j], w1[j]);      // a_i, with the roundings every other form of a_i has
+                        a.sk2[node * W + t] = q + kap;
+                    }
+            }
+            a.rkq2[nodeTop * W2 + nv + j0] = kap;
+            a.rkq2[nodeTop * W2 + nv + nx + j0] = q;
+        } else {                                        // Bu_i = b_i + Bu_child
+            const int j0 = t - nv - nx;
+            T acc = 0;
+            for (int k = a.N - 1; k >= top; k -= LIN_PF) {
+                T w0[LIN_PF], d0[LIN_PF], sp[LIN_PF];
+#pragma unroll
+                for (int j = 0; j < LIN_PF; j++) {
+                    const int kk = k - j >= top ? k - j : top;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    w0[j] = w[node * ny + 2 * nx + j0]; d0[j] = dy[(size_t)kk * ny + 2 * nx + j0];
+                    sp[j] = a.tr.sqrtp[node];
+                }
+#pragma unroll
+                for (int j = 0; j < LIN_PF; j++)
+                    if (k - j >= top) {
+                        const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
+                        acc += lin_b_elem(sp[j], d0[j], w0[j]);
+                        a.sk2[node * W + t] = acc;
+                    }
+            }
+            a.rkq2[nodeTop * W2 + nv + nx + j0] = acc;
+        }
+    }
+}
+// one crown node in the linear form: its children's (Bs | kappa | q | Bu) summed in ascending order, its own beta / a / b added
+template <typename T>
+__device__ __forceinline__ void up_crown_node_lin(const SweepArgs<T> &a, int stage, int pos, int tid, int nthreads) {
+    const int node = a.tr.stageCum[stage] + pos;
+    const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, W = nv + nx + nu, W2 = nv + 2 * nx + nu;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    const T *rk = a.rkq2;
+    const T sp = a.tr.sqrtp[node];
+    const T *dy = a.tr.dy + (size_t)stage * ny;
+    const T *wn = a.w + (size_t)node * ny;
+    for (int t = tid; t < W; t += nthreads) {
+        if (t < nv || t >= nv + nx) {                   // Bs or Bu: one children sum
+            const int col = t < nv ? t : t + nx;        // column in rkq2
+            T sum = 0;
+            for (int c = 0; c < nc; c += CHAIN_PF) {
+                T r[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) r[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * W2 + col] : (T)0;
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) sum += r[j];
+            }
+            T own;
+            if (t < nv) own = a.beta[(size_t)node * nv + t];
+            else { const int j0 = t - nv - nx; own = lin_b_elem(sp, dy[2 * nx + j0], wn[2 * nx + j0]); }
+            const T val = own + sum;
+            a.sk2[(size_t)node * W + t] = val;
+            a.rkq2[(size_t)node * W2 + col] = val;
+        } else {
+            const int j0 = t - nv;
+            T kap = 0, q = 0;
+            for (int c = 0; c < nc; c += CHAIN_PF) {
+                T kc[CHAIN_PF], qc[CHAIN_PF];
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    kc[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * W2 + nv + j0] : (T)0;
+                    qc[j] = (c + j < nc) ? rk[(size_t)(c0 + c + j) * W2 + nv + nx + j0] : (T)0;
+                }
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) { kap += kc[j] + qc[j]; q += qc[j]; }
+            }
+            const T qi = q + stream_qa_elem(sp, dy[j0], wn[j0], dy[nx + j0], wn[nx + j0]);
+            a.sk2[(size_t)node * W + t] = qi + kap;
+            a.rkq2[(size_t)node * W2 + nv + j0] = kap;
+            a.rkq2[(size_t)node * W2 + nv + nx + j0] = qi;
+        }
+    }
+}
+// one launch per crown stage, one workgroup per node (the root's step rides in workgroup 0 of the v / Lv launch: up_crown_node_lin there)
+template <typename T>
+__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, int stage) {
+    up_crown_node_lin<T>(a, stage, (int)blockIdx.x, (int)threadIdx.x, CROWN_THREADS);
+}
+
 // multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload).
 // Optimistic exchange: one more workgroup (blockIdx = number of cut parents, when fin.partials != nullptr) does the
 // bookkeeping of the PREVIOUS iteration's fused dual update -- folds its partials, writes the history entry, advances the

@@ -562,6 +562,13 @@ struct Ctx : CtxBase {
     // the shared operators of the slab products once more in MFMA fragment order (kernels.hpp, GemmArgs::Mf): [16-row tile][pair of k-steps][lane][2],
     // zero-padded like the column-major copies (pad16(m) rows, pad4(k) columns): a wave's A operands of two k-steps are one contiguous request
     T *d_RTf = nullptr, *d_LBLf = nullptr, *d_BLf = nullptr;
+    // structured mode, linear form of the leaf-to-root recursion (k_walks.hpp, k_up_chain_lin): the operator [Rinv | T1 | T2] of the v product
+    // (column-major padded, and in fragment order) and the running sums' buffers; allocated by the factor step of a structured context
+    T *d_RT2p = nullptr, *d_RT2f = nullptr, *d_sk2 = nullptr, *d_rkq2 = nullptr;
+    // the form applies to unsharded structured sweeps whose v / Lv slab (16 nodes x (nv + nx + nu) and 16 x nv values) fits a workgroup's 64 KB;
+    // otherwise (the wide fp32 network) the structured sweep keeps its first product k_gemm_prep_m2
+    bool lin_fits() const { return (size_t)16 * (slab_stride(pad4(d.nv + d.nx + d.nu)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024; }
+    bool lin_on() const { return structured && d_sk2 != nullptr && knob[RN_KNOB_STRUCT_LINEAR] != 0; }
     bool frag_on() const { return knob[RN_KNOB_SLAB_FRAG] != 0; }   // the slab products take their A operands from the fragment-ordered copies (default on)
     int upload_fragments(T *dst, const double *src, int m, int k) {
         const int mp = pad16(m), kp = pad4(k), tiles = mp / 16, pairs = kp / 8;
@@ -587,6 +594,7 @@ struct Ctx : CtxBase {
         a.chainStage = a.cutSums ? std::max(chainStage, cutStage) : chainStage;
         a.K = h_stageCum[a.chainStage + 1] - h_stageCum[a.chainStage];
         a.A = d_A; a.RT = d_RTp; a.L = d_L; a.B = d_B; a.structured = structured; a.ab = d_ab;
+        a.lin = (lin_on() && cutStage <= 0) ? 1 : 0; a.sk2 = d_sk2; a.rkq2 = d_rkq2;
         a.beta = d_beta; a.uhat = d_uhat; a.e = d_e; a.curX = d_curX; a.prevU = d_prevU; a.prevUhat = d_prevUhat;
         a.w = p_acc;
         a.my = d_my; a.my2 = d_my2; a.splitFirst = (splitFirst >= 0 && !structured) ? splitFirst : d.nodes; a.qa = d_qa; a.sk = d_sk; a.rkq = d_rkq; a.v = d_v; a.lvb = d_lvb; a.eb = d_eb; a.bw0 = d_bw0; a.bw = d_bw;
@@ -622,6 +630,14 @@ struct Ctx : CtxBase {
         RN_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) numCUs = cu; }
         if (hipHostMalloc((void **)&h_verdict, sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h_verdict = nullptr; } else *h_verdict = 0;
+        {   // The library's device code is six code objects (one per kernel unit) and the HIP runtime loads a code object when its first kernel is
+            // looked up: asked for here, so that no later call -- a control step under the caller's leak check (SmpcController.cu:1612-1623) --
+            // is the one during which the device's free memory shrinks by a code object
+            hipFuncAttributes fa;
+            for (const void *fn : {(const void *)k_stream_gemv<T, 1, false>, (const void *)k_dual_fused<T, false, false>, (const void *)k_up_chain<T, false>,
+                                   (const void *)k_gemm_slab<T, EPI_Z, false>, (const void *)k_pack<T>, (const void *)k_dots<T>})
+                if (hipFuncGetAttributes(&fa, fn) != hipSuccess) (void)hipGetLastError();
+        }
         const int N = d.N, nodes = d.nodes;
         // validate and convert the tree (reference conventions -> 0-based parent/children ranges)
         h_stageCum.assign(tr->nodesPerStageCumul, tr->nodesPerStageCumul + N + 1);
@@ -772,6 +788,20 @@ struct Ctx : CtxBase {
         std::copy(T1.begin(), T1.end(), RTm.begin() + (size_t)nv * nv);
         if (int rc = upload_padded(d_RTp, RTm.data(), nv, nv + nx)) return rc;
         if (int rc = upload_fragments(d_RTf, RTm.data(), nv, nv + nx)) return rc;
+        if (structured && lin_fits()) {   // [Rinv | T1 | T2]: nv x (nv + nx + nu)
+            const size_t no = (size_t)pad16(nv) * pad4(nv + nx + nu);
+            if (!d_RT2p) {
+                if (int rc = dalloc(&d_RT2p, no)) return rc;
+                if (int rc = dalloc(&d_RT2f, no)) return rc;
+                if (int rc = dalloc(&d_sk2, (size_t)d.nodes * (nv + nx + nu))) return rc;
+                if (int rc = dalloc(&d_rkq2, (size_t)d.nodes * (nv + 2 * nx + nu))) return rc;
+            }
+            std::vector<double> RT2((size_t)nv * (nv + nx + nu));
+            std::copy(RTm.begin(), RTm.end(), RT2.begin());
+            std::copy(T2.begin(), T2.end(), RT2.begin() + (size_t)nv * (nv + nx));
+            if (int rc = upload_padded(d_RT2p, RT2.data(), nv, nv + nx + nu)) return rc;
+            if (int rc = upload_fragments(d_RT2f, RT2.data(), nv, nv + nx + nu)) return rc;
+        }
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
         UP(d_Rinv, h_Rinv.data(), nv * nv) UP(d_Bbt, h_Bbt.data(), nv * nx) UP(d_L, s->matL, nu * nv) UP(d_B, s->matB, nx * nu)
@@ -1118,12 +1148,13 @@ struct Ctx : CtxBase {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
 #if RN_GEMM_SLAB
         GemmArgs<T> gV{d_RTp, nv, nv + nx, pad16(nv), pad4(nv + nx), a.sk, nv + nx, a.v, nv, a.my, 2 * nv, d_prob, d.nodes, a.my2, a.splitFirst};
+        if (a.lin) gV = GemmArgs<T>{d_RT2p, nv, nv + nx + nu, pad16(nv), pad4(nv + nx + nu), a.sk2, nv + nx + nu, a.v, nv, nullptr, 0, d_prob, d.nodes, nullptr, d.nodes};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         if (structured) gV.aux = nullptr;       // m1_i is folded into the v product (d_my's m1 half stays zero): the epilogue has nothing to fetch
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
-        if (frag_on()) { gV.Mf = d_RTf; gL.Mf = d_LBLf; }     // (read by the lean loops only: launches with more slabs than CUs)
+        if (frag_on()) { gV.Mf = a.lin ? d_RT2f : d_RTf; gL.Mf = d_LBLf; }
         if (lds <= 64 * 1024) {
             const int nSlabs = (d.nodes + 15) / 16;
             // many slabs per CU: one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
@@ -1207,7 +1238,9 @@ struct Ctx : CtxBase {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (phase != 2) {
             e0 = prof_begin(0);
-            if (structured) {
+            if (a.lin) {
+                // nothing: the linear form has no product in front of the chain walks
+            } else if (structured) {
                 launch_prep_m2(a);
             } else {
                 const StreamRhs2<T> r2{hessianInput2, d_myB, d_qaB};
@@ -1240,7 +1273,8 @@ struct Ctx : CtxBase {
             FinArgs fin{};
             const bool ride = pendingFin && !a.cutSums;
             if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
-            if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain<T, true>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+            if (a.lin) hipLaunchKernelGGL(k_up_chain_lin<T>, dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+            else if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain<T, true>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
             else hipLaunchKernelGGL((k_up_chain<T, false>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
         }
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
@@ -1278,7 +1312,8 @@ struct Ctx : CtxBase {
                     if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
                     if (foldRoot == 2) continue;                       // done by the v / Lv launch
                 }
-                hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
+                if (a.lin) hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k)), dim3(CROWN_THREADS), 0, stream, a, k);
+                else hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
         // (3) v_i = m1_i - (Rinv s_i + Rinv Bbt kappa_i) / (2 p_i) ; lv_i = L v_i    (batched over all nodes, MFMA)

@@ -123,3 +123,53 @@ def test_quasi_newton_loops_after_the_switch_to_dense(alg):
     assert np.array_equal(runs[0][2], runs[1][2]) and np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][3], runs[1][3])
     if alg == "namaAlgorithm":
         assert runs[0][4]["sweep_pairs"] == runs[1][4]["sweep_pairs"] > 0
+
+
+@pytest.mark.parametrize("name,precision,tol", [("medium", "f64", 1e-9), ("ragged", "f64", 1e-9), ("small2", "f64", 1e-9), ("late", "f64", 1e-9), ("deep", "f64", 1e-9),
+                                                ("horizon1", "f64", 1e-9), ("horizon2", "f64", 1e-9), ("toy", "f64", 1e-9), ("fan", "f64", 1e-9), ("odd", "f64", 1e-9),
+                                                ("barcelona31", "f64", 1e-9), ("medium", "f32", 2e-4), ("barcelona31", "f32", 2e-4)])
+def test_linear_form_of_the_structured_sweep(name, precision, tol):
+    """Structured mode, round 6: the running sums are taken of the INPUTS of the shared-operator products (k_up_chain_lin, k_up_crown_lin, the
+    root's step in the v / Lv launch) and the first product k_gemm_prep_m2 disappears -- against the oracle, and against the form with that
+    product (rn_debug_set_knob struct_linear = 0): the same sums in another association, so to rounding, not bitwise.  Chains from the root,
+    late branching, a deep crown (stage-by-stage crown launches), ragged child counts, odd ny (flat dual update), the shortest horizons."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
+    o.initialise(dh, ah)
+    runs = []
+    for lin in (1, 0):
+        s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", precision=precision, knobs={"struct_linear": lin})
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        h = np.concatenate([s.apgIterate(20), s.apgIterate(3), s.apgIterate(17)])      # optimistic batch, short exact batch, optimistic batch
+        # step-wise entry points on top of the iterated state
+        s.dualExtrapolationStep(0.5); s.solveStep()
+        runs.append((h, {nm: s.get(bid) for bid, nm in VECS}, s.get(capi.BUF_PRIMAL_XI), s.profileRead))
+        cls = None
+        s.close()
+    ho = o.apg(40)
+    o.extrapolate(0.5); o.solve_step()
+    for h, vecs, hx, _ in runs:
+        assert np.abs(h - ho).max() <= tol * np.abs(ho).max()
+        for nm in ("x", "u", "v"):
+            assert relmax(vecs[nm], o.get(nm)) < tol, nm
+        assert relmax(hx, o.get("primalXi")) < tol
+    assert relmax(runs[0][1]["x"], runs[1][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
+
+
+def test_linear_form_launches_no_first_product():
+    """the per-launch profile of a structured context: class 0 (the product in front of the chain walks) is empty in the linear form"""
+    p = synth.make_problem("medium")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    for lin, launches in ((1, 0), (0, 20)):
+        s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", knobs={"struct_linear": lin})
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        s.apgIterate(5, history=False)
+        s.profileEnable(1); s.profileReset()
+        s.apgIterate(20, history=False)
+        ms, n = s.profileRead()
+        s.profileEnable(0)
+        assert (ms[0] < 1e-3) == (lin == 1) and n[1] == 20, (lin, ms, n)
+        s.close()
