@@ -489,17 +489,18 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown(SweepArgs<T> a, int 
 // nv + nx + nu.  Same sums in another association: iterates agree with the dense form to rounding, as the structured mode always has.
 // k_up_chain_lin: one workgroup per scenario chain; component t of [Bs (nv) | kappa, q (nx) | Bu (nu)] belongs to thread t (the few
 // components beyond the workgroup's 256 threads to a second trip).  One more workgroup does the previous iteration's bookkeeping.
-constexpr int LIN_PF = 12;     // stages per batch of loads of the branches that need the dual, the preconditioner row and sqrt(p) per stage (five arrays: registers)
+constexpr int LIN_PF = 12;     // stages per batch of loads of the branches that need the dual and the preconditioner row per stage (registers)
+// the walk of chain s: W = a.w (global memory: node-major [node][ny]) or, LDS != nullptr, the chain's rows of the NEXT accelerated dual as the
+// fused walk + dual update has just left them in its LDS tile ([row = stage - c*][ny]); the same sums in the same order either way
 template <typename T>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain_lin(SweepArgs<T> a, FinArgs fin) {
-    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }
-    const int s = blockIdx.x;
+__device__ __forceinline__ void up_chain_lin_walk(const SweepArgs<T> &a, int s, const T *LDS, int tid, int nthreads) {
     const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, top = a.chainStage;
     const int W = nv + nx + nu, W2 = nv + 2 * nx + nu;
     const size_t nodeTop = (size_t)a.tr.stageCum[top] + s;
-    const T *__restrict__ w = a.w;
     const T *__restrict__ dy = a.tr.dy;
-    for (int t = threadIdx.x; t < W; t += CHAIN_THREADS) {
+    const T sp = a.tr.sqrtp[nodeTop];                  // (a chain does not branch: one probability from its top to its leaf)
+    auto wAt = [&](int kk, size_t node, int c) -> T { return LDS ? LDS[(size_t)(kk - top) * ny + c] : a.w[node * ny + c]; };
+    for (int t = tid; t < W; t += nthreads) {
         if (t < nv) {                                   // Bs_i = beta_i + Bs_child
             T acc = 0;
             for (int k = a.N - 1; k >= top; k -= UP_PF) {
@@ -522,21 +523,20 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain_lin(SweepArgs<T> a, 
             const int j0 = t - nv;
             T kap = 0, q = 0;
             for (int k = a.N - 1; k >= top; k -= LIN_PF) {
-                T w0[LIN_PF], w1[LIN_PF], d0[LIN_PF], d1[LIN_PF], sp[LIN_PF];
+                T w0[LIN_PF], w1[LIN_PF], d0[LIN_PF], d1[LIN_PF];
 #pragma unroll
                 for (int j = 0; j < LIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                    w0[j] = w[node * ny + j0]; w1[j] = w[node * ny + nx + j0];
+                    w0[j] = wAt(kk, node, j0); w1[j] = wAt(kk, node, nx + j0);
                     d0[j] = dy[(size_t)kk * ny + j0]; d1[j] = dy[(size_t)kk * ny + nx + j0];
-                    sp[j] = a.tr.sqrtp[node];
                 }
 #pragma unroll
                 for (int j = 0; j < LIN_PF; j++)
                     if (k - j >= top) {
                         const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
                         kap += q;
-                        q += stream_qa_elem(sp[j], d0[j], w0[j], d1[j], w1[j]);      // a_i, with the roundings every other form of a_i has
+                        q += stream_qa_elem(sp, d0[j], w0[j], d1[j], w1[j]);      // a_i, with the roundings every other form of a_i has
                         a.sk2[node * W + t] = q + kap;
                     }
             }
@@ -546,25 +546,29 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain_lin(SweepArgs<T> a, 
             const int j0 = t - nv - nx;
             T acc = 0;
             for (int k = a.N - 1; k >= top; k -= LIN_PF) {
-                T w0[LIN_PF], d0[LIN_PF], sp[LIN_PF];
+                T w0[LIN_PF], d0[LIN_PF];
 #pragma unroll
                 for (int j = 0; j < LIN_PF; j++) {
                     const int kk = k - j >= top ? k - j : top;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                    w0[j] = w[node * ny + 2 * nx + j0]; d0[j] = dy[(size_t)kk * ny + 2 * nx + j0];
-                    sp[j] = a.tr.sqrtp[node];
+                    w0[j] = wAt(kk, node, 2 * nx + j0); d0[j] = dy[(size_t)kk * ny + 2 * nx + j0];
                 }
 #pragma unroll
                 for (int j = 0; j < LIN_PF; j++)
                     if (k - j >= top) {
                         const size_t node = nodeTop + (size_t)(k - j - top) * a.K;
-                        acc += lin_b_elem(sp[j], d0[j], w0[j]);
+                        acc += lin_b_elem(sp, d0[j], w0[j]);
                         a.sk2[node * W + t] = acc;
                     }
             }
-            a.rkq2[nodeTop * W2 + nv + nx + j0] = acc;
+            a.rkq2[nodeTop * W2 + nv + 2 * nx + j0] = acc;
         }
     }
+}
+template <typename T>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain_lin(SweepArgs<T> a, FinArgs fin) {
+    if ((int)blockIdx.x >= a.K) { finalize_optimistic_body<T>(fin); return; }
+    up_chain_lin_walk<T>(a, (int)blockIdx.x, nullptr, (int)threadIdx.x, CHAIN_THREADS);
 }
 // one crown node in the linear form: its children's (Bs | kappa | q | Bu) summed in ascending order, its own beta / a / b added
 template <typename T>
@@ -614,8 +618,11 @@ __device__ __forceinline__ void up_crown_node_lin(const SweepArgs<T> &a, int sta
     }
 }
 // one launch per crown stage, one workgroup per node (the root's step rides in workgroup 0 of the v / Lv launch: up_crown_node_lin there)
+// (one more workgroup -- blockIdx = nodes of the stage, when fin.partials != nullptr -- does the previous iteration's bookkeeping: the chain
+//  walk that otherwise hosts it rode in the previous iteration's fused walk + dual update, k_down_chain_dual UPLIN)
 template <typename T>
-__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, int stage) {
+__global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, int stage, int nNodes, FinArgs fin) {
+    if ((int)blockIdx.x >= nNodes) { if (threadIdx.x < ELT_THREADS) finalize_optimistic_body<T>(fin); return; }
     up_crown_node_lin<T>(a, stage, (int)blockIdx.x, (int)threadIdx.x, CROWN_THREADS);
 }
 
@@ -901,7 +908,10 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // only when the primal iterates are stored), phase B walks the rows' 16-byte vectors like a k_dual_stage tile (dual_elem: the same
 // arithmetic element by element).  One dependent launch and the 42 MB round trip of Hx less per iteration.  The arg-max keeps the
 // reference's tie rule by comparing indices on equal magnitudes (a thread does not meet its elements in ascending order here).
-template <typename T, bool MATERIALIZE>
+// UPLIN (structured mode, linear form; inner iterations of a batch): the chain's leaf-to-top running sums of the NEXT iteration (k_up_chain_lin)
+// ride here as phase C -- the next accelerated dual of the chain's rows stays in the LDS tile in place of Hx, so the next sweep starts at its
+// crown launch: one dependent launch less per iteration (sk2 / rkq2 / beta are the same arrays in every sweep of the context).
+template <typename T, bool MATERIALIZE, bool UPLIN = false>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
@@ -1137,7 +1147,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
             reinterpret_cast<VT *>(da.ynew)[ivv[u]] = yn;
             reinterpret_cast<VT *>(da.wnext)[ivv[u]] = wn;
             if (MATERIALIZE) { reinterpret_cast<VT *>(da.z)[ivv[u]] = z; reinterpret_cast<VT *>(da.res)[ivv[u]] = res; }
+            if (UPLIN) {      // the next accelerated dual of this row, in place of its Hx (read above, by this thread only)
+                const int v = v0 + u * CHAIN_THREADS, row = v / vpn;
+                *reinterpret_cast<VT *>(shx + (size_t)row * ny + cv[u]) = wn;
+            }
         }
+    }
+    if (UPLIN && !crownWriter) {      // ---- phase C: the next sweep's chain walk, from the LDS tile
+        __syncthreads();
+        up_chain_lin_walk<T>(a, s, shx, (int)threadIdx.x, CHAIN_THREADS);
     }
     double valXi = r.valXi, valPsi = r.valPsi;
     long long idxXi = r.idxXi == 0xffffffffu ? 0x7fffffffffffffffLL : (long long)r.idxXi;

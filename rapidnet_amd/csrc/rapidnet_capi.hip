@@ -1251,6 +1251,9 @@ struct Ctx : CtxBase {
         // one-shot exchange: gathered by the launch that produces the cut parents' sums, every parent's workgroup its own
         auto helpers = [&](SweepArgs<T> &a) -> int {
         e1 = prof_begin(1);
+        const bool rodeUp = upDone && a.lin && phase == 0 && !hessianInput;
+        upDone = false;
+        FinArgs linFin{};
         // (2) leaf-to-root vector recursion: chains in one launch, crown stage by stage
         // sharded, cut right above the chains, few local chains per cut parent: one launch does the chain walks AND the cut
         // parents' local children sums (k_up_chain_cut)
@@ -1272,10 +1275,15 @@ struct Ctx : CtxBase {
             // single-GPU optimistic bookkeeping: the previous iteration's fold / history entry / distance check rides here
             FinArgs fin{};
             const bool ride = pendingFin && !a.cutSums;
+            if (rodeUp) {
+                // the chain walk of this sweep rode in the previous iteration's fused walk + dual update; the bookkeeping goes with the first crown launch
+                if (ride) { linFin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
+            } else {
             if (ride) { fin = FinArgs{d_partials, main_partials(), d_state, nullptr, d_hist, d_histParts, histCap, penX / stepSize, penXs / stepSize}; pendingFin = false; }
             if (a.lin) hipLaunchKernelGGL(k_up_chain_lin<T>, dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
             else if (a.splitFirst < d.nodes) hipLaunchKernelGGL((k_up_chain<T, true>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
             else hipLaunchKernelGGL((k_up_chain<T, false>), dim3(a.K + (ride ? 1 : 0)), dim3(CHAIN_THREADS), 0, stream, a, fin);
+            }
         }
         // small crowns are walked by ONE workgroup per direction (stage after stage inside the kernel)
         const bool fusedCrown = cs > 0 && h_stageCum[cs] <= 64;
@@ -1312,7 +1320,11 @@ struct Ctx : CtxBase {
                     if (phase == 1) { prof_end(e1); RN_HIP(hipGetLastError()); return RN_OK; }
                     if (foldRoot == 2) continue;                       // done by the v / Lv launch
                 }
-                if (a.lin) hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k)), dim3(CROWN_THREADS), 0, stream, a, k);
+                if (a.lin) {
+                    const bool host = linFin.partials != nullptr;       // (first crown launch of a sweep whose chain walk rode along)
+                    hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k) + (host ? 1 : 0)), dim3(CROWN_THREADS), 0, stream, a, k, nk(k), linFin);
+                    linFin = FinArgs{};
+                }
                 else hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
             }
         }
@@ -1332,7 +1344,11 @@ struct Ctx : CtxBase {
         const size_t fuseLds = (size_t)d.N * ny * sizeof(T);      // Hx of the chain's N - cs nodes and of up to cs crown nodes
         // (every workgroup leaves one entry in d_partials: trees with more chains than it holds take the two launches)
         if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024 && downGrid <= std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) {
-            if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
+            // structured mode, linear form, inner iteration of a batch: the NEXT sweep's chain walk rides in this launch (phase C) when that sweep
+            // has a crown launch to host the bookkeeping workgroup the chain walk otherwise carries
+            const bool upRide = a.lin && !fuseMat && foldCrown == 1 && (cs - 1 >= (foldRoot ? 1 : 0)) && knob[RN_KNOB_STRUCT_LINEAR] != 2;
+            if (upRide) { hipLaunchKernelGGL((k_down_chain_dual<T, false, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn); upDone = true; }
+            else if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
             else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
             fuseDone = true; mainPartials = downGrid;
         } else
@@ -1485,7 +1501,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
-        poisoned = false; carryTail = false; pendingFin = false; hxUnscaled = false;
+        poisoned = false; carryTail = false; pendingFin = false; hxUnscaled = false; upDone = false;
         h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
         return ensure_tables(0);
     }
@@ -1668,6 +1684,7 @@ struct Ctx : CtxBase {
     // $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 (read when the context runs its first batch) force it either way; while the per-launch profiling
     // of rn_profile_enable is on, the dual update always runs as a launch of its own (the kernel north_star's roofline target names).
     bool fuseReq = false, fuseDone = false, fuseMat = false;
+    bool upDone = false;   // the chain walk of the NEXT plain sweep has been done by the last fused launch (k_down_chain_dual UPLIN): consumed by that sweep
     DualArgs<T> fuseArgs{};
     double fuseLn = 0.0;
     int fuseMode = -2;     // -2: not decided yet ($RAPIDNET_FUSE_DOWN_DUAL, else by shape), -1: by shape, 0 / 1: forced
@@ -1984,7 +2001,7 @@ struct Ctx : CtxBase {
     // from an inconsistent accelerated dual.
     bool poisoned = false;
     int fail_batch(int rc) {
-        poisoned = true; carryTail = false; pendingFin = false; inBatch = false; hxUnscaled = false;
+        poisoned = true; carryTail = false; pendingFin = false; inBatch = false; hxUnscaled = false; upDone = false;
         err += " -- the batch was abandoned half-way: call rn_apg_reset before iterating again";
         return rc;
     }

@@ -173,3 +173,33 @@ def test_linear_form_launches_no_first_product():
         s.profileEnable(0)
         assert (ms[0] < 1e-3) == (lin == 1) and n[1] == 20, (lin, ms, n)
         s.close()
+
+
+@pytest.mark.parametrize("name,precision", [("medium", "f64"), ("ragged", "f64"), ("small2", "f64"), ("deep", "f64"), ("medium", "f32"), ("barcelona31", "f64")])
+def test_chain_walk_riding_in_the_fused_walk_and_dual_update(name, precision):
+    """Structured mode, linear form, fused walk + dual update (what the 493-scenario tree runs by default; forced here): the NEXT iteration's
+    leaf-to-top running sums are formed by the same workgroup from the accelerated dual it has just computed (k_down_chain_dual UPLIN, phase C),
+    the next sweep starts at its crown launch and that launch hosts the bookkeeping workgroup.  The same sums in the same order as the
+    stand-alone chain walk: bitwise its iterates, histories and batch counters (struct_linear = 2: the linear form without the ride) -- and the
+    oracle's.  barcelona31: the crown is the root alone (its step rides in the v / Lv launch), no crown launch to host the bookkeeping: no ride."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    tol = 1e-9 if precision == "f64" else 2e-4
+    o = Oracle(p["network"], p["tree"], p["config"], precision=precision)
+    o.initialise(dh, ah)
+    ho = o.apg(45)
+    runs = []
+    for lin in (1, 2):
+        s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", precision=precision, knobs={"struct_linear": lin})
+        s.setFusedWalkDual(1)
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        h = np.concatenate([s.apgIterate(20), s.apgIterate(5), s.apgIterate(20)])
+        runs.append((h, {nm: s.get(bid) for bid, nm in VECS}, s.counters()))
+        s.close()
+    assert runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][0], runs[1][0])
+    for nm in runs[0][1]:
+        assert np.array_equal(runs[0][1][nm], runs[1][1][nm]), nm
+        assert relmax(runs[0][1][nm], o.get(nm)) < tol, nm
+    assert np.abs(runs[0][0] - ho).max() <= tol * np.abs(ho).max()
