@@ -174,11 +174,10 @@ constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #define RN_SLAB_T 2
 #endif
 #define RN_SLAB_TR(EPI) (RN_SLAB_T == 1 || (RN_SLAB_T == 2 && (EPI) == EPI_LV))
-#ifndef RN_SLAB_DEEP
-#define RN_SLAB_DEEP 1   // 1: groups of 2 * RN_SLAB_KU k-steps in the lean loop of a wave that owns ONE tile (slab_product)
-#endif
 #ifndef RN_SLAB_KU
-#define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k)
+#define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k).  (Groups of 8 for the waves that own
+                       // one tile -- the v product: 7 tiles on 8 waves -- were measured in round 6: 29.6 against 28.8 us dense, 41.7 against 41.1 us in the
+                       // structured linear form: the lean loop is not waiting for its operand requests; profiles/r06_notes.md)
 #endif
 template <typename T, int SLAB_LD = 8>
 __device__ __forceinline__ void slab_load(T *sB, int SB, const T *in, int ldin, int k, int kp, int node0, int cnt, int wave, int nw, int lane, int rows = 16) {
@@ -428,10 +427,6 @@ __device__ __forceinline__ void slab_product(const GemmArgs<T> &g, const T *sB, 
         const int now = have < tg ? have : tg;
         if (now == 3) slab_pass<T, EPI, 3, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
         else if (now == 2) slab_pass<T, EPI, 2, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
-        // one tile per wave (the v product: 7 tiles on 8 waves): the lean loop is a chain of "request a group of operands, wait, multiply" whose
-        // length is the number of groups -- twice the k-steps per group halves the round trips to L2, and with one accumulator tile the registers
-        // are there.  Same operands into the same chain of MFMAs: the same bits.
-        else if (!PIPE && RN_SLAB_DEEP && ksteps % (2 * KU) == 0) slab_pass<T, EPI, 1, 2 * KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
         else slab_pass<T, EPI, 1, KU, PIPE>(g, sB, SB, node0, t0, nw, tiles, ksteps, lane, sOut, SO);
     }
 }
