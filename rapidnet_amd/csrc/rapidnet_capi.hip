@@ -1356,10 +1356,7 @@ struct Ctx : CtxBase {
             // inner iterations of an optimistic batch whose dual update is the stage-tiled kernel reading w: the walk leaves the primal values and
             // the dual update scales them (k_down_chain UNSC / k_dual_stage SCALE: the walk requests no preconditioner entries; bitwise the same Hx)
             const bool unsc = allowPending && !a.writePrimal && phase == 0 && !hessianInput && foldCrown && dualU != 0 && a.hx == d_hx && unscaled_on();
-            // (few chains -- a workgroup has its CU to itself, small trees and shards -- : all stages of a chain in ONE batch of loads; with many chains
-            //  the registers of that cost more in occupancy than the second round trip: 16.6 -> 16.8 us on the whole tree, round 5)
-            if (unsc && downGrid <= numCUs && d.N - cs <= 24 && knob[RN_KNOB_DOWN_ONE_BATCH] != 0) { hipLaunchKernelGGL((k_down_chain<T, true, 24>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
-            else if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true, RN_DOWN_PF_UNSC>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
+            if (unsc) { hipLaunchKernelGGL((k_down_chain<T, true, RN_DOWN_PF_UNSC>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown); hxUnscaled = true; }
             else hipLaunchKernelGGL((k_down_chain<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), 0, stream, a, foldCrown);
         }
         prof_end(e1);
