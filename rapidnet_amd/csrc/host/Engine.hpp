@@ -77,11 +77,20 @@ public:
     // element type is double for RN_F64 engines (the default) and float for RN_F32 ones -- the reference's real_t is float, this
     // host API's is double, so the pointers are untyped and getDevicePrecision() says which.
     int getDevicePrecision();                           // RN_F64 or RN_F32
-    void *getDevicePointer(int bufferId, size_t *n = nullptr);      // RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA (others: std::logic_error)
+    void *getDevicePointer(int bufferId, size_t *n = nullptr);      // RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA, _XMIN ... _UMAX (others: std::runtime_error)
     void *getVecUhat() { return getDevicePointer(RN_BUF_UHAT); }   // Engine.cuh: getVecUhat
     void *getVecBeta() { return getDevicePointer(RN_BUF_BETA); }   //             getVecBeta
     void *getVecE() { return getDevicePointer(RN_BUF_E); }         //             getVecE
     void *getPriceAlpha() { return getDevicePointer(RN_BUF_ALPHA); }   //         getPriceAlpha
+    // the scaled bounds (Engine.cuh:294-314; after factorStep()): node-major copies in the reference's layout, made by the first call of any of the five
+    void *getSysXmin() { return getDevicePointer(RN_BUF_XMIN); }   //             getSysXmin
+    void *getSysXmax() { return getDevicePointer(RN_BUF_XMAX); }   //             getSysXmax
+    void *getSysXs() { return getDevicePointer(RN_BUF_XS); }       //             getSysXs
+    void *getSysUmin() { return getDevicePointer(RN_BUF_UMIN); }   //             getSysUmin
+    void *getSysUmax() { return getDevicePointer(RN_BUF_UMAX); }   //             getSysUmax
+    void *getVecX() { return getDevicePointer(RN_BUF_X); }         // SmpcController.cuh: devVecX (protected there; public here for GPU-side consumers)
+    void *getVecU() { return getDevicePointer(RN_BUF_U); }         //                     devVecU
+    void *getVecV() { return getDevicePointer(RN_BUF_V); }         //                     devVecV
     ~Engine();
 
 private:

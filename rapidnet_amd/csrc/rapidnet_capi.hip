@@ -821,8 +821,9 @@ struct Ctx : CtxBase {
         const int colChunks = std::min(ny, 8);
         hipLaunchKernelGGL(k_expand_operators<T>, dim3(d.nodes, colChunks), dim3(LD >= 192 ? 256 : (LD >= 96 ? 128 : 64)), 0, stream, ea);
         RN_HIP(hipGetLastError());
-        RN_HIP(hipStreamSynchronize(stream));
         factored = true;
+        if (int rc = refresh_bounds_copies()) return rc;
+        RN_HIP(hipStreamSynchronize(stream));
         return RN_OK;
     }
     int set_tree_errors(const double *ed, const double *ep) override {
@@ -1502,7 +1503,7 @@ struct Ctx : CtxBase {
         p_xi = d_ybuf[0]; p_upd = d_ybuf[1]; p_acc = d_wbuf[0]; p_acc_other = d_wbuf[1]; p_acc_view = p_acc;
         acc_ready = true;  // w_0 = (1+l) 0 - l 0 = 0
         poisoned = false; carryTail = false; pendingFin = false; hxUnscaled = false; upDone = false;
-        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
+        h_it = 0;      // (the lambda table is the same fixed sequence after every restart: kept, with its device copy)
         return ensure_tables(0);
     }
     // warm start: keep the duals of the previous control step, restart the momentum (theta = {1,1} => w_0 = y+)
@@ -1510,7 +1511,7 @@ struct Ctx : CtxBase {
         RN_HIP(hipSetDevice(device));
         RN_HIP(hipMemcpyAsync(p_xi, p_upd, (size_t)ntot() * sizeof(T), hipMemcpyDeviceToDevice, stream));   // y := y+
         RN_HIP(hipMemsetAsync(d_state, 0, sizeof(IterState), stream));
-        h_it = 0; theta0 = 1; theta1 = 1; h_lam.clear(); lamUploaded = 0;
+        h_it = 0;
         acc_ready = false;   // the first iteration re-derives w_0 = (1 + 0) y+ - 0 y
         return ensure_tables(0);
     }
@@ -2183,11 +2184,39 @@ struct Ctx : CtxBase {
             default: *n = 0; return nullptr;
         }
     }
+    // The scaled bounds (Engine.cuh:294-314 getSysXmin ... getSysUmax; Engine.cu:433-463) live interleaved in the dual layout here ([node][ny]: the
+    // fused dual update rebuilds them from tables).  A caller that asks for their device pointers gets node-major copies in the reference's layout,
+    // made on the first request (5 arrays, (3 nx + 2 nu) reals per node) and refreshed by every later factor step.
+    T *d_bnd[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int refresh_bounds_copies() {
+        if (!d_bnd[0]) return RN_OK;
+        const int ids[5] = {RN_BUF_XMIN, RN_BUF_XMAX, RN_BUF_XS, RN_BUF_UMIN, RN_BUF_UMAX};
+        for (int i = 0; i < 5; i++) {
+            T *b; int off, dim;
+            if (!ymap(ids[i], &b, &off, &dim)) continue;
+            hipLaunchKernelGGL(k_pack<T>, dim3(eltBlocks), dim3(ELT_THREADS), 0, stream, b, d_bnd[i], ny, off, dim, (long long)d.nodes, 0);
+        }
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
     int device_pointer(int id, void **ptr, size_t *n, int *prec) override {
         RN_CHECK(ptr && n && prec, RN_E_ARG, "rn_device_pointer: null output");
+        *ptr = nullptr; *n = 0; *prec = sizeof(T) == 8 ? RN_F64 : RN_F32;
+        if (id >= RN_BUF_XMIN && id <= RN_BUF_UMAX) {
+            RN_CHECK(factored, RN_E_STATE, "rn_device_pointer: the scaled bounds exist after rn_factor_step");
+            RN_HIP(hipSetDevice(device));
+            if (!d_bnd[0]) {
+                const size_t dims[5] = {(size_t)d.nx, (size_t)d.nx, (size_t)d.nx, (size_t)d.nu, (size_t)d.nu};
+                for (int i = 0; i < 5; i++) if (int rc = dalloc(&d_bnd[i], (size_t)d.nodes * dims[i])) return rc;
+                if (int rc = refresh_bounds_copies()) return rc;
+                RN_HIP(hipStreamSynchronize(stream));
+            }
+            const int i = id - RN_BUF_XMIN;
+            *ptr = d_bnd[i]; *n = (size_t)d.nodes * (i < 3 ? d.nx : d.nu);
+            return RN_OK;
+        }
         size_t cnt = 0;
         T *p = plain(id, &cnt);
-        *ptr = nullptr; *n = 0; *prec = sizeof(T) == 8 ? RN_F64 : RN_F32;
         RN_CHECK(p != nullptr && cnt > 0, RN_E_ARG, "rn_device_pointer: this buffer is not kept in the reference's layout on the device (or not allocated yet): use rn_get");
         *ptr = p; *n = cnt;
         return RN_OK;

@@ -1,6 +1,7 @@
 """rn_device_pointer: the raw device pointers of the arrays the library keeps in the reference's own layout (the counterpart of the
 reference's raw getters, Engine.cuh:108-318, and protected device vectors, SmpcController.cuh:336-462): what a device-to-host copy
-from the pointer returns must be what rn_get returns, in both precisions; the dual-shaped buffers refuse."""
+from the pointer returns must be what rn_get returns, in both precisions; the scaled bounds come as node-major copies made on request; the
+dual iterates refuse."""
 import ctypes as C
 
 import numpy as np
@@ -31,6 +32,22 @@ def test_device_pointers_hold_what_the_getters_return(precision):
         ptr, n, prec = s.devicePointer(bid)
         assert ptr and n == s.nodes * dim and prec == precision
         assert np.array_equal(_d2h(ptr, n, prec), s.get(bid)), bid
+    # the scaled bounds (Engine.cuh:294-314 getSysXmin ... getSysUmax): node-major copies made by the first request, refreshed by a factor step
+    bounds = {capi.BUF_XMIN: s.nx, capi.BUF_XMAX: s.nx, capi.BUF_XS: s.nx, capi.BUF_UMIN: s.nu, capi.BUF_UMAX: s.nu}
+    mem0 = s.deviceMemoryInfo()["context_bytes"]
+    ptrs = {}
+    for bid, dim in bounds.items():
+        ptr, n, prec = s.devicePointer(bid)
+        assert ptr and n == s.nodes * dim and prec == precision
+        assert np.array_equal(_d2h(ptr, n, prec), s.get(bid)), bid
+        ptrs[bid] = ptr
+    assert s.deviceMemoryInfo()["context_bytes"] == mem0 + s.nodes * (3 * s.nx + 2 * s.nu) * (8 if precision == "f64" else 4)      # made once, all five
+    s.network["vecUmax"] = [1.5 * v for v in np.asarray(s.network["vecUmax"], float).ravel()]
+    s.factorStep()
+    s.synchronize()
+    for bid, dim in bounds.items():
+        ptr, n, prec = s.devicePointer(bid)
+        assert ptr == ptrs[bid] and np.array_equal(_d2h(ptr, n, prec), s.get(bid)), bid     # same arrays, new contents
     for bid in (capi.BUF_XI, capi.BUF_UPD_PSI, capi.BUF_PRIMAL_XI):      # kept interleaved [node][2nx + nu]: not the reference's layout
         with pytest.raises(capi.RapidNetError, match="not kept in the reference's layout"):
             s.devicePointer(bid)
