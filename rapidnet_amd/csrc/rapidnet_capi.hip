@@ -1237,11 +1237,9 @@ struct Ctx : CtxBase {
             aux_dirty = false;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (phase != 2) {
+        if (phase != 2 && !a.lin) {      // (the structured mode's linear form has no product in front of the chain walks: class 0 stays empty)
             e0 = prof_begin(0);
-            if (a.lin) {
-                // nothing: the linear form has no product in front of the chain walks
-            } else if (structured) {
+            if (structured) {
                 launch_prep_m2(a);
             } else {
                 const StreamRhs2<T> r2{hessianInput2, d_myB, d_qaB};

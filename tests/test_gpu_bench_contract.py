@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10", "--cpu-iterations", "5"],
+    # (the default line minus what has tests of its own and takes long here: the 160 GB wide network -- test_gpu_baseline_configs.py -- and the
+    #  quasi-Newton loops at full size -- test_gpu_fullsize.py; the round's collection runs the default line as the driver does)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10", "--cpu-iterations", "5",
+                        "--other-configs", "barcelona31,barcelona493:f32", "--no-quasi-newton"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
@@ -54,7 +57,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     sp = d["timing_spread"]
     assert sp["regions"] >= 5 and sp["ms_per_step_min"] <= sp["ms_per_step_median"] <= sp["ms_per_step_max"]
     names = [(c.get("workload"), c.get("dtype")) for c in d.get("configs", [])]
-    assert names == [("barcelona31", "f64"), ("wide4096", "f32"), ("barcelona493", "f32")], names      # the last: the headline tree in the reference's only precision
+    assert names == [("barcelona31", "f64"), ("barcelona493", "f32")], names      # the last: the headline tree in the reference's only precision
     for c in d["configs"]:
         assert "error" not in c, c
         assert c["roofline"]["kernel"] == "k_stream_gemv" and 0.3 < c["roofline"]["frac"] < 1.0 and c["cpu_baseline"]["value"] > 0
@@ -82,12 +85,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "error" not in sm and sm["value"] > 4 * d["value"], sm.get("value")
     if ts["measured_in_this_run"]:
         assert "error" not in sm["mfma"], sm["mfma"]
-        assert 0.05 < sm["mfma_busy_frac"] < 1.0 and any(k.startswith("k_gemm_prep_m2") for k in sm["mfma"]["kernels"]), sm["mfma"]
-    qn = d["quasi_newton"]
-    for k in ("global_fbe_dense", "nama_dense", "global_fbe_structured", "nama_structured"):
-        assert "error" not in qn[k], qn[k]
-        assert 0 < qn[k]["ms_per_iteration"] < 20.0 and qn[k]["counters"]["searches"] > 0, qn[k]
-    assert qn["nama_dense"]["counters"]["sweep_pairs"] > 0 and qn["nama_dense"]["ms_per_iteration"] < qn["global_fbe_dense"]["ms_per_iteration"]
+        assert 0.05 < sm["mfma_busy_frac"] < 1.0 and any(k.startswith("k_gemm_vlv") for k in sm["mfma"]["kernels"]), sm["mfma"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -163,8 +163,7 @@ def test_linear_form_launches_no_first_product():
     """the per-launch profile of a structured context: class 0 (the product in front of the chain walks) holds no launch in the linear form"""
     p = synth.make_problem("medium")
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    t0 = {}
-    for lin in (1, 0):
+    for lin, launches in ((1, 0), (0, 20)):
         s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", knobs={"struct_linear": lin})
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
@@ -173,10 +172,8 @@ def test_linear_form_launches_no_first_product():
         s.apgIterate(20, history=False)
         ms, n = s.profileRead()
         s.profileEnable(0)
-        assert n[1] == 20, n
-        t0[lin] = ms[0]
+        assert n[0] == launches and n[1] == 20 and (ms[0] > 0) == (launches > 0), (lin, ms, n)
         s.close()
-    assert t0[1] < 0.3 * t0[0], t0      # (an empty pair of events against a kernel)
 
 
 @pytest.mark.parametrize("name,precision", [("medium", "f64"), ("ragged", "f64"), ("small2", "f64"), ("deep", "f64"), ("medium", "f32"), ("barcelona31", "f64")])
