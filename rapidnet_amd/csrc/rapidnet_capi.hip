@@ -1676,10 +1676,9 @@ struct Ctx : CtxBase {
     T *d_ckView = nullptr;       // the tuner's copy of the accelerated dual a getter would show (allocated when the one-shot transport becomes a candidate)
     // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual): the optimistic batches ask for
     // it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened.
-    // Default BY SHAPE (round 6): on where one workgroup per chain fills the chip -- at least as many chains as CUs, unsharded:
-    // the whole 493-scenario tree -6 us per iteration (0.9 %), +5.4 % iterations/s in structured mode -- off on small trees and shards
-    // (62 workgroups of a 1/8 shard cannot keep as many bytes in flight as the stage-tiled kernel's grid: +2 us;
-    // profiles/r05_ab_fused_walk_dual.txt, profiles/r06_ab_fuse_by_shape.txt).  rn_set_fused_walk_dual(ctx, 0 / 1) or
+    // Default BY SHAPE (round 6): on where one workgroup per chain (nearly) fills the chip -- chains >= 3/4 of the CUs: the whole 493-scenario
+    // tree -2.2 % per iteration dense, -5.6 % structured, a 1/2 shard -0.7 % -- off on small trees and smaller shards (62 workgroups of a 1/8 shard
+    // cannot keep as many bytes in flight as the stage-tiled kernel's grid: +2.7 %; profiles/r06_ab_fuse_by_shape.txt).  rn_set_fused_walk_dual(ctx, 0 / 1) or
     // $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 (read when the context runs its first batch) force it either way; while the per-launch profiling
     // of rn_profile_enable is on, the dual update always runs as a launch of its own (the kernel north_star's roofline target names).
     bool fuseReq = false, fuseDone = false, fuseMat = false;
@@ -1688,9 +1687,9 @@ struct Ctx : CtxBase {
     double fuseLn = 0.0;
     int fuseMode = -2;     // -2: not decided yet ($RAPIDNET_FUSE_DOWN_DUAL, else by shape), -1: by shape, 0 / 1: forced
     int set_fused_walk_dual(int on) override { RN_CHECK(on >= -1 && on <= 1, RN_E_ARG, "rn_set_fused_walk_dual: 0, 1 or -1 (by shape)"); fuseMode = on; return RN_OK; }
-    bool fuse_by_shape() const {
-        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];
-        return cutStage <= 0 && K >= numCUs;
+    bool fuse_by_shape() const {      // (profiles/r06_ab_fuse_by_shape.txt: 493 chains -2.2 % dense / -5.6 % structured, 247 chains of a 1/2 shard -0.7 %, 124 chains: a tie,
+        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];      //  62 and 31 chains: +3-4 %)
+        return 4 * K >= 3 * numCUs;
     }
     bool fuse_want() {
         if (fuseMode == -2) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseMode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }
