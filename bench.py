@@ -339,7 +339,7 @@ def merge_exchange(out, alt):
     first = {"value": out.get("value"), "ms_per_step": out.get("ms_per_step"), "exchange_us": out.get("exchange_us")}
     ex = {"candidates": {"rccl_default": dict(first, what="ncclAllReduce on the solver's stream, RCCL's own defaults: the first worker's timed region")},
           "chosen": "rccl_default", "value_rccl_default": out.get("value")}
-    if isinstance(alt, dict) and "error" not in alt and alt.get("value"):
+    if isinstance(alt, dict) and "error" not in alt and alt.get("value") and alt.get("ms_per_step"):
         t = alt.get("tune") or {}
         ex["candidates"]["auto"] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"], "chosen_transport": alt.get("chosen"), "rccl_hints": alt.get("rccl_hints"),
                                     "tune_us_per_iteration": {"collective_hinted": t.get("collective_us"), "one_shot": t.get("oneshot_us")},
@@ -550,7 +550,11 @@ def supervise(args):
             print("bench.py: rank 0's worker ended without a result line", file=sys.stderr, flush=True)
             os._exit(1)
         if alt is not None:
-            out = merge_exchange(json.loads(line), alt)
+            try:
+                out = merge_exchange(json.loads(line), alt)
+            except Exception as e:   # noqa: BLE001 -- whatever the second worker printed cannot take the first worker's line with it
+                out = json.loads(line)
+                out["alt_exchange"] = {"error": "could not be merged (%s: %s)" % (type(e).__name__, e), "raw": alt}
             with lock:
                 best[0] = json.dumps(out)
         emit()
@@ -892,6 +896,7 @@ def main():
                 s_ = capi.Solver(problem["network"], tree, problem["config"], precision=precision, device=device, structured=structured, knobs=knobs)
                 s_.commInit(0, 1, None)
                 s_.setCutStage(cut_stage, (debug_part["momE"], debug_part["momP"]))
+                s_.setExchangeTransport(capi.EXCHANGE_COLLECTIVE)      # (these timing modes say which transport they time: --one-shot switches below)
                 return s_
             # the real thing: partition + cut stage + children moments in ONE call of the C-ABI -- WITHOUT a communicator yet
             s_ = capi.Solver(problem["network"], problem["tree"], problem["config"], precision=precision, device=device, structured=structured,

@@ -1785,7 +1785,9 @@ struct Ctx : CtxBase {
     bool prepared = false;
     int exchange_prepare() {
         if (prepared || peerReady || oneShotBroken) return RN_OK;
-        if (comm == nullptr || nranks < 2 || nranks > PEER_MAX || cutStage <= 0) return RN_OK;   // stand-in communicators: the test wires the inboxes
+        // (stand-in communicators: the test wires the inboxes.  A ONE-rank communicator goes through all of it too -- the rank's own inbox, the
+        //  gather, the agreement: what a one-GPU box can exercise of this path)
+        if (comm == nullptr || nranks < 1 || nranks > PEER_MAX || cutStage <= 0) return RN_OK;
         prepared = true;
         RN_HIP(hipSetDevice(device));
         unsigned char handle[64] = {0};
@@ -1830,7 +1832,7 @@ struct Ctx : CtxBase {
         RN_CHECK(iters >= 1, RN_E_ARG, "rn_exchange_autotune: iterations >= 1");
         RN_HIP(hipSetDevice(device));
         tuned = true;
-        const bool sharded = has_comm() && cutStage > 0 && nranks > 1 && optimistic;
+        const bool sharded = has_comm() && cutStage > 0 && nranks >= 1 && optimistic;
         if (sharded && !peerReady) { if (int rc = exchange_prepare()) return rc; }
         const bool canOne = sharded && peerReady && !oneShotBroken;
         tuneInfo[1] = 1.0 + (canOne ? 2.0 : 0.0); tuneInfo[6] = 0; tuneInfo[2] = tuneInfo[3] = tuneInfo[4] = tuneInfo[5] = 0.0;

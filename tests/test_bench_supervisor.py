@@ -112,3 +112,26 @@ def test_a_worker_that_fails_before_any_headline_fails_the_job(tmp_path):
     elapsed, rc, lines, err = _result(_finish(t0, p, 120))
     assert rc != 0 and not lines, (rc, lines, err[-1500:])
     assert elapsed < 20 + 60, elapsed          # (budget: 120 s)
+
+
+def test_merge_reports_the_better_exchange_as_value():
+    """N > 1: rank 0's supervisor merges the first worker's line (RCCL defaults) with the second worker's result (the context chose its
+    exchange itself, RCCL under the hint set): `value` is the better timed region, `exchange` names it and keeps every candidate's figure."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = {"metric": "apg_iterations_per_sec", "value": 4000.0, "ms_per_step": 0.25, "exchange_us": 41.0, "config": {"parallelism": "subtree sharding below stage 2, 1 RCCL all-reduce/iteration"},
+            "shard_ceiling_same_box": {"ms_per_step": 0.13}}
+    tune = {"transport": 1, "candidates": 3, "collective_us": 170.0, "oneshot_us": 150.0, "iterations": 200}
+    better = bench.merge_exchange(dict(line, config=dict(line["config"])), {"value": 5000.0, "ms_per_step": 0.2, "chosen": "one-shot", "tune": tune, "rccl_hints": dict(bench.RCCL_HINTS)})
+    assert better["value"] == 5000.0 and better["ms_per_step"] == 0.2 and better["exchange"]["chosen"] == "auto:one-shot"
+    assert better["exchange"]["value_rccl_default"] == 4000.0 and better["exchange"]["candidates"]["rccl_default"]["exchange_us"] == 41.0
+    assert better["exchange"]["candidates"]["auto"]["tune_us_per_iteration"] == {"collective_hinted": 170.0, "one_shot": 150.0}
+    assert abs(better["speedup_vs_shard_ceiling"] - 0.13 / 0.2) < 1e-12 and "auto:one-shot" in better["config"]["parallelism"]
+    worse = bench.merge_exchange(dict(line, config=dict(line["config"])), {"value": 3000.0, "ms_per_step": 1 / 3.0, "chosen": "collective", "tune": tune})
+    assert worse["value"] == 4000.0 and worse["exchange"]["chosen"] == "rccl_default" and worse["exchange"]["candidates"]["auto"]["value"] == 3000.0
+    failed = bench.merge_exchange(dict(line, config=dict(line["config"])), {"error": "the one-shot exchange job did not finish"})
+    assert failed["value"] == 4000.0 and "error" in failed["exchange"]["candidates"]["auto"] and failed["alt_exchange"]["error"]
+    assert set(bench.RCCL_HINTS) == {"NCCL_PROTO", "NCCL_ALGO", "NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"}

@@ -92,3 +92,49 @@ def test_single_rank_rccl_cut_path():
                         (capi.BUF_DUAL_XI, "dualXi")):
             assert relmax(s.get(bid), o.get(nm)) < REL_TOL, nm
         assert np.abs(hist - ohist).max() <= 1e-9 * np.abs(ohist).max()
+
+
+@pytest.mark.parametrize("name,kw,replayed", [("medium", {}, 0), ("ragged", {}, 0), ("medium", {"penalty_x": 20.0, "penalty_xs": 5.0}, 1)])
+def test_the_exchange_sets_itself_up_and_chooses_over_a_real_communicator(name, kw, replayed):
+    """RN_EXCHANGE_AUTO over the library's own RCCL communicator, as far as one GPU can show it: a one-rank communicator made AFTER the cut
+    stage is known -- rn_comm_init then allocates the rank's inbox, gathers the IPC handles over the communicator (a byte-wise SUM
+    all-reduce), wires the inbox and agrees that everybody could -- and the first batch times the real ncclAllReduce against the one-shot
+    exchange on the context's own iterations.  Whatever it picks: the oracle's iterates, the counters of an untuned run, and the getters
+    untouched by an explicit second tune (incl. a batch whose soft-constraint thresholds trip and is replayed)."""
+    p = synth.make_problem(name, **kw)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    o = Oracle(p["network"], p["tree"], p["config"])
+    o.initialise(dh, ah)
+    ohist = o.apg(41)
+    cut = partition.default_cut_stage(p["tree"])
+    runs = {}
+    for fixed in (None, capi.EXCHANGE_COLLECTIVE, capi.EXCHANGE_ONESHOT):
+        s = capi.Solver(p["network"], p["tree"], p["config"])
+        s.setCutStage(cut, partition.cut_children_moments(p["tree"], cut))
+        if fixed == capi.EXCHANGE_COLLECTIVE:
+            s.setExchangeTransport(fixed)                  # before the communicator: nothing of the one-shot transport is set up
+        s.commInit(0, 1, capi.comm_unique_id())
+        if fixed == capi.EXCHANGE_ONESHOT:
+            s.setExchangeTransport(fixed)                  # the inboxes were wired by rn_comm_init
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        h = [s.apgIterate(20), s.apgIterate(1)]
+        info = s.exchangeAutotune(0)
+        if fixed is None:
+            assert info["tunes"] == 1 and info["candidates"] == 3 and info["iterations"] == 20 and info["collective_us"] > 0 and info["oneshot_us"] > 0, info
+            assert info["transport"] == (1 if info["oneshot_us"] < info["collective_us"] else 0), info
+            state = (capi.BUF_XI, capi.BUF_PSI, capi.BUF_UPD_XI, capi.BUF_UPD_PSI, capi.BUF_ACC_XI, capi.BUF_ACC_PSI)
+            before = [s.get(b) for b in state]
+            again = s.exchangeAutotune(12)
+            assert again["tunes"] == 2 and all(np.array_equal(a, s.get(b)) for a, b in zip(before, state))
+        else:
+            assert info["tunes"] == 0 and info["transport"] == fixed, info
+        h.append(s.apgIterate(20))
+        runs[fixed] = (np.concatenate(h), s.counters(), [s.get(b) for b in (capi.BUF_X, capi.BUF_U, capi.BUF_UPD_XI, capi.BUF_UPD_PSI)])
+        s.close()
+    for fixed, (h, c, vecs) in runs.items():
+        assert np.abs(h - ohist).max() <= 1e-9 * np.abs(ohist).max(), fixed
+        for v, nm in zip(vecs, ("x", "u", "updXi", "updPsi")):
+            assert relmax(v, o.get(nm)) < REL_TOL, (fixed, nm)
+        assert c == runs[capi.EXCHANGE_COLLECTIVE][1] and c["replayed"] >= replayed, (fixed, c)
+        assert np.array_equal(h, runs[capi.EXCHANGE_COLLECTIVE][0])            # one rank: the same sums whichever way they travel
