@@ -500,7 +500,15 @@ __device__ __forceinline__ void up_chain_lin_walk(const SweepArgs<T> &a, int s, 
     const T *__restrict__ dy = a.tr.dy;
     const T sp = a.tr.sqrtp[nodeTop];                  // (a chain does not branch: one probability from its top to its leaf)
     auto wAt = [&](int kk, size_t node, int c) -> T { return LDS ? LDS[(size_t)(kk - top) * ny + c] : a.w[node * ny + c]; };
-    for (int t = tid; t < W; t += nthreads) {
+    // Components are dealt to the threads in WAVE-ALIGNED ranges -- [kappa, q | Bu | Bs], each padded to whole waves -- so that a wave runs one kind
+    // of walk (a wave that straddles two kinds runs both, one after the other); the components beyond the workgroup's threads (the tail of Bs,
+    // the cheapest kind: one array, one batch of loads) take a second trip.
+    const int kqW = (nx + 63) / 64 * 64, buW = (nu + 63) / 64 * 64, bsW = (nv + 63) / 64 * 64;
+    for (int slot = tid; slot < kqW + buW + bsW; slot += nthreads) {
+        int t;                                          // component in the order [Bs (nv) | kappa, q (nx) | Bu (nu)] of sk2
+        if (slot < kqW) { if (slot >= nx) continue; t = nv + slot; }
+        else if (slot < kqW + buW) { if (slot - kqW >= nu) continue; t = nv + nx + (slot - kqW); }
+        else { if (slot - kqW - buW >= nv) continue; t = slot - kqW - buW; }
         if (t < nv) {                                   // Bs_i = beta_i + Bs_child
             T acc = 0;
             for (int k = a.N - 1; k >= top; k -= UP_PF) {
