@@ -626,12 +626,61 @@ __device__ __forceinline__ void up_crown_node_lin(const SweepArgs<T> &a, int sta
     }
 }
 // one launch per crown stage, one workgroup per node (the root's step rides in workgroup 0 of the v / Lv launch: up_crown_node_lin there)
-// (one more workgroup -- blockIdx = nodes of the stage, when fin.partials != nullptr -- does the previous iteration's bookkeeping: the chain
-//  walk that otherwise hosts it rode in the previous iteration's fused walk + dual update, k_down_chain_dual UPLIN)
+// One launch per crown stage, one workgroup per node.  The children's rows (Bs | kappa | q | Bu) are summed by `parts` groups of threads side by
+// side -- every load of the node in flight at once (up to CROWN_LIN_PF children per thread) -- and folded through LDS in part order (fixed
+// association).  (One more workgroup -- blockIdx = nodes of the stage, when fin.partials != nullptr -- does the previous iteration's bookkeeping:
+// the chain walk that otherwise hosts it rode in the previous iteration's fused walk + dual update, k_down_chain_dual UPLIN.)
+constexpr int CROWN_LIN_PF = 16;
 template <typename T>
 __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, int stage, int nNodes, FinArgs fin) {
     if ((int)blockIdx.x >= nNodes) { if (threadIdx.x < ELT_THREADS) finalize_optimistic_body<T>(fin); return; }
-    up_crown_node_lin<T>(a, stage, (int)blockIdx.x, (int)threadIdx.x, CROWN_THREADS);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sh = reinterpret_cast<T *>(smem_raw);            // [parts][W2]
+    const int node = a.tr.stageCum[stage] + (int)blockIdx.x;
+    const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, W = nv + nx + nu, W2 = nv + 2 * nx + nu;
+    const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
+    const int wp = (W2 + 63) / 64 * 64;
+    const int parts = CROWN_THREADS / wp > 0 ? CROWN_THREADS / wp : 1;
+    const int part = threadIdx.x / wp;
+    const int tstep = wp < CROWN_THREADS ? wp : CROWN_THREADS;
+    // this thread's own terms, requested with the children's rows
+    const T sp = a.tr.sqrtp[node];
+    const T *dy = a.tr.dy + (size_t)stage * ny;
+    const T *wn = a.w + (size_t)node * ny;
+    if (part < parts) for (int t = threadIdx.x % wp; t < W2; t += tstep) {
+        T sum = 0;
+        for (int c = part; c < nc; c += parts * CROWN_LIN_PF) {
+            T r[CROWN_LIN_PF];
+#pragma unroll
+            for (int j = 0; j < CROWN_LIN_PF; j++) r[j] = (c + j * parts < nc) ? a.rkq2[(size_t)(c0 + c + j * parts) * W2 + t] : (T)0;
+#pragma unroll
+            for (int j = 0; j < CROWN_LIN_PF; j++) sum += r[j];
+        }
+        sh[part * W2 + t] = sum;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < W; t += CROWN_THREADS) {
+        if (t < nv || t >= nv + nx) {
+            const int col = t < nv ? t : t + nx;
+            T sum = 0;
+            for (int p = 0; p < parts; p++) sum += sh[p * W2 + col];
+            T own;
+            if (t < nv) own = a.beta[(size_t)node * nv + t];
+            else { const int j0 = t - nv - nx; own = lin_b_elem(sp, dy[2 * nx + j0], wn[2 * nx + j0]); }
+            const T val = own + sum;
+            a.sk2[(size_t)node * W + t] = val;
+            a.rkq2[(size_t)node * W2 + col] = val;
+        } else {
+            const int j0 = t - nv;
+            T ks = 0, qs = 0;
+            for (int p = 0; p < parts; p++) { ks += sh[p * W2 + nv + j0]; qs += sh[p * W2 + nv + nx + j0]; }
+            const T kap = ks + qs;                       // kappa_i = sum_c (kappa_c + q_c)
+            const T qi = qs + stream_qa_elem(sp, dy[j0], wn[j0], dy[nx + j0], wn[nx + j0]);
+            a.sk2[(size_t)node * W + t] = qi + kap;
+            a.rkq2[(size_t)node * W2 + nv + j0] = kap;
+            a.rkq2[(size_t)node * W2 + nv + nx + j0] = qi;
+        }
+    }
 }
 
 // multi-GPU: partial children sums of the cut parents, [parent][rho(nv) | kappa(nx) | q(nx)] (the all-reduce payload).

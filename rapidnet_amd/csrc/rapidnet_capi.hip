@@ -1321,7 +1321,9 @@ struct Ctx : CtxBase {
                 }
                 if (a.lin) {
                     const bool host = linFin.partials != nullptr;       // (first crown launch of a sweep whose chain walk rode along)
-                    hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k) + (host ? 1 : 0)), dim3(CROWN_THREADS), 0, stream, a, k, nk(k), linFin);
+                    const int w2 = nv + 2 * nx + d.nu, wp2 = (w2 + 63) / 64 * 64;
+                    const size_t ldsLin = (size_t)std::max(1, CROWN_THREADS / wp2) * w2 * sizeof(T);
+                    hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k) + (host ? 1 : 0)), dim3(CROWN_THREADS), ldsLin, stream, a, k, nk(k), linFin);
                     linFin = FinArgs{};
                 }
                 else hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
