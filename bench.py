@@ -747,8 +747,21 @@ def quasi_newton(problem, device, iterations=40):
     return out
 
 
+_PHASES = []       # [name, seconds since the start of this process] at every phase boundary; "phases_s" of the JSON line = the time each took
+
+
+def phase(what):
+    _PHASES.append([what, time.time()])
+
+
+def phases_taken():
+    ts = _PHASES + [["end", time.time()]]
+    return [[ts[i][0], round(ts[i + 1][1] - ts[i][1], 2)] for i in range(len(ts) - 1) if ts[i + 1][1] - ts[i][1] >= 0.05]
+
+
 def main():
     args = parse()
+    phase("start")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -763,12 +776,15 @@ def main():
     head_precision = args.precision or ("f32" if args.workload == "wide4096" else "f64")
     measured, mfma_structured = {}, None
     if world == 1 and args.gpus == 1 and not args.no_traffic and not args.structured and not args.force_shard and args.emulate_world == 0:
+        phase("PMC passes: HBM traffic (%s %s)" % (args.workload, head_precision))
         measured[(args.workload, head_precision)] = measure_traffic(args)   # child processes; nothing in this process has touched the GPU yet
         for spec in (args.other_configs.split(",") if not args.traffic_probe else []):      # the same workload in the other precision rides along: its own passes
             w_, _, pr_ = spec.partition(":")
             if w_ == args.workload and pr_ in ("f32", "f64") and pr_ != head_precision:
+                phase("PMC passes: HBM traffic (%s %s)" % (w_, pr_))
                 measured[(w_, pr_)] = measure_traffic(args, precision=pr_)
         if not (args.dense_only or args.traffic_probe):
+            phase("PMC pass: MFMA busy (structured)")
             mfma_structured = measure_mfma(args)
     if world > 1 and os.environ.get("RAPIDNET_BENCH_TRAFFIC_JSON"):      # rank 0's worker: what its supervisor measured before starting it
         try:
@@ -826,6 +842,7 @@ def main():
     wd = Watchdog(rank, 600.0) if world > 1 else None
 
     def beat(what, limit=None):
+        phase(what)
         if wd is not None:
             wd.beat(what, limit)
 
@@ -1424,6 +1441,7 @@ def main():
             # rank 0 only, after every timed region (the other ranks wait at the closing barrier)
             beat("CPU baseline (%s)" % args.workload, 1300.0)
             out["cpu_baseline"] = cpu_baseline(args.workload, problem, precision, args.cpu_iterations)
+        out["phases_s"] = phases_taken()      # where this run's wall-clock went (>= 0.05 s each), for whoever budgets it
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

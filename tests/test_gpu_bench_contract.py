@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_prints_one_json_line_with_the_contract_fields():
     # (the default line minus what has tests of its own and takes long here: the 160 GB wide network -- test_gpu_baseline_configs.py -- and the
     #  quasi-Newton loops at full size -- test_gpu_fullsize.py; the round's collection runs the default line as the driver does)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10", "--cpu-iterations", "5",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--profile-steps", "10", "--cpu-iterations", "2",
                         "--other-configs", "barcelona31,barcelona493:f32", "--no-quasi-newton"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -25,6 +25,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"] == "apg_iterations_per_sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    # where the run's wall-clock went: every phase of a second or more is named
+    assert d["phases_s"] and all(isinstance(n_, str) and t_ >= 0.05 for n_, t_ in d["phases_s"]) and any("PMC" in n_ for n_, _ in d["phases_s"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
     assert "workload" in d["config"] and "barcelona493" in d["config"]["workload"] and "model" not in d["config"]
@@ -108,14 +110,14 @@ def test_gpus_2_spawns_its_own_ranks():
     processes, gloo rendezvous, rn_create_sharded on both, agreed fallback exchange, max-over-ranks timing) and labels the
     line as a fallback.  With two or more GPUs the plain form simply has to produce a sharded result."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--profile-steps", "10", "--repeats", "1",
-            "--cpu-iterations", "3"]
+            "--cpu-iterations", "2"]
     if _devices() >= 2:
         p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
         assert d["n_gpus"] == 2 and d["rccl"]["ranks_seen_by_rccl"] == 2 and "FALLBACK" not in d["config"]["parallelism"]
         return
-    p = subprocess.run(base, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run(base + ["--no-traffic", "--other-configs", ""], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode != 0
     assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")], "no result line for a run that could not create its communicator"
     err = p.stderr.decode()
