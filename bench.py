@@ -695,9 +695,9 @@ def shard_ceiling(problem, device, steps, unsharded_ms, profile_steps=40):
                                               "dual_update": 1e3 * ms[2] / max(n[2], 1), "collective_per_step": 1e3 * cms / max(profile_steps, 1)},
                         "speedup_before_wire": unsharded_ms / med}
 
+            s.setExchangeTransport(capi.EXCHANGE_COLLECTIVE)      # both transports are timed here: nothing for the context to choose
             row["rccl_one_rank"] = timed("rccl")
-            s.peerInboxConnect([s.peerInboxCreate()])
-            s.setExchangeTransport(1)
+            s.setExchangeTransport(capi.EXCHANGE_ONESHOT)         # (the library wires the rank's own inbox over its communicator)
             row["one_shot"] = timed("oneshot")
             best = min(row["rccl_one_rank"]["ms_per_step"], row["one_shot"]["ms_per_step"])
             row["exchange_budget_us_for_3p5x"] = 1e3 * (unsharded_ms / 3.5 - best) if W == 8 else None
@@ -972,8 +972,11 @@ def main():
                     s = make_local()
             comm_ranks[0] = s.shardInfo()["comm_ranks"]
             if world == 1 and args.one_shot:
-                s.peerInboxConnect([s.peerInboxCreate()])
-                s.setExchangeTransport(1)
+                try:
+                    s.setExchangeTransport(capi.EXCHANGE_ONESHOT)     # a one-rank communicator: the library has wired the rank's own inbox
+                except capi.RapidNetError:
+                    s.peerInboxConnect([s.peerInboxCreate()])         # no communicator: by hand
+                    s.setExchangeTransport(capi.EXCHANGE_ONESHOT)
         else:
             s = make_local()
         beat("factor step + affine terms (%s)" % workload)
