@@ -1461,7 +1461,7 @@ struct Ctx : CtxBase {
         a.regen = RN_DUAL_REGEN; a.stageOf = d_stageOf; a.sqrtp = d_sqrtp; a.dy = d_dy; a.blo = d_blo; a.bhi = d_bhi;
         return a;
     }
-    int lamUploaded = 0;   // leading entries of h_lam that are on the device (0 after every restart of the theta recursion)
+    int lamUploaded = 0;   // leading entries of h_lam that are on the device (kept across restarts: the theta recursion always starts at (1, 1))
     int ensure_tables(int upto) {  // lambda table and history capacity for iterations [0, upto]
         if (upto + 2 > lamCap) {
             const int cap = std::max(1024, 2 * (upto + 2));
@@ -1479,7 +1479,7 @@ struct Ctx : CtxBase {
             lamUploaded = 0;
         }
         // the theta recursion (SmpcController.cu:1513-1520) is a fixed sequence: the table is filled up to the device array's capacity at once
-        // and uploaded ONCE per restart, so that a batch in steady state starts without a copy and a host sync of its own
+        // and uploaded ONCE per capacity, so that a batch in steady state starts without a copy and a host sync of its own
         while ((int)h_lam.size() < lamCap) {
             h_lam.push_back(theta1 * (1.0 / theta0 - 1.0));
             theta0 = theta1;

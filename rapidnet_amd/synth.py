@@ -46,6 +46,10 @@ CONFIGS = {
     # non-uniform two-stage crown (root 3 -> 2, 4, 1 chains) with an even ny: the chain-local sweep's crown kernel on unequal children counts
     "small2": (23, 5, 10, 6, 3, 8, [3, [2, 4, 1]]),
     "ragged2": (22, 4, 7, 5, 2, 7, [[2], [3, 1], [1, 1, 2, 4], [2, 1, 1, 1, 1, 3, 1, 1]]),
+    # crown nodes with many children: 40 and 3 under the root's two (k_up_crown_lin: several thread groups per node, several children per group),
+    # and 20 children per node on a network whose crown rows are wider than half a workgroup (one group, two batches of loads)
+    "bigfan": (25, 4, 8, 6, 3, 5, [2, [40, 3]]),
+    "widefan": (26, 150, 240, 60, 20, 4, [2, 20]),
 }
 
 

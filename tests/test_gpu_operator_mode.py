@@ -127,12 +127,14 @@ def test_quasi_newton_loops_after_the_switch_to_dense(alg):
 
 @pytest.mark.parametrize("name,precision,tol", [("medium", "f64", 1e-9), ("ragged", "f64", 1e-9), ("small2", "f64", 1e-9), ("late", "f64", 1e-9), ("deep", "f64", 1e-9),
                                                 ("horizon1", "f64", 1e-9), ("horizon2", "f64", 1e-9), ("toy", "f64", 1e-9), ("fan", "f64", 1e-9), ("odd", "f64", 1e-9),
-                                                ("barcelona31", "f64", 1e-9), ("medium", "f32", 2e-4), ("barcelona31", "f32", 2e-4)])
+                                                ("barcelona31", "f64", 1e-9), ("medium", "f32", 2e-4), ("barcelona31", "f32", 2e-4),
+                                                ("bigfan", "f64", 1e-9), ("widefan", "f32", 2e-4)])
 def test_linear_form_of_the_structured_sweep(name, precision, tol):
     """Structured mode, round 6: the running sums are taken of the INPUTS of the shared-operator products (k_up_chain_lin, k_up_crown_lin, the
     root's step in the v / Lv launch) and the first product k_gemm_prep_m2 disappears -- against the oracle, and against the form with that
     product (rn_debug_set_knob struct_linear = 0): the same sums in another association, so to rounding, not bitwise.  Chains from the root,
-    late branching, a deep crown (stage-by-stage crown launches), ragged child counts, odd ny (flat dual update), the shortest horizons."""
+    late branching, a deep crown (stage-by-stage crown launches), ragged child counts, odd ny (flat dual update), the shortest horizons, crown nodes
+    with 40 children (several thread groups per node in k_up_crown_lin) and crown rows wider than half a workgroup (one group, two batches)."""
     p = synth.make_problem(name)
     dh, ah = synth.forecast_at(p["forecast"], 0)
     # (late branching and the shortest horizons: the reference's aliasing of Omega / Theta by scenario position does not apply, tests/test_gpu_parity.py EDGE_SHAPES)
