@@ -1,11 +1,11 @@
 #!/bin/bash
-# same-box A/B of the FBE / NAMA loops:  bash tools/ab_fbe.sh VAR   (VAR = RAPIDNET_NAMA_PAIR | RAPIDNET_VALUE_MFMA | RAPIDNET_LS_SEQUENTIAL ...; on = 1, off = 0)
+# same-box A/B of the FBE / NAMA loops:  bash tools/ab_fbe.sh KNOB   (KNOB = nama_pair | value_mfma | ls_sequential: rapidnet_amd.capi.KNOBS; 1 against 0)
 set -o pipefail
-VAR=${1:-RAPIDNET_NAMA_PAIR}
+KNOB=${1:-nama_pair}
 for r in 1 2; do
   for v in 1 0; do
-    echo "round $r $VAR=$v"
-    env $VAR=$v python3 tools/time_fbe_nama.py barcelona493 40 2>&1 | python3 -c "
+    echo "round $r $KNOB=$v"
+    python3 tools/time_fbe_nama.py barcelona493 40 f64 $KNOB=$v 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -1,12 +1,12 @@
 #!/bin/bash
-# A/B of RAPIDNET_SLAB_FRAG (A operands of the slab products from the fragment-ordered operator copies) by kernel time under rocprofv3:
+# A/B of the knob slab_frag (A operands of the slab products from the fragment-ordered operator copies) by kernel time under rocprofv3:
 #   bash tools/ab_frag.sh   -> whole tree dense / structured, 31-scenario tree, 1/8 shard, wide fp32 network: the slab kernels' average durations, FRAG = 0 | 1
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() {  # tag, bench args...
   tag=$1; shift
   for f in 0 1; do
     rm -rf gpurun_out/abfrag_${tag}_$f
-    RAPIDNET_SLAB_FRAG=$f rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abfrag_${tag}_$f -o k -- python3 bench.py --no-cpu-baseline --no-traffic --profile-steps 0 --repeats 0 --other-configs "" "$@" > gpurun_out/abfrag_${tag}_$f.json 2> gpurun_out/abfrag_${tag}_$f.err || { tail -3 gpurun_out/abfrag_${tag}_$f.err; exit 1; }
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abfrag_${tag}_$f -o k -- python3 bench.py --no-cpu-baseline --no-traffic --profile-steps 0 --repeats 0 --other-configs "" --knob slab_frag=$f "$@" > gpurun_out/abfrag_${tag}_$f.json 2> gpurun_out/abfrag_${tag}_$f.err || { tail -3 gpurun_out/abfrag_${tag}_$f.err; exit 1; }
   done
   python3 - "$tag" <<'PY'
 import csv, glob, json, sys

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the command of record behind profiles/r03_*; it names switches and test files of that round (round 6 turned the tuning
+# environment variables into rn_debug_set_knob choices and removed the forms that lost their A/B) -- tools/collect_r06.sh is the current one.
 # Round-3 measurement set (one gpurun call): bench line, rocprof kernel stats of the same command, emulated shards, the
 # two-rank launcher rehearsal, FBE / NAMA timings, PMC traffic file.  Outputs under gpurun_out/r03/.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"

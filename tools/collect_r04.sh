@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the command of record behind profiles/r04_*; it names switches and test files of that round (round 6 turned the tuning
+# environment variables into rn_debug_set_knob choices and removed the forms that lost their A/B) -- tools/collect_r06.sh is the current one.
 # Round-4 measurement set (one gpurun call): bench line, rocprof kernel stats of the same command, emulated shards (RCCL one-rank
 # vs one-shot), kernel stats of the 1/8 shard for both transports, the two-rank launcher rehearsal, the fault-injection run,
 # fp32 on the headline tree, FBE / NAMA timings.  Outputs under gpurun_out/r04/.

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the command of record behind profiles/r05_*; it names switches and test files of that round (round 6 turned the tuning
+# environment variables into rn_debug_set_knob choices and removed the forms that lost their A/B) -- tools/collect_r06.sh is the current one.
 # round 5, on the GPU box (gpurun -- bash tools/collect_r05.sh <step> ...): every step writes under gpurun_out/r05/
 # steps: tests bench kstats n2 guard sq probes   (A/B runs of the slab-product variants: tools/ab_slab.sh; in-kernel stamps: tools/ktiming_reg.py)
 set -o pipefail

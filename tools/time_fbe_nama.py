@@ -1,6 +1,7 @@
 """Times the global-FBE / NAMA loops (rn_algorithm_fbe_nama) on a synthetic workload; prints one JSON line per run.
 
-usage: python tools/time_fbe_nama.py [workload] [iterations] [f64|f32]     (default: barcelona493 30 f64)
+usage: python tools/time_fbe_nama.py [workload] [iterations] [f64|f32] [knob=value ...]     (default: barcelona493 30 f64; knobs: rapidnet_amd.capi.KNOBS,
+the library's test hook rn_debug_set_knob -- e.g. nama_pair=0, value_mfma=0, ls_sequential=1 for the A/B of tools/ab_fbe.sh)
 Not a bench.py line (the headline metric is APG iterations/s); the numbers go into DESIGN.md.
 """
 import json
@@ -15,11 +16,12 @@ from rapidnet_amd import capi, synth
 name = sys.argv[1] if len(sys.argv) > 1 else "barcelona493"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 precision = sys.argv[3] if len(sys.argv) > 3 else "f64"
+knobs = {k: int(v) for k, _, v in (a.partition("=") for a in sys.argv[4:])}
 p = synth.make_problem(name)
 dh, ah = synth.forecast_at(p["forecast"], 0)
 for structured in (False, True):
     for alg in ("proximalAlgorithm", "globalFbeAlgorithm", "namaAlgorithm"):
-        s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision)
+        s = capi.Solver(p["network"], p["tree"], p["config"], structured=structured, precision=precision, knobs=knobs or None)
         s.initialiseSmpcController(dh, ah)
         if alg == "proximalAlgorithm":
             s.algorithmApg(5); s.synchronize()
