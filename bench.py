@@ -1085,8 +1085,8 @@ def main():
                       "ms_per_step_min": 1e3 * allr[0] / steps, "ms_per_step_max": 1e3 * allr[-1] / steps,
                       "value_median": steps / float(np.median(allr)), "note": "region 1 is the contract's timed region (`value`); all regions max over ranks"}
         # the other form of the forward walk + dual update in the SAME context (same buffers: two contexts of one process differ by up to 5 %
-        # through the placement of their buffers alone).  Since round 6 the library decides by shape (rn_set_fused_walk_dual, -1): one launch
-        # (k_down_chain_dual) on unsharded trees with at least as many chains as CUs -- this workload -- two launches otherwise.  Timed here:
+        # through the placement of their buffers alone).  Since round 6 the one launch (k_down_chain_dual) is the library's default (rn_set_fused_walk_dual,
+        # -1), shaped by the tree: one workgroup per chain where the chains fill the chip -- this workload --, up to four otherwise.  Timed here:
         # the two-launch form forced, `repeats` regions, then back to the default.
         fused = None
         if fused_ab and not sharded and rep:
@@ -1104,7 +1104,7 @@ def main():
                 iterate(40)
                 s.synchronize()
                 tm, um = float(np.median(frep)), float(np.median(rep))
-                fused = {"default": "by shape: one launch (k_down_chain_dual) here", "value": steps / um, "ms_per_step": 1e3 * um / steps, "regions": len(rep),
+                fused = {"default": "one launch (k_down_chain_dual), workgroups per chain by shape", "value": steps / um, "ms_per_step": 1e3 * um / steps, "regions": len(rep),
                          "two_launches_same_context": {"value": steps / tm, "ms_per_step": 1e3 * tm / steps, "ms_per_step_min": 1e3 * min(frep) / steps,
                                                        "ms_per_step_max": 1e3 * max(frep) / steps, "regions": len(frep)},
                          "speedup": tm / um,

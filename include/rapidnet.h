@@ -398,10 +398,11 @@ int rn_set_exchange_transport(rn_ctx *ctx, int transport);
 int rn_exchange_autotune(rn_ctx *ctx, int iterations, double info[8]);
 /* The forward walk and the fused dual update of the nodes it has just walked in ONE launch (k_down_chain_dual: Hx stays in LDS between
  * the two; SmpcController.cu:676-747 + :759-864 per node) inside batches of >= 16 iterations; identical iterates (bitwise).
- * on = -1 (default): decided by the shape of the context -- on where the (rank-local) tree has at least 3/4 as many scenario chains as the
- * device has compute units (the 493-scenario tree: 2 % faster per iteration, 5.6 % in structured mode), off for small trees and small
- * shards (where it measured 3-4 % slower); 0 / 1: off / on whenever the shape allows it.  $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 sets the default of contexts
- * that were not told.  While rn_profile_enable is on the dual update always runs as a launch of its own. */
+ * on = -1 (default): on, shaped by the context -- one workgroup per scenario chain where the (rank-local) tree has at least 3/4 as many chains as
+ * the device has compute units (the 493-scenario tree: 2 % faster per iteration, 5.6 % in structured mode), up to four per chain -- each updating
+ * the dual of its own slice of the chain's nodes -- on small trees and small shards (1-4 % faster; with one per chain those measured 3-4 % slower);
+ * 0 / 1: off / on whenever the shape allows it.  $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 sets the default of contexts that were not told.  While
+ * rn_profile_enable is on the dual update always runs as a launch of its own. */
 int rn_set_fused_walk_dual(rn_ctx *ctx, int on);
 /* Device-buffer guard mode ("race detection / sanitizers": no GPU address sanitizer exists on this pool).
  * With RAPIDNET_GUARD=1 in the environment when a context is created, every device buffer of the context gets a 128 KiB red

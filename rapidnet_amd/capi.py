@@ -23,7 +23,7 @@ OPS_DENSE, OPS_STRUCTURED, OPS_AUTO = 0, 1, 2
 OPS_MODES = {"dense": OPS_DENSE, "structured": OPS_STRUCTURED, "auto": OPS_AUTO}
 # include/rapidnet_debug.h, RN_KNOB_*
 KNOBS = {k: i for i, k in enumerate(("dual_trips", "dual_pipe", "vlv_wide", "slab_pipe", "slab_frag", "unscaled_walk", "stream_two_per_cu",
-                                     "stream_split", "nama_pair", "ls_sequential", "value_mfma", "tune_bias_us", "struct_linear"))}
+                                     "stream_split", "nama_pair", "ls_sequential", "value_mfma", "tune_bias_us", "struct_linear", "fuse_split"))}
 EXCHANGE_COLLECTIVE, EXCHANGE_ONESHOT, EXCHANGE_AUTO = 0, 1, 2
 
 # every symbol include/rapidnet.h (the boundary) and include/rapidnet_debug.h (test hooks, rn_debug_*) declare

@@ -969,17 +969,25 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // ride here as phase C -- the next accelerated dual of the chain's rows stays in the LDS tile in place of Hx, so the next sweep starts at its
 // crown launch: one dependent launch less per iteration (sk2 / rkq2 / beta are the same arrays in every sweep of the context).
 template <typename T, bool MATERIALIZE, bool UPLIN = false>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext) {
+__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext, int P) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *shx = reinterpret_cast<T *>(smem_raw);      // [L + top][ny]: rows 0 .. L-1 the chain's nodes (stage top + r), rows L + dd the crown nodes this workgroup writes
     __shared__ Partial sh_p[CHAIN_THREADS / 64];
     __shared__ int sh_rowNode[CROWN_MAX_DEPTH];     // crown rows: node (or -1)
-    const bool crownWriter = (int)blockIdx.x >= a.K;
-    const int s = crownWriter ? 0 : (int)blockIdx.x;
+    // P workgroups per chain (trees and shards with fewer chains than CUs): workgroup (s, part) walks the chain from its top as far as its own
+    // rows [r0, r1) reach -- the walk is a running sum, the loads of the rows above are L2 hits shared with the chain's other workgroups -- and
+    // updates the dual of those rows only.  The last part walks the whole chain (it stores the primal iterates when they are asked for), part 0
+    // also takes the crown rows.  UPLIN: P = 1 (phase C needs the whole chain's rows in one tile).
+    const bool crownWriter = (int)blockIdx.x >= a.K * P;
+    const int s = crownWriter ? 0 : (int)blockIdx.x % a.K;
+    const int part = crownWriter ? 0 : (int)blockIdx.x / a.K;
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage, L = a.N - top;
+    const int r0 = crownWriter ? 0 : (int)((long long)part * L / P), r1 = crownWriter ? 0 : (int)((long long)(part + 1) * L / P);
+    const int kEnd = top + r1;                         // stages [top, kEnd) are walked
+    const bool primalWg = part == P - 1, crownRowsWg = part == 0;
     const int ntop = a.tr.stageCum[top] + s;
     const size_t nodeTop = (size_t)ntop;
     const T sp = a.tr.sqrtp[ntop];
@@ -997,7 +1005,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
             if (dd < top) {
                 const int p = a.tr.parent[n];
                 first = first && (a.tr.childStart[p] == n);
-                anc[dd] = p; writer[dd] = first && foldCrown == 1 && !crownWriter;
+                anc[dd] = p; writer[dd] = first && foldCrown == 1 && !crownWriter && crownRowsWg;
                 n = p;
             } else { anc[dd] = 0; writer[dd] = false; }
         }
@@ -1009,9 +1017,9 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
         sh_rowNode[threadIdx.x] = nd;
     }
     // ---- phase A: the walk (k_down_chain, foldCrown 1 / 2), Hx into LDS
-    auto put = [&](int row, size_t node, int c, T val) {
+    auto put = [&](int row, size_t node, int c, T val, bool store) {
         shx[(size_t)row * ny + c] = val;
-        if (a.writePrimal) a.hx[node * ny + c] = val;
+        if (a.writePrimal && store) a.hx[node * ny + c] = val;
     };
     for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
@@ -1029,14 +1037,14 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                     if (writer[dd]) {
                         const T spc = a.tr.sqrtp[anc[dd]];
                         if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
-                        put(L + dd, (size_t)anc[dd], 2 * nx + t, spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv);
+                        put(L + dd, (size_t)anc[dd], 2 * nx + t, spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv, true);
                     }
                 }
-            for (int k = top; k < a.N; k += CHAIN_PF) {
+            for (int k = top; k < kEnd; k += CHAIN_PF) {
                 T dv[CHAIN_PF], uh2[CHAIN_PF], d0[CHAIN_PF];
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
                     uh2[j] = uhat[node * nu + t];
@@ -1044,12 +1052,12 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
-                    if (k + j < a.N) {
+                    if (k + j < kEnd) {
                         const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         run += dv[j];
                         const T uv = uh2[j] + run;
-                        if (a.writePrimal) a.u[node * nu + t] = uv;
-                        put(k + j - top, node, 2 * nx + t, sp * d0[j] * uv);
+                        if (a.writePrimal && primalWg) a.u[node * nu + t] = uv;
+                        put(k + j - top, node, 2 * nx + t, sp * d0[j] * uv, primalWg);
                     }
                 }
             }
@@ -1070,15 +1078,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                         const T spc = a.tr.sqrtp[anc[dd]];
                         a.bw[(size_t)anc[dd] * nx + j0] = bw;
                         if (a.writePrimal) a.x[(size_t)anc[dd] * nx + j0] = xr;
-                        put(L + dd, (size_t)anc[dd], j0, spc * dyAll[(size_t)k * ny + j0] * xr);
-                        put(L + dd, (size_t)anc[dd], nx + j0, spc * dyAll[(size_t)k * ny + nx + j0] * xr);
+                        put(L + dd, (size_t)anc[dd], j0, spc * dyAll[(size_t)k * ny + j0] * xr, true);
+                        put(L + dd, (size_t)anc[dd], nx + j0, spc * dyAll[(size_t)k * ny + nx + j0] * xr, true);
                     }
                 }
-            for (int k = top; k < a.N; k += CHAIN_PF) {
+            for (int k = top; k < kEnd; k += CHAIN_PF) {
                 T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
                     ev[j] = eb[node * nx + j0];
@@ -1087,13 +1095,13 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                 }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
-                    if (k + j < a.N) {
+                    if (k + j < kEnd) {
                         const size_t node = nodeTop + (size_t)(k + j - top) * a.K;
                         bw += dv[j];
                         xr += ev[j] + bw;
-                        if (a.writePrimal) a.x[node * nx + j0] = xr;
-                        put(k + j - top, node, j0, sp * d0[j] * xr);
-                        put(k + j - top, node, nx + j0, sp * d1[j] * xr);
+                        if (a.writePrimal && primalWg) a.x[node * nx + j0] = xr;
+                        put(k + j - top, node, j0, sp * d0[j] * xr, primalWg);
+                        put(k + j - top, node, nx + j0, sp * d1[j] * xr, primalWg);
                     }
                 }
             }
@@ -1101,7 +1109,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
     }
     int cwNode = -1, cwStage = 0;
     if (crownWriter) {      // sharded runs (foldCrown = 2): this workgroup writes crown node j (root -> j walk), row 0
-        const int j = (int)blockIdx.x - a.K;
+        const int j = (int)blockIdx.x - a.K * P;
         cwNode = j; cwStage = a.tr.stageOf[j];
         const int kj = cwStage;
         int pth[CROWN_MAX_DEPTH];
@@ -1123,7 +1131,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
                 if (a.writePrimal) a.u[(size_t)j * nu + t] = uv;
-                put(0, (size_t)j, 2 * nx + t, spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv);
+                put(0, (size_t)j, 2 * nx + t, spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv, true);
             } else {
                 const int j0 = t - nu;
                 T bw = a.bw0[j0], xr = a.curX[j0];
@@ -1136,15 +1144,16 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                     if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
                 a.bw[(size_t)j * nx + j0] = bw;
                 if (a.writePrimal) a.x[(size_t)j * nx + j0] = xr;
-                put(0, (size_t)j, j0, spj * dyAll[(size_t)kj * ny + j0] * xr);
-                put(0, (size_t)j, nx + j0, spj * dyAll[(size_t)kj * ny + nx + j0] * xr);
+                put(0, (size_t)j, j0, spj * dyAll[(size_t)kj * ny + j0] * xr, true);
+                put(0, (size_t)j, nx + j0, spj * dyAll[(size_t)kj * ny + nx + j0] * xr, true);
             }
         }
     }
     __syncthreads();
     // ---- phase B: the dual update of the rows' elements (dual_slot_use's arithmetic; LAZY = 0)
     const int vpn = ny / VN;
-    const int nRows = crownWriter ? 1 : L + top;
+    const int nOwn = r1 - r0;
+    const int nRows = crownWriter ? 1 : nOwn + (crownRowsWg ? top : 0);     // this workgroup's rows: its slice of the chain, then (part 0) the crown rows
     const T ln = (T)lnNext;
     DualAcc<T> r;
     constexpr int U = 3;
@@ -1158,7 +1167,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
         for (int u = 0; u < U; u++) {
             const int v = v0 + u * CHAIN_THREADS;
             const bool in = v < nRows * vpn;
-            const int row = in ? v / vpn : 0, j = in ? v - row * vpn : 0;
+            const int lr = in ? v / vpn : 0, j = in ? v - lr * vpn : 0;
+            const int row = crownWriter ? 0 : (lr < nOwn ? r0 + lr : L + (lr - nOwn));
             int node, stage;
             T spn;
             if (crownWriter) { node = cwNode; stage = cwStage; spn = a.tr.sqrtp[cwNode]; }
@@ -1205,7 +1215,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
             reinterpret_cast<VT *>(da.wnext)[ivv[u]] = wn;
             if (MATERIALIZE) { reinterpret_cast<VT *>(da.z)[ivv[u]] = z; reinterpret_cast<VT *>(da.res)[ivv[u]] = res; }
             if (UPLIN) {      // the next accelerated dual of this row, in place of its Hx (read above, by this thread only)
-                const int v = v0 + u * CHAIN_THREADS, row = v / vpn;
+                const int v = v0 + u * CHAIN_THREADS, row = v / vpn;      // (P = 1: local row = row)
                 *reinterpret_cast<VT *>(shx + (size_t)row * ny + cv[u]) = wn;
             }
         }

@@ -1341,17 +1341,20 @@ struct Ctx : CtxBase {
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
         }
         // sharded (foldCrown = 2): one more workgroup per replicated crown node, which writes that node while the chains are walked
-        const int downGrid = a.K + (foldCrown == 2 ? h_stageCum[cs] : 0);
+        const int nCrownWg = foldCrown == 2 ? h_stageCum[cs] : 0;
+        const int downGrid = a.K + nCrownWg;
         const size_t fuseLds = (size_t)d.N * ny * sizeof(T);      // Hx of the chain's N - cs nodes and of up to cs crown nodes
+        const int split = fuse_split();                           // workgroups per chain of the fused launch
+        const int fuseGrid = a.K * split + nCrownWg;
         // (every workgroup leaves one entry in d_partials: trees with more chains than it holds take the two launches)
-        if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024 && downGrid <= std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) {
+        if (fuseReq && foldCrown && phase == 0 && !hessianInput && fuseLds <= 64 * 1024 && fuseGrid <= std::max(ELT_MAX_BLOCKS, RN_DUAL_STAGE_MAX_BLOCKS)) {
             // structured mode, linear form, inner iteration of a batch: the NEXT sweep's chain walk rides in this launch (phase C) when that sweep
-            // has a crown launch to host the bookkeeping workgroup the chain walk otherwise carries
-            const bool upRide = a.lin && !fuseMat && foldCrown == 1 && (cs - 1 >= (foldRoot ? 1 : 0)) && knob[RN_KNOB_STRUCT_LINEAR] != 2;
-            if (upRide) { hipLaunchKernelGGL((k_down_chain_dual<T, false, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn); upDone = true; }
-            else if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
-            else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(downGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn);
-            fuseDone = true; mainPartials = downGrid;
+            // has a crown launch to host the bookkeeping workgroup the chain walk otherwise carries (one workgroup per chain only: the walk needs the chain's rows in one tile)
+            const bool upRide = a.lin && !fuseMat && foldCrown == 1 && split == 1 && (cs - 1 >= (foldRoot ? 1 : 0)) && knob[RN_KNOB_STRUCT_LINEAR] != 2;
+            if (upRide) { hipLaunchKernelGGL((k_down_chain_dual<T, false, true>), dim3(fuseGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn, 1); upDone = true; }
+            else if (fuseMat) hipLaunchKernelGGL((k_down_chain_dual<T, true>), dim3(fuseGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn, split);
+            else hipLaunchKernelGGL((k_down_chain_dual<T, false>), dim3(fuseGrid), dim3(CHAIN_THREADS), fuseLds, stream, a, foldCrown, fuseArgs, fuseLn, split);
+            fuseDone = true; mainPartials = fuseGrid;
         } else
         {
             // inner iterations of an optimistic batch whose dual update is the stage-tiled kernel reading w: the walk leaves the primal values and
@@ -1678,9 +1681,9 @@ struct Ctx : CtxBase {
     T *d_ckView = nullptr;       // the tuner's copy of the accelerated dual a getter would show (allocated when the one-shot transport becomes a candidate)
     // The forward walk and the dual update of the nodes it has walked in ONE launch (k_down_chain_dual): the optimistic batches ask for
     // it per iteration (fuseReq + the dual update's arguments), the sweep says whether it happened.
-    // Default BY SHAPE (round 6): on where one workgroup per chain (nearly) fills the chip -- chains >= 3/4 of the CUs: the whole 493-scenario
-    // tree -2.2 % per iteration dense, -5.6 % structured, a 1/2 shard -0.7 % -- off on small trees and smaller shards (62 workgroups of a 1/8 shard
-    // cannot keep as many bytes in flight as the stage-tiled kernel's grid: +2.7 %; profiles/r06_ab_fuse_by_shape.txt).  rn_set_fused_walk_dual(ctx, 0 / 1) or
+    // Default (round 6): on, with the number of workgroups per chain BY SHAPE (fuse_split) -- one where the chains (nearly) fill the chip: the whole
+    // 493-scenario tree -2.2 % per iteration dense, -5.6 % structured, a 1/2 shard -0.7 %; several on small trees and smaller shards (with one, the 62
+    // workgroups of a 1/8 shard cannot keep as many bytes in flight as the stage-tiled kernel's grid: +2.7 %; profiles/r06_ab_fuse_by_shape.txt).  rn_set_fused_walk_dual(ctx, 0 / 1) or
     // $RAPIDNET_FUSE_DOWN_DUAL = 0 / 1 (read when the context runs its first batch) force it either way; while the per-launch profiling
     // of rn_profile_enable is on, the dual update always runs as a launch of its own (the kernel north_star's roofline target names).
     bool fuseReq = false, fuseDone = false, fuseMat = false;
@@ -1690,12 +1693,24 @@ struct Ctx : CtxBase {
     int fuseMode = -2;     // -2: not decided yet ($RAPIDNET_FUSE_DOWN_DUAL, else by shape), -1: by shape, 0 / 1: forced
     int set_fused_walk_dual(int on) override { RN_CHECK(on >= -1 && on <= 1, RN_E_ARG, "rn_set_fused_walk_dual: 0, 1 or -1 (by shape)"); fuseMode = on; return RN_OK; }
     bool fuse_by_shape() const {      // (profiles/r06_ab_fuse_by_shape.txt: 493 chains -2.2 % dense / -5.6 % structured, 247 chains of a 1/2 shard -0.7 %, 124 chains: a tie,
-        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];      //  62 and 31 chains: +3-4 %)
+        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs];      //  62 and 31 chains: +3-4 % with ONE workgroup per chain)
         return 4 * K >= 3 * numCUs;
+    }
+    // workgroups per chain of the fused launch: one where the chains (nearly) fill the chip; otherwise up to four, as many as give every CU a
+    // workgroup, each updating the dual of its own slice of the chain's rows (k_down_chain_dual, P) -- the dual update of a 1/8 shard's 62 chains
+    // then runs on 248 workgroups instead of 62.  With that the one launch is never slower than the two (profiles/r06_ab_fuse_split.txt: 31-scenario
+    // tree -1 ... -3 % dense, -4.4 % structured; 1/4 shard -1.1 %; 1/8 shard -0.5 %; more than four redo too much of the walk).
+    // rn_debug_set_knob(RN_KNOB_FUSE_SPLIT): n > 0 forces n, 0 = one per chain and only by fuse_by_shape() (the rule before the split existed).
+    int fuse_split() const {
+        const int cs = chainStage, K = h_stageCum[cs + 1] - h_stageCum[cs], L = d.N - cs;
+        if (knob[RN_KNOB_FUSE_SPLIT] > 0) return std::max(1, std::min(knob[RN_KNOB_FUSE_SPLIT], L));
+        if (knob[RN_KNOB_FUSE_SPLIT] == 0 || fuse_by_shape()) return 1;
+        return std::max(1, std::min(std::min(L, 4), numCUs / std::max(K, 1)));
     }
     bool fuse_want() {
         if (fuseMode == -2) { const char *e = std::getenv("RAPIDNET_FUSE_DOWN_DUAL"); fuseMode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }
-        return (fuseMode == 1 || (fuseMode == -1 && fuse_by_shape())) && dualU != 0 && !prof;
+        const bool shapeSaysYes = knob[RN_KNOB_FUSE_SPLIT] == 0 ? fuse_by_shape() : true;
+        return (fuseMode == 1 || (fuseMode == -1 && shapeSaysYes)) && dualU != 0 && !prof;
     }
     unsigned int peerSeq = 0;     // sequence number of the last one-shot exchange (the same on every rank: they issue the same exchanges)
     unsigned int peer_slots() const { return (unsigned int)((size_t)(h_stageCum[cutStage] - h_stageCum[cutStage - 1]) * (d.nv + 2 * d.nx) + 2); }

@@ -66,6 +66,50 @@ def test_fused_walk_and_dual_update_sharded(monkeypatch, name, world, structured
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,structured,precision", [("medium", False, "f64"), ("ragged", True, "f64"), ("barcelona31", False, "f64"), ("small", False, "f32"),
+                                                       ("late", False, "f64")])
+def test_several_workgroups_per_chain_are_bitwise_the_two_launches(monkeypatch, name, structured, precision):
+    """k_down_chain_dual with P workgroups per chain (trees and shards with fewer chains than CUs: each walks the chain as far as its own rows reach and
+    updates the dual of those rows only; part 0 takes the crown rows, the last part stores the primal iterates): P = 1, 2, 3, the chain length (one
+    row per workgroup; requests beyond it are clamped) and the library's own choice -- iterates, histories, counters bit for bit those of the two launches."""
+    p = synth.make_problem(name)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "0")
+    h0, o0, c0 = run(p, structured, precision)
+    monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", "1")
+    for split in (1, 2, 3, 1000, None):
+        h1, o1, c1 = run(p, structured, precision, knobs=None if split is None else {"fuse_split": split})
+        assert c0 == c1, (split, c0, c1)
+        assert np.array_equal(h0, h1), split
+        for b in BUFS:
+            assert np.array_equal(o0[b], o1[b]), (split, b)
+
+
+@pytest.mark.parametrize("name,world,structured,split", [("medium", 2, False, 3), ("ragged", 3, True, 2), ("medium", 4, False, 1000)])
+def test_several_workgroups_per_chain_sharded(monkeypatch, name, world, structured, split):
+    """the same on shards (crown nodes written by workgroups of their own behind the K x P chain workgroups)"""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    out = []
+    for fused, knobs in (("0", None), ("1", {"fuse_split": split})):
+        monkeypatch.setenv("RAPIDNET_FUSE_DOWN_DUAL", fused)
+        rk = Ranks(p, world, 0, structured, knobs=knobs)
+        try:
+            def solve(s):
+                s.initialiseSmpcController(dh, ah)
+                s.apgReset()
+                return s.counters(), np.concatenate([s.apgIterate(20), s.apgIterate(5)])
+
+            res = rk.run(solve)
+            d = dims_of(rk.shards[0])
+            out.append((res[0][0], res[0][1], [rk.gathered(bid, d[dm]) for bid, _, dm in VECS]))
+        finally:
+            rk.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)
+
+
 def test_the_switch_can_be_flipped_between_batches():
     """rn_set_fused_walk_dual on a live context: batches with and without the fusion alternate and the iterates are those of a context
     that never fused (what bench.py's same-context A/B relies on)."""
