@@ -188,6 +188,9 @@ struct SweepArgs {
     // the few tree-table entries the crown steps start from, by value (a table load in front of the first batch of requests is one
     // more dependent round trip on the critical workgroup of the v / Lv launch): stageCum[1], stageCum[2], childStart[0], childCount[0]
     int s1, e1, rootC0, rootNc;
+    // the forward chain walks' crown paths as a per-chain table (Ctx::ensure_chain_anc): [K][CROWN_MAX_DEPTH = 8] ancestors of the chain's top, leaf-most
+    // first, bit 30 set where the chain is the node's first descendant chain (the one that writes the node); chain0 = first node of stage chainStage
+    const int *chainAnc; int chain0;
 };
 
 // ------------------------------------------------------------------------------------------------------

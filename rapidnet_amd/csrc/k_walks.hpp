@@ -745,13 +745,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
     // foldCrown = 2 (sharded runs): the grid has one more workgroup per crown node behind the K chain workgroups; it writes that
     // node (root -> node walk at the end of this kernel) while the chain workgroups walk their chains, instead of 18 of the 62
     // chain workgroups doing it after their own chain (15.2 -> see DESIGN.md section 6 for the measured effect)
+    // Request order (round 6): the first batch of the chain's rows needs nothing but the chain's number, so it is requested FIRST; the crown path
+    // comes from a per-chain table (SweepArgs::chainAnc: one 32-byte scalar load instead of a parent -> parent chase of dependent table loads),
+    // its rows are requested right behind the batch -- one round trip for both instead of three.
     const bool crownWriter = (int)blockIdx.x >= a.K;
     const int s = crownWriter ? 0 : (int)blockIdx.x;
     const int nx = a.nx, nu = a.nu, ny = a.ny, w = nu + nx;
     const int top = a.chainStage;
-    const int ntop = a.tr.stageCum[top] + s;
+    const int ntop = a.chain0 + s;
     const size_t nodeTop = (size_t)ntop;   // every stage >= c* has K nodes: node of stage k in this chain = nodeTop + (k - c*) K
-    const int par = a.tr.parent[ntop];
     const T sp = a.tr.sqrtp[ntop];   // p is constant along a chain
     const T *__restrict__ lvb = a.lvb;
     const T *__restrict__ uhat = a.uhat;
@@ -762,42 +764,18 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
     int anc[CROWN_MAX_DEPTH];
     bool writer[CROWN_MAX_DEPTH];
     if (foldCrown) {
-        int n = ntop;
-        bool first = true;
+        const int *ca = a.chainAnc + (size_t)s * CROWN_MAX_DEPTH;
 #pragma unroll
         for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) {
-            if (dd < top) {
-                const int p = a.tr.parent[n];
-                first = first && (a.tr.childStart[p] == n);
-                anc[dd] = p; writer[dd] = first && foldCrown == 1;
-                n = p;
-            } else { anc[dd] = 0; writer[dd] = false; }
+            const int e = ca[dd];
+            anc[dd] = e & 0x3fffffff; writer[dd] = dd < top && (e >> 30) != 0 && foldCrown == 1;
         }
     }
+    const int par = foldCrown ? 0 : a.tr.parent[ntop];
     for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
-            T run;
-            if (foldCrown) {
-                run = a.prevU[t] - a.prevUhat[t];
-                T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
-#pragma unroll
-                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uh[dd] = uhat[(size_t)anc[dd] * nu + t]; }
-#pragma unroll
-                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
-                    if (dd < top) {
-                        const int k = top - 1 - dd;                       // stage of anc[dd]
-                        const T uv = uh[dd] + run + lv[dd];               // same association as down_crown_node
-                        run = uv - uh[dd];                                 // what a child reads back: u_par - uhat_par
-                        if (writer[dd]) {
-                            const T spc = a.tr.sqrtp[anc[dd]];
-                            if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
-                            a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = UNSC ? uv : spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
-                        }
-                    }
-            } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-            for (int k = top; k < a.N; k += PF) {
-                T dv[PF], uh[PF], d0[PF];
+            T dv[PF], uh[PF], d0[PF];
+            auto request = [&](int k) {
 #pragma unroll
                 for (int j = 0; j < PF; j++) {
                     const int kk = k + j < a.N ? k + j : a.N - 1;
@@ -806,6 +784,29 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     uh[j] = uhat[node * nu + t];
                     d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + 2 * nx + t];
                 }
+            };
+            request(top);
+            T run;
+            if (foldCrown) {
+                run = a.prevU[t] - a.prevUhat[t];
+                T lv[CROWN_MAX_DEPTH], uhc[CROWN_MAX_DEPTH];
+#pragma unroll
+                for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uhc[dd] = uhat[(size_t)anc[dd] * nu + t]; }
+#pragma unroll
+                for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
+                    if (dd < top) {
+                        const int k = top - 1 - dd;                       // stage of anc[dd]
+                        const T uv = uhc[dd] + run + lv[dd];              // same association as down_crown_node
+                        run = uv - uhc[dd];                                // what a child reads back: u_par - uhat_par
+                        if (writer[dd]) {
+                            const T spc = a.tr.sqrtp[anc[dd]];
+                            if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
+                            a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = UNSC ? uv : spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
+                        }
+                    }
+            } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+            for (int k = top; k < a.N; k += PF) {
 #pragma unroll
                 for (int j = 0; j < PF; j++) {
                     if (k + j < a.N) {
@@ -816,22 +817,36 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         a.hx[node * ny + 2 * nx + t] = UNSC ? uv : sp * d0[j] * uv;
                     }
                 }
+                if (k + PF < a.N) request(k + PF);
             }
         } else {
             const int j0 = t - nu;
+            T dv[PF], ev[PF], d0[PF], d1[PF];
+            auto request = [&](int k) {
+#pragma unroll
+                for (int j = 0; j < PF; j++) {
+                    const int kk = k + j < a.N ? k + j : a.N - 1;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    dv[j] = lvb[node * w + nu + j0];
+                    ev[j] = eb[node * nx + j0];
+                    d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + j0];
+                    d1[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + nx + j0];
+                }
+            };
+            request(top);
             T bw, xr;
             if (foldCrown) {
                 bw = a.bw0[j0]; xr = a.curX[j0];
-                T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
+                T lv[CROWN_MAX_DEPTH], evc[CROWN_MAX_DEPTH];
 #pragma unroll
                 for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; ev[dd] = eb[(size_t)anc[dd] * nx + j0]; }
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; evc[dd] = eb[(size_t)anc[dd] * nx + j0]; }
 #pragma unroll
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd < top) {
                         const int k = top - 1 - dd;
                         bw = bw + lv[dd];
-                        xr = xr + ev[dd] + bw;
+                        xr = xr + evc[dd] + bw;
                         if (writer[dd]) {
                             const T spc = a.tr.sqrtp[anc[dd]];
                             a.bw[(size_t)anc[dd] * nx + j0] = bw;
@@ -845,16 +860,6 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                 xr = par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0];
             }
             for (int k = top; k < a.N; k += PF) {
-                T dv[PF], ev[PF], d0[PF], d1[PF];
-#pragma unroll
-                for (int j = 0; j < PF; j++) {
-                    const int kk = k + j < a.N ? k + j : a.N - 1;
-                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                    dv[j] = lvb[node * w + nu + j0];
-                    ev[j] = eb[node * nx + j0];
-                    d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + j0];
-                    d1[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + nx + j0];
-                }
 #pragma unroll
                 for (int j = 0; j < PF; j++) {
                     if (k + j < a.N) {
@@ -866,6 +871,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                         a.hx[node * ny + nx + j0] = UNSC ? xr : sp * d1[j] * xr;
                     }
                 }
+                if (k + PF < a.N) request(k + PF);
             }
         }
     }
@@ -969,7 +975,7 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // ride here as phase C -- the next accelerated dual of the chain's rows stays in the LDS tile in place of Hx, so the next sweep starts at its
 // crown launch: one dependent launch less per iteration (sk2 / rkq2 / beta are the same arrays in every sweep of the context).
 template <typename T, bool MATERIALIZE, bool UPLIN = false>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext, int P) {
+__global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext, int P) {
     typedef typename VecOf<T>::type VT;
     constexpr int VN = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -988,7 +994,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
     const int r0 = crownWriter ? 0 : (int)((long long)part * L / P), r1 = crownWriter ? 0 : (int)((long long)(part + 1) * L / P);
     const int kEnd = top + r1;                         // stages [top, kEnd) are walked
     const bool primalWg = part == P - 1, crownRowsWg = part == 0;
-    const int ntop = a.tr.stageCum[top] + s;
+    const int ntop = a.chain0 + s;
     const size_t nodeTop = (size_t)ntop;
     const T sp = a.tr.sqrtp[ntop];
     const T *__restrict__ lvb = a.lvb;
@@ -997,17 +1003,12 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
     const T *__restrict__ dyAll = a.tr.dy;
     int anc[CROWN_MAX_DEPTH];
     bool writer[CROWN_MAX_DEPTH];
-    {
-        int n = ntop;
-        bool first = true;
+    {      // the crown path from the per-chain table (k_down_chain: one scalar load instead of a chase of dependent ones)
+        const int *ca = a.chainAnc + (size_t)s * CROWN_MAX_DEPTH;
 #pragma unroll
         for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) {
-            if (dd < top) {
-                const int p = a.tr.parent[n];
-                first = first && (a.tr.childStart[p] == n);
-                anc[dd] = p; writer[dd] = first && foldCrown == 1 && !crownWriter && crownRowsWg;
-                n = p;
-            } else { anc[dd] = 0; writer[dd] = false; }
+            const int e = ca[dd];
+            anc[dd] = e & 0x3fffffff; writer[dd] = dd < top && (e >> 30) != 0 && foldCrown == 1 && !crownWriter && crownRowsWg;
         }
     }
     if (threadIdx.x < CROWN_MAX_DEPTH) {
@@ -1016,13 +1017,23 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
         for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++) if ((int)threadIdx.x == dd && writer[dd]) nd = anc[dd];
         sh_rowNode[threadIdx.x] = nd;
     }
-    // ---- phase A: the walk (k_down_chain, foldCrown 1 / 2), Hx into LDS
-    auto put = [&](int row, size_t node, int c, T val, bool store) {
-        shx[(size_t)row * ny + c] = val;
-        if (a.writePrimal && store) a.hx[node * ny + c] = val;
-    };
+    // ---- phase A: the walk (k_down_chain, foldCrown 1 / 2), the PRIMAL values (x | x | u) of the rows into LDS: phase B applies the scaling
+    // sqrt(p_i) d_k -- it has that factor in registers for the bounds anyway, the product is the same two roundings (k_down_chain UNSC) -- so the walk
+    // requests no preconditioner entries, and Hx, when it is asked for (writePrimal), is stored by the workgroup that updates the row
+    auto put = [&](int row, int c, T val) { shx[(size_t)row * ny + c] = val; };
     for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
+            T dv[CHAIN_PF], uh2[CHAIN_PF];
+            auto request = [&](int k) {
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    dv[j] = lvb[node * w + t];
+                    uh2[j] = uhat[node * nu + t];
+                }
+            };
+            if (kEnd > top) request(top);          // needs nothing but the chain's number: requested first (k_down_chain)
             T run = a.prevU[t] - a.prevUhat[t];
             T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
 #pragma unroll
@@ -1035,21 +1046,11 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                     const T uv = uh[dd] + run + lv[dd];
                     run = uv - uh[dd];
                     if (writer[dd]) {
-                        const T spc = a.tr.sqrtp[anc[dd]];
                         if (a.writePrimal) a.u[(size_t)anc[dd] * nu + t] = uv;
-                        put(L + dd, (size_t)anc[dd], 2 * nx + t, spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv, true);
+                        put(L + dd, 2 * nx + t, uv);
                     }
                 }
             for (int k = top; k < kEnd; k += CHAIN_PF) {
-                T dv[CHAIN_PF], uh2[CHAIN_PF], d0[CHAIN_PF];
-#pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
-                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                    dv[j] = lvb[node * w + t];
-                    uh2[j] = uhat[node * nu + t];
-                    d0[j] = dyAll[(size_t)kk * ny + 2 * nx + t];
-                }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k + j < kEnd) {
@@ -1057,12 +1058,24 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                         run += dv[j];
                         const T uv = uh2[j] + run;
                         if (a.writePrimal && primalWg) a.u[node * nu + t] = uv;
-                        put(k + j - top, node, 2 * nx + t, sp * d0[j] * uv, primalWg);
+                        put(k + j - top, 2 * nx + t, uv);
                     }
                 }
+                if (k + CHAIN_PF < kEnd) request(k + CHAIN_PF);
             }
         } else {
             const int j0 = t - nu;
+            T dv[CHAIN_PF], ev[CHAIN_PF];
+            auto request = [&](int k) {
+#pragma unroll
+                for (int j = 0; j < CHAIN_PF; j++) {
+                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
+                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
+                    dv[j] = lvb[node * w + nu + j0];
+                    ev[j] = eb[node * nx + j0];
+                }
+            };
+            if (kEnd > top) request(top);
             T bw = a.bw0[j0], xr = a.curX[j0];
             T lv[CROWN_MAX_DEPTH], ev0[CROWN_MAX_DEPTH];
 #pragma unroll
@@ -1075,24 +1088,13 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                     bw = bw + lv[dd];
                     xr = xr + ev0[dd] + bw;
                     if (writer[dd]) {
-                        const T spc = a.tr.sqrtp[anc[dd]];
                         a.bw[(size_t)anc[dd] * nx + j0] = bw;
                         if (a.writePrimal) a.x[(size_t)anc[dd] * nx + j0] = xr;
-                        put(L + dd, (size_t)anc[dd], j0, spc * dyAll[(size_t)k * ny + j0] * xr, true);
-                        put(L + dd, (size_t)anc[dd], nx + j0, spc * dyAll[(size_t)k * ny + nx + j0] * xr, true);
+                        put(L + dd, j0, xr);
+                        put(L + dd, nx + j0, xr);
                     }
                 }
             for (int k = top; k < kEnd; k += CHAIN_PF) {
-                T dv[CHAIN_PF], ev[CHAIN_PF], d0[CHAIN_PF], d1[CHAIN_PF];
-#pragma unroll
-                for (int j = 0; j < CHAIN_PF; j++) {
-                    const int kk = k + j < kEnd ? k + j : kEnd - 1;
-                    const size_t node = nodeTop + (size_t)(kk - top) * a.K;
-                    dv[j] = lvb[node * w + nu + j0];
-                    ev[j] = eb[node * nx + j0];
-                    d0[j] = dyAll[(size_t)kk * ny + j0];
-                    d1[j] = dyAll[(size_t)kk * ny + nx + j0];
-                }
 #pragma unroll
                 for (int j = 0; j < CHAIN_PF; j++) {
                     if (k + j < kEnd) {
@@ -1100,10 +1102,11 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                         bw += dv[j];
                         xr += ev[j] + bw;
                         if (a.writePrimal && primalWg) a.x[node * nx + j0] = xr;
-                        put(k + j - top, node, j0, sp * d0[j] * xr, primalWg);
-                        put(k + j - top, node, nx + j0, sp * d1[j] * xr, primalWg);
+                        put(k + j - top, j0, xr);
+                        put(k + j - top, nx + j0, xr);
                     }
                 }
+                if (k + CHAIN_PF < kEnd) request(k + CHAIN_PF);
             }
         }
     }
@@ -1131,7 +1134,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd <= kj) { uv = uh[dd] + run + lv[dd]; run = uv - uh[dd]; }
                 if (a.writePrimal) a.u[(size_t)j * nu + t] = uv;
-                put(0, (size_t)j, 2 * nx + t, spj * dyAll[(size_t)kj * ny + 2 * nx + t] * uv, true);
+                put(0, 2 * nx + t, uv);
             } else {
                 const int j0 = t - nu;
                 T bw = a.bw0[j0], xr = a.curX[j0];
@@ -1144,8 +1147,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                     if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
                 a.bw[(size_t)j * nx + j0] = bw;
                 if (a.writePrimal) a.x[(size_t)j * nx + j0] = xr;
-                put(0, (size_t)j, j0, spj * dyAll[(size_t)kj * ny + j0] * xr, true);
-                put(0, (size_t)j, nx + j0, spj * dyAll[(size_t)kj * ny + nx + j0] * xr, true);
+                put(0, j0, xr);
+                put(0, nx + j0, xr);
             }
         }
     }
@@ -1199,6 +1202,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
                 const T k = spv[u] * dyv[u][e];
                 const T lo = k * blov[u][e];
                 const T hi = (isXi && !isBox) ? bhiv[u][e] : k * bhiv[u][e];
+                hxv[u][e] = k * hxv[u][e];                 // Hx = sqrt(p_i) d_k (x | x | u): the walk left the primal value
                 const DualOut<T> o = dual_elem<T, false>(hxv[u][e], wv[u][e], lo, hi, ypv[u][e], da.lambda, da.invLambda, ln, (T)0);
                 yn[e] = o.yn; wn[e] = o.wn; z[e] = o.z; res[e] = o.res;
                 const double dd = counted ? (double)o.diff * (double)o.diff : 0.0;
@@ -1213,6 +1217,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain_dual(SweepArgs<T> 
             }
             reinterpret_cast<VT *>(da.ynew)[ivv[u]] = yn;
             reinterpret_cast<VT *>(da.wnext)[ivv[u]] = wn;
+            if (a.writePrimal) reinterpret_cast<VT *>(a.hx)[ivv[u]] = hxv[u];
             if (MATERIALIZE) { reinterpret_cast<VT *>(da.z)[ivv[u]] = z; reinterpret_cast<VT *>(da.res)[ivv[u]] = res; }
             if (UPLIN) {      // the next accelerated dual of this row, in place of its Hx (read above, by this thread only)
                 const int v = v0 + u * CHAIN_THREADS, row = v / vpn;      // (P = 1: local row = row)

@@ -602,7 +602,34 @@ struct Ctx : CtxBase {
         a.distTail = (carryTail && a.cutSums) ? d_cut + cut_tail_offset() : nullptr;
         a.thrX = penX / stepSize; a.thrS = penXs / stepSize; a.iterState = d_state;
         a.writePrimal = 1;
+        a.chain0 = h_stageCum[a.chainStage]; a.chainAnc = chainAncStage == a.chainStage ? d_chainAnc : nullptr;
         return a;
+    }
+    // The crown path of every chain as a table (SweepArgs::chainAnc; k_down_chain / k_down_chain_dual with foldCrown): built for the stage the chains
+    // start at -- the tree's own, or the cut stage of a shard -- the first time a sweep folds the crown into the forward walk, and again if that stage changes.
+    int *d_chainAnc = nullptr;
+    int chainAncStage = -1;
+    int ensure_chain_anc(int cs) {
+        if (chainAncStage == cs && d_chainAnc) return RN_OK;
+        RN_CHECK(cs >= 0 && cs <= CROWN_MAX_DEPTH && cs + 1 < (int)h_stageCum.size(), RN_E_STATE, "ensure_chain_anc: the crown is deeper than the folded walk supports");
+        const int K = h_stageCum[cs + 1] - h_stageCum[cs];
+        std::vector<int> tab((size_t)K * CROWN_MAX_DEPTH, 0);
+        for (int c = 0; c < K; c++) {
+            int n = h_stageCum[cs] + c;
+            bool first = true;
+            for (int dd = 0; dd < cs; dd++) {
+                const int p = h_parent[n];
+                first = first && h_childStart[p] == n;
+                tab[(size_t)c * CROWN_MAX_DEPTH + dd] = p | (first ? (1 << 30) : 0);
+                n = p;
+            }
+        }
+        int *nt = nullptr;
+        if (int rc = dalloc(&nt, tab.size())) return rc;
+        RN_HIP(hipMemcpyAsync(nt, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        RN_HIP(hipStreamSynchronize(stream));   // (pageable source; the previous table, if any, is freed with the context)
+        d_chainAnc = nt; chainAncStage = cs;
+        return RN_OK;
     }
     long long ntot() const { return (long long)d.nodes * ny; }
 
@@ -1336,6 +1363,7 @@ struct Ctx : CtxBase {
         // single GPU: the first descendant chain of a crown node writes it (1); sharded: workgroup 0 writes them all (2),
         // because a replicated crown node may have no chain on this rank while its Hx still feeds the replicated duals
         const int foldCrown = fold_crown_mode(cs, a.cutSums != nullptr);
+        if (foldCrown) { if (int rc = ensure_chain_anc(cs)) return rc; a.chainAnc = d_chainAnc; }
         if (!foldCrown) {
             if (fusedCrown) hipLaunchKernelGGL(k_down_crown_all<T>, dim3(1), dim3(CROWN_THREADS), 0, stream, a, cs);
             else for (int k = 0; k < cs; k++) hipLaunchKernelGGL(k_down_crown<T>, dim3(nk(k)), dim3(CHAIN_THREADS), 0, stream, a, k);
