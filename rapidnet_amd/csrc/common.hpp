@@ -191,6 +191,7 @@ struct SweepArgs {
     // the forward chain walks' crown paths as a per-chain table (Ctx::ensure_chain_anc): [K][CROWN_MAX_DEPTH = 8] ancestors of the chain's top, leaf-most
     // first, bit 30 set where the chain is the node's first descendant chain (the one that writes the node); chain0 = first node of stage chainStage
     const int *chainAnc; int chain0;
+    int cut0;         // first node of stage cutStage - 1 (the cut parents), by value
 };
 
 // ------------------------------------------------------------------------------------------------------

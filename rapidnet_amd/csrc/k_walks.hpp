@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_up_chain(SweepArgs<T> a, FinA
     const T *__restrict__ my = a.my;
     const T *__restrict__ qa = a.qa;
     // every stage >= c* has K nodes: the node of stage k in chain s is nodeTop + (k - c*) K -- no stage-table load per step
-    const size_t nodeTop = (size_t)a.tr.stageCum[top] + s;
+    const size_t nodeTop = (size_t)a.chain0 + s;      // (by value: no stage-table load in front of the first requests)
     for (int t = threadIdx.x; t < nv + nx; t += CHAIN_THREADS) {
         if (t < nv) {
             T rho = 0;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(UPCUT_THREADS) k_up_chain_cut(SweepArgs<T> a, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sh = reinterpret_cast<T *>(smem_raw);         // [slots][nv + 2 nx]
     const int nv = a.nv, nx = a.nx, w = nv + 2 * nx;
-    const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
+    const int node = a.cut0 + blockIdx.x;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     // lanesPer is a whole number of waves: the chain a wave works on is wave-uniform, and telling the compiler so keeps the node
     // indices and the stage-table loads on the scalar unit, as in k_up_chain
@@ -496,7 +496,7 @@ template <typename T>
 __device__ __forceinline__ void up_chain_lin_walk(const SweepArgs<T> &a, int s, const T *LDS, int tid, int nthreads) {
     const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, top = a.chainStage;
     const int W = nv + nx + nu, W2 = nv + 2 * nx + nu;
-    const size_t nodeTop = (size_t)a.tr.stageCum[top] + s;
+    const size_t nodeTop = (size_t)a.chain0 + s;      // (by value: no stage-table load in front of the first requests)
     const T *__restrict__ dy = a.tr.dy;
     const T sp = a.tr.sqrtp[nodeTop];                  // (a chain does not branch: one probability from its top to its leaf)
     auto wAt = [&](int kk, size_t node, int c) -> T { return LDS ? LDS[(size_t)(kk - top) * ny + c] : a.w[node * ny + c]; };
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(CUT_THREADS) k_cut_partial_sums(SweepArgs<T> a
             peer_gather_small<T>(a.peer, a.peerSeq, out, (int)tailIdx, (int)tailIdx + 2, threadIdx.x, 64, reinterpret_cast<IterState *>(a.iterState));
         return;
     }
-    const int node = a.tr.stageCum[a.cutStage - 1] + blockIdx.x;
+    const int node = a.cut0 + blockIdx.x;
     const int w = a.nv + 2 * a.nx;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
     for (int t = threadIdx.x; t < w; t += blockDim.x) {

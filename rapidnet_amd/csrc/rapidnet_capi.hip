@@ -603,6 +603,7 @@ struct Ctx : CtxBase {
         a.thrX = penX / stepSize; a.thrS = penXs / stepSize; a.iterState = d_state;
         a.writePrimal = 1;
         a.chain0 = h_stageCum[a.chainStage]; a.chainAnc = chainAncStage == a.chainStage ? d_chainAnc : nullptr;
+        a.cut0 = cutStage > 0 ? h_stageCum[cutStage - 1] : 0;
         return a;
     }
     // The crown path of every chain as a table (SweepArgs::chainAnc; k_down_chain / k_down_chain_dual with foldCrown): built for the stage the chains
