@@ -625,11 +625,14 @@ struct Ctx : CtxBase {
                 n = p;
             }
         }
-        int *nt = nullptr;
-        if (int rc = dalloc(&nt, tab.size())) return rc;
-        RN_HIP(hipMemcpyAsync(nt, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        RN_HIP(hipStreamSynchronize(stream));   // (pageable source; the previous table, if any, is freed with the context)
-        d_chainAnc = nt; chainAncStage = cs;
+        if (!d_chainAnc) {      // room for the widest stage, once (rn_create): a control step never allocates (the reference's leak check, SmpcController.cu:1593-1667)
+            int widest = 1;
+            for (size_t k = 0; k + 1 < h_stageCum.size(); k++) widest = std::max(widest, h_stageCum[k + 1] - h_stageCum[k]);
+            if (int rc = dalloc(&d_chainAnc, (size_t)widest * CROWN_MAX_DEPTH)) return rc;
+        }
+        RN_HIP(hipStreamSynchronize(stream));   // (a sweep in flight may still read the previous table)
+        RN_HIP(hipMemcpy(d_chainAnc, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        chainAncStage = cs;
         return RN_OK;
     }
     long long ntot() const { return (long long)d.nodes * ny; }
@@ -715,6 +718,7 @@ struct Ctx : CtxBase {
         if (int rc = upload_int(d_childStart, h_childStart)) return rc;
         if (int rc = upload_int(d_childCount, h_childCount)) return rc;
         if (int rc = upload_int(d_stageOf, h_stageOf)) return rc;
+        if (chainStage <= CROWN_MAX_DEPTH) { if (int rc = ensure_chain_anc(chainStage)) return rc; }
         const size_t n = nodes;
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd;
 #define DA(ptr, cnt) if (int rc = dalloc(&ptr, (size_t)(cnt))) return rc;
