@@ -503,7 +503,9 @@ __device__ __forceinline__ void up_chain_lin_walk(const SweepArgs<T> &a, int s, 
     // Components are dealt to the threads in WAVE-ALIGNED ranges -- [kappa, q | Bu | Bs], each padded to whole waves -- so that a wave runs one kind
     // of walk (a wave that straddles two kinds runs both, one after the other); the components beyond the workgroup's threads (the tail of Bs,
     // the cheapest kind: one array, one batch of loads) take a second trip.
-    const int kqW = (nx + 63) / 64 * 64, buW = (nu + 63) / 64 * 64, bsW = (nv + 63) / 64 * 64;
+    // (a.lin & 2: Bs_i -- the subtree sums of beta, which no iteration changes -- is not walked: its term of v_i is a constant of the control step,
+    //  SweepArgs::lin)
+    const int kqW = (nx + 63) / 64 * 64, buW = (nu + 63) / 64 * 64, bsW = (a.lin & 2) ? 0 : (nv + 63) / 64 * 64;
     for (int slot = tid; slot < kqW + buW + bsW; slot += nthreads) {
         int t;                                          // component in the order [Bs (nv) | kappa, q (nx) | Bu (nu)] of sk2
         if (slot < kqW) { if (slot >= nx) continue; t = nv + slot; }
@@ -588,7 +590,7 @@ __device__ __forceinline__ void up_crown_node_lin(const SweepArgs<T> &a, int sta
     const T sp = a.tr.sqrtp[node];
     const T *dy = a.tr.dy + (size_t)stage * ny;
     const T *wn = a.w + (size_t)node * ny;
-    for (int t = tid; t < W; t += nthreads) {
+    for (int t = tid + ((a.lin & 2) ? nv : 0); t < W; t += nthreads) {     // (a.lin & 2: the Bs columns are constants of the control step)
         if (t < nv || t >= nv + nx) {                   // Bs or Bu: one children sum
             const int col = t < nv ? t : t + nx;        // column in rkq2
             T sum = 0;
@@ -639,7 +641,8 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, 
     const int node = a.tr.stageCum[stage] + (int)blockIdx.x;
     const int nv = a.nv, nx = a.nx, nu = a.nu, ny = a.ny, W = nv + nx + nu, W2 = nv + 2 * nx + nu;
     const int c0 = a.tr.childStart[node], nc = a.tr.childCount[node];
-    const int wp = (W2 + 63) / 64 * 64;
+    const int cLo = (a.lin & 2) ? nv : 0;               // first column that is summed (a.lin & 2: the Bs columns are constants of the control step)
+    const int wp = (W2 - cLo + 63) / 64 * 64;
     const int parts = CROWN_THREADS / wp > 0 ? CROWN_THREADS / wp : 1;
     const int part = threadIdx.x / wp;
     const int tstep = wp < CROWN_THREADS ? wp : CROWN_THREADS;
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, 
     const T sp = a.tr.sqrtp[node];
     const T *dy = a.tr.dy + (size_t)stage * ny;
     const T *wn = a.w + (size_t)node * ny;
-    if (part < parts) for (int t = threadIdx.x % wp; t < W2; t += tstep) {
+    if (part < parts) for (int t = cLo + threadIdx.x % wp; t < W2; t += tstep) {
         T sum = 0;
         for (int c = part; c < nc; c += parts * CROWN_LIN_PF) {
             T r[CROWN_LIN_PF];
@@ -659,7 +662,7 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_up_crown_lin(SweepArgs<T> a, 
         sh[part * W2 + t] = sum;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < W; t += CROWN_THREADS) {
+    for (int t = cLo + threadIdx.x; t < W; t += CROWN_THREADS) {
         if (t < nv || t >= nv + nx) {
             const int col = t < nv ? t : t + nx;
             T sum = 0;

@@ -565,6 +565,12 @@ struct Ctx : CtxBase {
     // structured mode, linear form of the leaf-to-root recursion (k_walks.hpp, k_up_chain_lin): the operator [Rinv | T1 | T2] of the v product
     // (column-major padded, and in fragment order) and the running sums' buffers; allocated by the factor step of a structured context
     T *d_RT2p = nullptr, *d_RT2f = nullptr, *d_sk2 = nullptr, *d_rkq2 = nullptr;
+    // Bs_i = beta_i + sum_c Bs_c only changes with the affine terms (once per control step): its term of v_i, c_i = -Rinv Bs_i / (2 p_i), is computed by
+    // lin_const_refresh when they change and enters the v product as its epilogue operand -- the product itself is [T1 | T2] [q_i + kappa_i ; Bu_i],
+    // K = nx + nu instead of nv + nx + nu, and the walks leave the Bs columns alone.  rn_debug_set_knob(RN_KNOB_STRUCT_LINEAR, 3): Bs in every iteration's product.
+    T *d_T12p = nullptr, *d_T12f = nullptr, *d_vconst = nullptr;
+    bool linConstValid = false;
+    bool lin_const() const { return knob[RN_KNOB_STRUCT_LINEAR] != 3; }
     // the form applies to unsharded structured sweeps whose v / Lv slab (16 nodes x (nv + nx + nu) and 16 x nv values) fits a workgroup's 64 KB;
     // otherwise (the wide fp32 network) the structured sweep keeps its first product k_gemm_prep_m2
     bool lin_fits() const { return (size_t)16 * (slab_stride(pad4(d.nv + d.nx + d.nu)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024; }
@@ -827,12 +833,18 @@ struct Ctx : CtxBase {
                 if (int rc = dalloc(&d_RT2f, no)) return rc;
                 if (int rc = dalloc(&d_sk2, (size_t)d.nodes * (nv + nx + nu))) return rc;
                 if (int rc = dalloc(&d_rkq2, (size_t)d.nodes * (nv + 2 * nx + nu))) return rc;
+                if (int rc = dalloc(&d_T12p, (size_t)pad16(nv) * pad4(nx + nu))) return rc;
+                if (int rc = dalloc(&d_T12f, (size_t)pad16(nv) * pad4(nx + nu))) return rc;
+                if (int rc = dalloc(&d_vconst, (size_t)d.nodes * nv)) return rc;
             }
             std::vector<double> RT2((size_t)nv * (nv + nx + nu));
             std::copy(RTm.begin(), RTm.end(), RT2.begin());
             std::copy(T2.begin(), T2.end(), RT2.begin() + (size_t)nv * (nv + nx));
             if (int rc = upload_padded(d_RT2p, RT2.data(), nv, nv + nx + nu)) return rc;
             if (int rc = upload_fragments(d_RT2f, RT2.data(), nv, nv + nx + nu)) return rc;
+            if (int rc = upload_padded(d_T12p, RT2.data() + (size_t)nv * nv, nv, nx + nu)) return rc;       // [T1 | T2]: the columns behind Rinv
+            if (int rc = upload_fragments(d_T12f, RT2.data() + (size_t)nv * nv, nv, nx + nu)) return rc;
+            linConstValid = false;
         }
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
         if (int rc = upload_padded(d_Bp, s->matB, nx, nu)) return rc;
@@ -1176,6 +1188,24 @@ struct Ctx : CtxBase {
         return crownScratchVals;
     }
     static int wide_waves() { return std::min(RN_WIDE_THREADS / 64, 8); }
+    size_t crown_lin_lds(int lin) const {      // k_up_crown_lin's LDS: [parts][W2], parts as the kernel counts them
+        const int w2 = d.nv + 2 * d.nx + d.nu, span = w2 - ((lin & 2) ? d.nv : 0), wp = (span + 63) / 64 * 64;
+        return (size_t)std::max(1, CROWN_THREADS / wp) * w2 * sizeof(T);
+    }
+    // Structured mode, linear form: Bs of every node (one full leaf-to-root pass of the linear form: chain walks, crown stages, the root) and
+    // c_i = -Rinv Bs_i / (2 p_i) (one product with the first nv columns of [Rinv | T1 | T2]) -- when the affine terms have changed, i.e. once per control step.
+    int lin_const_refresh(const SweepArgs<T> &a0) {
+        SweepArgs<T> c = a0;
+        c.lin = 1;
+        const int cs = c.chainStage;
+        hipLaunchKernelGGL(k_up_chain_lin<T>, dim3(c.K), dim3(CHAIN_THREADS), 0, stream, c, FinArgs{});
+        for (int k = cs - 1; k >= 0; k--)
+            hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(h_stageCum[k + 1] - h_stageCum[k]), dim3(CROWN_THREADS), crown_lin_lds(1), stream, c, k, h_stageCum[k + 1] - h_stageCum[k], FinArgs{});
+        launch_gemm<EPI_V>(d_RT2p, d.nv, d.nv, d_sk2, d.nv + d.nx + d.nu, d_vconst, d.nv, nullptr, 0);
+        RN_HIP(hipGetLastError());
+        linConstValid = true;
+        return RN_OK;
+    }
     // (3) of the sweep: v_i and [L v_i ; B L v_i] for all nodes
     void launch_v_lv(const SweepArgs<T> &a, int foldRoot) {
         const int nx = d.nx, nu = d.nu, nv = d.nv;
@@ -1184,10 +1214,14 @@ struct Ctx : CtxBase {
         if (a.lin) gV = GemmArgs<T>{d_RT2p, nv, nv + nx + nu, pad16(nv), pad4(nv + nx + nu), a.sk2, nv + nx + nu, a.v, nv, nullptr, 0, d_prob, d.nodes, nullptr, d.nodes};
         if (!a.writePrimal) gV.out = nullptr;   // slab kernel only: v stays in LDS for the second product
         if (structured) gV.aux = nullptr;       // m1_i is folded into the v product (d_my's m1 half stays zero): the epilogue has nothing to fetch
+        if (a.lin & 2) {        // Bs's term is the constant c_i (lin_const_refresh): v_i = c_i - [T1 | T2] [q_i + kappa_i ; Bu_i] / (2 p_i); a Hessian sweep (beta = 0) has none
+            gV = GemmArgs<T>{d_T12p, nv, nx + nu, pad16(nv), pad4(nx + nu), a.sk2 + nv, nv + nx + nu, a.writePrimal ? a.v : nullptr, nv,
+                             a.beta == d_zero ? nullptr : d_vconst, nv, d_prob, d.nodes, nullptr, d.nodes};
+        }
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
-        if (frag_on()) { gV.Mf = a.lin ? d_RT2f : d_RTf; gL.Mf = d_LBLf; }
+        if (frag_on()) { gV.Mf = (a.lin & 2) ? d_T12f : (a.lin ? d_RT2f : d_RTf); gL.Mf = d_LBLf; }
         if (lds <= 64 * 1024) {
             const int nSlabs = (d.nodes + 15) / 16;
             // many slabs per CU: one workgroup per CU with CT slabs each, every A fragment (from L2) used CT times (k_gemm_vlv_wide)
@@ -1267,6 +1301,11 @@ struct Ctx : CtxBase {
             launch_gemm<EPI_Z>(d_Bp, nx, nu, d_uhat, nu, d_eb, nx, d_e, nx);            // eb_i = e_i + B uhat_i
             hipLaunchKernelGGL(k_bw0<T>, dim3(1), dim3(128), 0, stream, d_B, nx, nu, d_prevU, d_prevUhat, d_bw0);
             aux_dirty = false;
+            linConstValid = false;      // (the affine terms may have changed: beta)
+        }
+        if (a.lin && lin_const()) {
+            if (!hessianInput && !linConstValid) { if (int rc = lin_const_refresh(a)) return rc; }
+            a.lin = 3;              // the walks leave the Bs columns alone
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (phase != 2 && !a.lin) {      // (the structured mode's linear form has no product in front of the chain walks: class 0 stays empty)
@@ -1353,9 +1392,7 @@ struct Ctx : CtxBase {
                 }
                 if (a.lin) {
                     const bool host = linFin.partials != nullptr;       // (first crown launch of a sweep whose chain walk rode along)
-                    const int w2 = nv + 2 * nx + d.nu, wp2 = (w2 + 63) / 64 * 64;
-                    const size_t ldsLin = (size_t)std::max(1, CROWN_THREADS / wp2) * w2 * sizeof(T);
-                    hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k) + (host ? 1 : 0)), dim3(CROWN_THREADS), ldsLin, stream, a, k, nk(k), linFin);
+                    hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(nk(k) + (host ? 1 : 0)), dim3(CROWN_THREADS), crown_lin_lds(a.lin), stream, a, k, nk(k), linFin);
                     linFin = FinArgs{};
                 }
                 else hipLaunchKernelGGL(k_up_crown<T>, dim3(nk(k)), dim3(CROWN_THREADS), ldsCrown, stream, a, k);
