@@ -543,6 +543,30 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_vlv(GemmArgs<T> gV
 #endif
 }
 
+// Structured mode, linear form with the subtree sums of beta as a constant of the control step: v_i only ever feeds [L v_i ; B L v_i], so the two
+// products are ONE with the composite operator [L ; B L] [T1 | T2] ((nu + nx) x (nx + nu), formed by the host in fp64):
+//   [L v_i ; B L v_i] = [L ; B L] c_i - ([L ; B L] [T1 | T2]) [q_i + kappa_i ; Bu_i] / (2 p_i)
+// -- the first term a constant of the control step (GemmArgs::aux), the second one slab product with the v product's epilogue: no v tile, no barrier
+// between two products, fewer MFMAs (12 tiles x 45 k-steps against 7 x 45 + 12 x 25 on the Barcelona network).  v_i itself is an output only: the
+// iterations that store the primal iterates run its product as a launch of its own.  foldRoot (0 / 1) as in k_gemm_vlv.
+template <typename T, bool PIPE>
+__global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_comp(GemmArgs<T> g, int SB, SweepArgs<T> a, int foldRoot) {
+    extern __shared__ unsigned char gemm_smem[];
+    T *sB = reinterpret_cast<T *>(gemm_smem);   // [16][SB] slab of [q + kappa ; Bu]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    if (foldRoot == 1 && blockIdx.x == 0) {
+        up_crown_node_lin<T>(a, 0, 0, threadIdx.x, blockDim.x);
+        __threadfence_block();                   // same workgroup reads sk2 of node 0 back below (same CU, same L1)
+        __syncthreads();
+    }
+    const int node0 = blockIdx.x * 16;
+    const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
+    slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
+    __syncthreads();
+    slab_product<T, EPI_V, PIPE>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+}
+
 // The same two products for trees with MORE slabs than the chip has CUs (the 493-scenario tree: 679 slabs on 256 CUs).  There
 // k_gemm_vlv puts three workgroups on most CUs, and each of them streams the shared operators (RT: 124 KB, [L; BL]: 137 KB)
 // from L2 through the CU's one vector-memory pipe: 890 KB of A fragments per CU and launch, as long a stream as the fp64 MFMAs of

@@ -571,6 +571,10 @@ struct Ctx : CtxBase {
     T *d_T12p = nullptr, *d_T12f = nullptr, *d_vconst = nullptr;
     bool linConstValid = false;
     bool lin_const() const { return knob[RN_KNOB_STRUCT_LINEAR] != 3; }
+    // ... and since v_i then only feeds [L v_i ; B L v_i], the two products are one with the composite operator MC = [L ; B L] [T1 | T2] (k_gemm_comp);
+    // d_lvconst = [L ; B L] c_i.  RN_KNOB_STRUCT_LINEAR 4: the two products kept apart.
+    T *d_MCp = nullptr, *d_MCf = nullptr, *d_lvconst = nullptr;
+    bool lin_comp() const { return lin_const() && knob[RN_KNOB_STRUCT_LINEAR] != 4 && d_MCp != nullptr; }
     // the form applies to unsharded structured sweeps whose v / Lv slab (16 nodes x (nv + nx + nu) and 16 x nv values) fits a workgroup's 64 KB;
     // otherwise (the wide fp32 network) the structured sweep keeps its first product k_gemm_prep_m2
     bool lin_fits() const { return (size_t)16 * (slab_stride(pad4(d.nv + d.nx + d.nu)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024; }
@@ -811,8 +815,9 @@ struct Ctx : CtxBase {
             if (int rc = upload_padded(d_BLp, BL.data(), nv, nx + nu)) return rc;
             if (int rc = upload_fragments(d_BLf, BL.data(), nv, nx + nu)) return rc;
         }
+        std::vector<double> LBL((size_t)(nu + nx) * nv);
         {   // [L ; B L]  ((nu+nx) x nv) for the forward GEMM
-            std::vector<double> BLm((size_t)nx * nv), LBL((size_t)(nu + nx) * nv);
+            std::vector<double> BLm((size_t)nx * nv);
             h_gemm(false, false, nx, nv, nu, s->matB, nx, s->matL, nu, BLm.data());
             for (int j = 0; j < nv; j++) {
                 for (int i = 0; i < nu; i++) LBL[i + (size_t)j * (nu + nx)] = s->matL[i + (size_t)j * nu];
@@ -836,6 +841,9 @@ struct Ctx : CtxBase {
                 if (int rc = dalloc(&d_T12p, (size_t)pad16(nv) * pad4(nx + nu))) return rc;
                 if (int rc = dalloc(&d_T12f, (size_t)pad16(nv) * pad4(nx + nu))) return rc;
                 if (int rc = dalloc(&d_vconst, (size_t)d.nodes * nv)) return rc;
+                if (int rc = dalloc(&d_MCp, (size_t)pad16(nu + nx) * pad4(nx + nu))) return rc;
+                if (int rc = dalloc(&d_MCf, (size_t)pad16(nu + nx) * pad4(nx + nu))) return rc;
+                if (int rc = dalloc(&d_lvconst, (size_t)d.nodes * (nu + nx))) return rc;
             }
             std::vector<double> RT2((size_t)nv * (nv + nx + nu));
             std::copy(RTm.begin(), RTm.end(), RT2.begin());
@@ -844,6 +852,12 @@ struct Ctx : CtxBase {
             if (int rc = upload_fragments(d_RT2f, RT2.data(), nv, nv + nx + nu)) return rc;
             if (int rc = upload_padded(d_T12p, RT2.data() + (size_t)nv * nv, nv, nx + nu)) return rc;       // [T1 | T2]: the columns behind Rinv
             if (int rc = upload_fragments(d_T12f, RT2.data() + (size_t)nv * nv, nv, nx + nu)) return rc;
+            {   // MC = [L ; B L] [T1 | T2]: (nu + nx) x (nx + nu)
+                std::vector<double> MC((size_t)(nu + nx) * (nx + nu));
+                h_gemm(false, false, nu + nx, nx + nu, nv, LBL.data(), nu + nx, RT2.data() + (size_t)nv * nv, nv, MC.data());
+                if (int rc = upload_padded(d_MCp, MC.data(), nu + nx, nx + nu)) return rc;
+                if (int rc = upload_fragments(d_MCf, MC.data(), nu + nx, nx + nu)) return rc;
+            }
             linConstValid = false;
         }
         if (int rc = upload_padded(d_Lp, s->matL, nu, nv)) return rc;
@@ -1202,6 +1216,7 @@ struct Ctx : CtxBase {
         for (int k = cs - 1; k >= 0; k--)
             hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(h_stageCum[k + 1] - h_stageCum[k]), dim3(CROWN_THREADS), crown_lin_lds(1), stream, c, k, h_stageCum[k + 1] - h_stageCum[k], FinArgs{});
         launch_gemm<EPI_V>(d_RT2p, d.nv, d.nv, d_sk2, d.nv + d.nx + d.nu, d_vconst, d.nv, nullptr, 0);
+        if (d_MCp) launch_gemm<EPI_LV>(d_LBLp, d.nu + d.nx, d.nv, d_vconst, d.nv, d_lvconst, d.nu + d.nx, nullptr, 0);      // [L ; B L] c_i
         RN_HIP(hipGetLastError());
         linConstValid = true;
         return RN_OK;
@@ -1219,6 +1234,18 @@ struct Ctx : CtxBase {
                              a.beta == d_zero ? nullptr : d_vconst, nv, d_prob, d.nodes, nullptr, d.nodes};
         }
         GemmArgs<T> gL{d_LBLp, nu + nx, nv, pad16(nu + nx), pad4(nv), a.v, nv, a.lvb, nu + nx, nullptr, 0, d_prob, d.nodes};
+        if ((a.lin & 2) && lin_comp()) {      // one product with the composite operator (k_gemm_comp); v_i, when it is stored, by a launch of its own
+            const bool hess = a.beta == d_zero;
+            GemmArgs<T> gC{d_MCp, nu + nx, nx + nu, pad16(nu + nx), pad4(nx + nu), a.sk2 + nv, nv + nx + nu, a.lvb, nu + nx,
+                           hess ? nullptr : d_lvconst, nu + nx, d_prob, d.nodes, nullptr, d.nodes};
+            if (frag_on()) gC.Mf = d_MCf;
+            const int SBc = slab_stride(gC.kp), nSlabs = (d.nodes + 15) / 16;
+            const int nwc = slab_waves((nu + nx + 15) / 16, gC.kp / 4, 0, 0);
+            if (few_slabs()) hipLaunchKernelGGL((k_gemm_comp<T, true>), dim3(nSlabs), dim3(64 * nwc), (size_t)16 * SBc * sizeof(T), stream, gC, SBc, a, foldRoot);
+            else hipLaunchKernelGGL((k_gemm_comp<T, false>), dim3(nSlabs), dim3(64 * nwc), (size_t)16 * SBc * sizeof(T), stream, gC, SBc, a, foldRoot);
+            if (a.writePrimal) launch_gemm<EPI_V>(d_T12p, nv, nx + nu, a.sk2 + nv, nv + nx + nu, a.v, nv, hess ? nullptr : d_vconst, nv);
+            return;
+        }
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
         const size_t lds = (size_t)16 * (SB + SV) * sizeof(T);
         if (frag_on()) { gV.Mf = (a.lin & 2) ? d_T12f : (a.lin ? d_RT2f : d_RTf); gL.Mf = d_LBLf; }

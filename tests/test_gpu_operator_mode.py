@@ -141,7 +141,9 @@ def test_linear_form_of_the_structured_sweep(name, precision, tol):
     o = Oracle(p["network"], p["tree"], p["config"], precision=precision, alias_operators=name not in ("late", "horizon1", "horizon2"))
     o.initialise(dh, ah)
     runs = []
-    for lin in (1, 0, 3):      # the linear form (the subtree sums of beta as a constant of the control step), the form with the first product, the linear form with beta walked every iteration
+    # the linear form as it ships (the subtree sums of beta a constant of the control step, one product with the composite operator), the form with the
+    # first product, the linear form with beta walked every iteration, and the constant with v / [Lv; BLv] as two products
+    for lin in (1, 0, 3, 4):
         s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", precision=precision, knobs={"struct_linear": lin})
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
@@ -160,6 +162,8 @@ def test_linear_form_of_the_structured_sweep(name, precision, tol):
         assert relmax(hx, o.get("primalXi")) < tol
     assert relmax(runs[0][1]["x"], runs[1][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
     assert relmax(runs[0][1]["x"], runs[2][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
+    assert relmax(runs[0][1]["x"], runs[3][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
+    assert relmax(runs[0][1]["v"], runs[3][1]["v"]) < (1e-10 if precision == "f64" else 2e-4)      # v_i by its own launch in the iterations that store it
 
 
 def test_linear_form_launches_no_first_product():
