@@ -15,7 +15,9 @@ namespace rn {
 //   EPI_V : v_i  = m1_i - acc / (2 p_i)        M = [Rinv | Rinv Bbt], in = [s_i; kappa_i]     (:604-623)
 //   EPI_LV: lv_i = acc                          M = L,  in = v_i                                (:692,:701,:727)
 //   EPI_Z : z_i  = e_i + acc                    M = B,  in = u_i                                (:695,:715,:736)
-enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2 };   // EPI_LV is also used for the structured m2_i = [Bbt | L'] [a_i; b_i]
+enum { EPI_V = 0, EPI_LV = 1, EPI_Z = 2, EPI_VT = 3 };   // EPI_LV is also used for the structured m2_i = [Bbt | L'] [a_i; b_i]; EPI_VT: EPI_V's epilogue on a product
+                                                          // that multiplies transposed (slab kernels: results leave as whole lines; k_gemm_comp)
+#define RN_EPI_IS_V(EPI) ((EPI) == EPI_V || (EPI) == EPI_VT)
 template <typename T>
 struct GemmArgs {
     const T *M; int m, k;        // logical m x k; stored zero-padded, col-major, mp x kp with mp % 64 == 0, kp % (4 * RN_SLAB_KU) == 0
@@ -173,7 +175,7 @@ constexpr int SLAB_MAX_WAVES = RN_SLAB_MAX_WAVES;
 #ifndef RN_SLAB_T
 #define RN_SLAB_T 2
 #endif
-#define RN_SLAB_TR(EPI) (RN_SLAB_T == 1 || (RN_SLAB_T == 2 && (EPI) == EPI_LV))
+#define RN_SLAB_TR(EPI) (RN_SLAB_T == 1 || (EPI) == EPI_VT || (RN_SLAB_T == 2 && (EPI) == EPI_LV))
 #ifndef RN_SLAB_KU
 #define RN_SLAB_KU 4   // k-steps per group of operands; the operators' K is stored padded to whole groups (host: pad_k).  (Groups of 8 for the waves that own
                        // one tile -- the v product: 7 tiles on 8 waves -- were measured in round 6: 29.6 against 28.8 us dense, 41.7 against 41.1 us in the
@@ -343,7 +345,7 @@ __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T (&scale)[4], const 
         for (int reg = 0; reg < 4; reg++) {
             const int node = node0 + Mfma16<T>::row(lane, reg);
             const int nodeC = node < g.nodes ? node : g.nodes - 1;
-            scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+            scale[reg] = RN_EPI_IS_V(EPI) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
 #pragma unroll
             for (int j = 0; j < TG; j++) {
                 const int gr = (t0 + ts * j) * 16 + (lane & 15);
@@ -355,7 +357,7 @@ __device__ __forceinline__ void slab_aux(T (&auxv)[TG][4], T (&scale)[4], const 
     const int node = node0 + (lane & 15);
     const int nodeC = node < g.nodes ? node : g.nodes - 1;
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) scale[reg] = (EPI == EPI_V) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
+    for (int reg = 0; reg < 4; reg++) scale[reg] = RN_EPI_IS_V(EPI) ? (T)(-0.5) / g.prob[nodeC] : (T)0;
 #pragma unroll
     for (int j = 0; j < TG; j++)
 #pragma unroll
@@ -378,7 +380,7 @@ __device__ __forceinline__ void slab_store(const typename Mfma16<T>::acc_t (&acc
             const int node = node0 + ln;
             const bool nodeOk = node < g.nodes;
             T r = acc[j][reg];
-            if (EPI == EPI_V) r = auxv[j][reg] + scale[reg] * r;
+            if (RN_EPI_IS_V(EPI)) r = auxv[j][reg] + scale[reg] * r;
             if (EPI == EPI_Z) r = auxv[j][reg] + r;
             const bool live = t < tiles && gr < g.m;
             if (g.out && live && nodeOk) g.out[(size_t)node * g.ldout + gr] = r;   // out == nullptr: the result only lives in sOut
@@ -564,7 +566,10 @@ __global__ void __launch_bounds__(64 * SLAB_MAX_WAVES) k_gemm_comp(GemmArgs<T> g
     const int cnt = g.nodes - node0 < 16 ? g.nodes - node0 : 16;
     slab_load<T>(sB, SB, g.in, g.ldin, g.k, g.kp, node0, cnt, wave, nw, lane);
     __syncthreads();
-    slab_product<T, EPI_V, PIPE>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
+#ifndef RN_COMP_T
+#define RN_COMP_T 1
+#endif
+    slab_product<T, RN_COMP_T ? EPI_VT : EPI_V, PIPE>(g, sB, SB, node0, wave, nw, lane, nullptr, 0);
 }
 
 // The same two products for trees with MORE slabs than the chip has CUs (the 493-scenario tree: 679 slabs on 256 CUs).  There
