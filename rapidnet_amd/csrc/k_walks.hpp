@@ -977,6 +977,9 @@ __global__ void __launch_bounds__(CROWN_THREADS) k_down_crown_all(SweepArgs<T> a
 // UPLIN (structured mode, linear form; inner iterations of a batch): the chain's leaf-to-top running sums of the NEXT iteration (k_up_chain_lin)
 // ride here as phase C -- the next accelerated dual of the chain's rows stays in the LDS tile in place of Hx, so the next sweep starts at its
 // crown launch: one dependent launch less per iteration (sk2 / rkq2 / beta are the same arrays in every sweep of the context).
+#ifndef RN_FUSE_U
+#define RN_FUSE_U 3     // 16-byte vectors per thread and pass of phase B
+#endif
 template <typename T, bool MATERIALIZE, bool UPLIN = false>
 __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<T> a, int foldCrown, DualArgs<T> da, double lnNext, int P) {
     typedef typename VecOf<T>::type VT;
@@ -1162,7 +1165,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
     const int nRows = crownWriter ? 1 : nOwn + (crownRowsWg ? top : 0);     // this workgroup's rows: its slice of the chain, then (part 0) the crown rows
     const T ln = (T)lnNext;
     DualAcc<T> r;
-    constexpr int U = 3;
+    constexpr int U = RN_FUSE_U;
     for (int v0 = threadIdx.x; v0 < nRows * vpn; v0 += U * CHAIN_THREADS) {
         VT hxv[U], wv[U], ypv[U], dyv[U], blov[U], bhiv[U];
         T spv[U];
