@@ -87,7 +87,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "error" not in sm and sm["value"] > 4 * d["value"], sm.get("value")
     if ts["measured_in_this_run"]:
         assert "error" not in sm["mfma"], sm["mfma"]
-        assert 0.05 < sm["mfma_busy_frac"] < 1.0 and any(k.startswith("k_gemm_vlv") for k in sm["mfma"]["kernels"]), sm["mfma"]
+        assert 0.05 < sm["mfma_busy_frac"] < 1.0 and any(k.startswith("k_gemm_comp") for k in sm["mfma"]["kernels"]), sm["mfma"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
