@@ -211,3 +211,36 @@ def test_chain_walk_riding_in_the_fused_walk_and_dual_update(name, precision):
         assert np.array_equal(runs[0][1][nm], runs[1][1][nm]), nm
         assert relmax(runs[0][1][nm], o.get(nm)) < tol, nm
     assert np.abs(runs[0][0] - ho).max() <= tol * np.abs(ho).max()
+
+
+@pytest.mark.parametrize("name", ["medium", "ragged", "barcelona31"])
+def test_constants_of_the_control_step_follow_the_affine_terms(name):
+    """Structured mode keeps the subtree sums of beta and their share of v_i / [L v_i; B L v_i] as constants of the control step (Ctx::lin_const_refresh).
+    They must follow every way the affine terms can change: a write to beta through rn_set between two batches, a new control step
+    (eliminateInputDistubanceCoupling with another forecast), a new state (updateStateControl) -- against a dense context that is given exactly the
+    same calls, iterate by iterate; and a context in the form that walks beta every iteration (rn_debug_set_knob struct_linear = 3)."""
+    p = synth.make_problem(name)
+    dh, ah = synth.forecast_at(p["forecast"], 0)
+    dh1, ah1 = synth.forecast_at(p["forecast"], 1)
+    ctx = [capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured"),
+           capi.Solver(p["network"], p["tree"], p["config"], operator_mode="dense"),
+           capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", knobs={"struct_linear": 3})]
+    outs = []
+    for s in ctx:
+        s.initialiseSmpcController(dh, ah)
+        s.apgReset()
+        h = [s.apgIterate(20)]
+        s.set(capi.BUF_BETA, 1.3 * s.get(capi.BUF_BETA))            # the affine term itself, by hand
+        h.append(s.apgIterate(20))
+        s.eliminateInputDistubanceCoupling(dh1, ah1)                 # the next control step's forecast
+        s.apgReset()
+        h.append(s.apgIterate(20))
+        s.updateStateControl(0.9 * np.asarray(p["config"]["currentX"], dtype=float).ravel(), np.asarray(p["config"]["prevU"], dtype=float).ravel(),
+                             np.asarray(p["config"]["prevDemand"], dtype=float).ravel())
+        h.append(s.apgIterate(20))
+        outs.append((np.concatenate(h), s.get(capi.BUF_X), s.get(capi.BUF_U), s.get(capi.BUF_V)))
+        s.close()
+    for k in (1, 2):
+        assert np.abs(outs[0][0] - outs[k][0]).max() <= 1e-9 * np.abs(outs[k][0]).max(), k
+        for a, b in zip(outs[0][1:], outs[k][1:]):
+            assert relmax(a, b) < 1e-9, k
