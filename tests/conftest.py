@@ -135,6 +135,14 @@ class _FullSizeOracle:
 _fullsize_oracle = _FullSizeOracle()
 
 
+def pytest_collection_modifyitems(session, config, items):
+    """the test that collects the full-size oracle's 100 s background run goes last: by then the run has finished behind the other tests
+    (in file order it came up after ~90 s and waited for the rest)"""
+    last = [it for it in items if "test_500_iterations_against_the_oracle_at_full_size" in it.nodeid]
+    if last:
+        items[:] = [it for it in items if it not in last] + last
+
+
 def pytest_collection_finish(session):
     if any("test_500_iterations_against_the_oracle_at_full_size" in item.nodeid for item in session.items) and not session.config.option.collectonly:
         _fullsize_oracle.start()
@@ -143,3 +151,13 @@ def pytest_collection_finish(session):
 @pytest.fixture(scope="session")
 def fullsize_oracle():
     return _fullsize_oracle.result()
+
+
+def run_pair(fa, fb):
+    """two CPU-oracle runs side by side (the oracle's C code runs without the GIL, every Oracle instance owns its state): the base run and the
+    perturbed run of the long-run parity tests, which otherwise keep the GPU box waiting for twice their time"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(2) as ex:
+        a, b = ex.submit(fa), ex.submit(fb)
+        return a.result(), b.result()

@@ -10,6 +10,7 @@ import pytest
 
 from oracle.oracle import Oracle
 from rapidnet_amd import capi, synth
+from conftest import run_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -420,8 +421,7 @@ def test_reference_fixture_500_iterations(ref_fixture, capsys):
     names = ("x", "u", "v", "updXi", "updPsi", "xi", "psi", "primalXi", "dualXi", "resPsi")
     bids = {"x": capi.BUF_X, "u": capi.BUF_U, "v": capi.BUF_V, "updXi": capi.BUF_UPD_XI, "updPsi": capi.BUF_UPD_PSI, "xi": capi.BUF_XI,
             "psi": capi.BUF_PSI, "primalXi": capi.BUF_PRIMAL_XI, "dualXi": capi.BUF_DUAL_XI, "resPsi": capi.BUF_RES_PSI}
-    base = _oracle_checkpoints(f, dh, ah, 0.0, names)
-    pert = _oracle_checkpoints(f, dh, ah, 1e-13, names)
+    base, pert = run_pair(lambda: _oracle_checkpoints(f, dh, ah, 0.0, names), lambda: _oracle_checkpoints(f, dh, ah, 1e-13, names))
     s = capi.Solver(f["network"], f["tree"], f["config"])
     s.initialiseSmpcController(dh, ah)
     s.apgReset()
@@ -452,8 +452,7 @@ def test_barcelona31_500_iterations_within_1e8(capsys):
     dh, ah = synth.forecast_at(p["forecast"], 0)
     names = ("x", "u", "updXi", "updPsi")
     bids = {"x": capi.BUF_X, "u": capi.BUF_U, "updXi": capi.BUF_UPD_XI, "updPsi": capi.BUF_UPD_PSI}
-    base = _oracle_checkpoints(p, dh, ah, 0.0, names)
-    pert = _oracle_checkpoints(p, dh, ah, 1e-13, names)
+    base, pert = run_pair(lambda: _oracle_checkpoints(p, dh, ah, 0.0, names), lambda: _oracle_checkpoints(p, dh, ah, 1e-13, names))
     s = capi.Solver(p["network"], p["tree"], p["config"])
     s.initialiseSmpcController(dh, ah)
     s.apgReset()
@@ -479,8 +478,7 @@ def test_rounding_sensitivity_bounds_long_runs(capsys):
     within the oracle's OWN rounding sensitivity at every checkpoint up to 500, and within 1e-9 early on."""
     p = synth.make_problem("barcelona31_infeasible")
     dh, ah = synth.forecast_at(p["forecast"], 0)
-    base = _oracle_checkpoints(p, dh, ah, 0.0, ("x",))
-    pert = _oracle_checkpoints(p, dh, ah, 1e-15, ("x",))
+    base, pert = run_pair(lambda: _oracle_checkpoints(p, dh, ah, 0.0, ("x",)), lambda: _oracle_checkpoints(p, dh, ah, 1e-15, ("x",)))
     s = capi.Solver(p["network"], p["tree"], p["config"])
     s.initialiseSmpcController(dh, ah)
     s.apgReset()

@@ -98,8 +98,8 @@ def test_hip_path_on_reference_held_data(capsys):
     st = int(g["stride"][0])
     dh, ah = forecast_at(p["forecast"], 0)
     cks = (1, 10, 50, 100, 200, 300, 400, 500)
-    base, ohist = oracle_checkpoints(p, dh, ah, 0.0, cks)
-    pert, _ = oracle_checkpoints(p, dh, ah, 1e-13, cks)
+    from conftest import run_pair
+    (base, ohist), (pert, _) = run_pair(lambda: oracle_checkpoints(p, dh, ah, 0.0, cks), lambda: oracle_checkpoints(p, dh, ah, 1e-13, cks))
     bids = {"x": capi.BUF_X, "u": capi.BUF_U, "updXi": capi.BUF_UPD_XI, "updPsi": capi.BUF_UPD_PSI, "dualXi": capi.BUF_DUAL_XI}
     s = capi.Solver(p["network"], p["tree"], p["config"])
     s.initialiseSmpcController(dh, ah)
