@@ -64,7 +64,7 @@ enum {
     RN_KNOB_LS_SEQUENTIAL = 9,     /* global FBE / NAMA: 1 = trial-by-trial line search instead of the batched candidates */
     RN_KNOB_VALUE_MFMA = 10,       /* global FBE / NAMA: 0 = the value's primal terms on the vector ALUs */
     RN_KNOB_TUNE_BIAS_US = 11,     /* rn_exchange_autotune, test of the selection: microseconds per iteration added to THIS rank's measured one-shot time */
-    RN_KNOB_STRUCT_LINEAR = 12,    /* structured mode: 0 = the first product k_gemm_prep_m2 in front of the chain walks instead of the linear form (k_up_chain_lin); 2 = the linear form without the chain walk riding in the fused walk + dual update; 3 = the linear form with the subtree sums of beta walked and multiplied in every iteration instead of once per control step; 4 = that constant, but v_i and [L v_i; B L v_i] as two products instead of one with the composite operator */
+    RN_KNOB_STRUCT_LINEAR = 12,    /* structured mode: 0 = the first product k_gemm_prep_m2 in front of the chain walks instead of the linear form (k_up_chain_lin); 2 = the linear form without the chain walk riding in the fused walk + dual update; 3 = the linear form with the subtree sums of beta walked and multiplied in every iteration instead of once per control step; 4 = that constant, but v_i and [L v_i; B L v_i] as two products instead of one with the composite operator; 5 = the composite operator without the forward walk's affine terms in its constant operand */
     RN_KNOB_FUSE_SPLIT = 13,       /* fused forward walk + dual update: workgroups per chain (1 .. chain length); 0 = one per chain and only where the chains fill 3/4 of the CUs (round 6's first rule) */
     RN_KNOB_COUNT = 14
 };

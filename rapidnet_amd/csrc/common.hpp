@@ -165,7 +165,7 @@ struct SweepArgs {
     T *rkq;           // [node][nv+2nx] rho_i, kappa_i, q_i (kept for chain tops and crown nodes)
     // structured mode, LINEAR form of the leaf-to-root recursion (lin != 0; k_up_chain_lin, k_walks.hpp): the running sums are taken of the
     // INPUTS of the shared-operator products instead of their outputs, so that no product sits in front of the recursion at all
-    int lin;          // 0: off; bit 0: the linear form; bit 1: Bs_i is not walked (a constant of the control step: Ctx::lin_const_refresh)
+    int lin;          // 0: off; bit 0: the linear form; bit 1: Bs_i is not walked (a constant of the control step: Ctx::lin_const_refresh); bit 2: lvb carries the forward walk's affine terms (no uhat / eb requests)
     T *sk2;           // [node][nv+nx+nu]  Bs_i | q_i + kappa_i | Bu_i : the v product's input ([Rinv | T1 | T2] applied to it)
     T *rkq2;          // [node][nv+2nx+nu] Bs_i | kappa_i | q_i | Bu_i  (chain tops and crown nodes: what a parent sums)
     T *v, *lvb;       // [node][nv] ; [node][nu+nx] = [L v_i ; B L v_i]

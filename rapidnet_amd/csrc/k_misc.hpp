@@ -193,4 +193,20 @@ __global__ void k_clamp_vec(T *u, const T *lo, const T *hi, int n) {   // projec
 }
 
 
+// Structured mode, composite operator (k_gemm_comp): the forward walk's affine terms join the product's constant operand, so that the walk's running
+// sums of [L v_i ; B L v_i] are u_i and x_i - x_anc themselves and the walk requests neither uhat nor eb (SweepArgs::lin bit 2):
+//   lvconst_i[0 .. nu) += uhat_i - uhat_anc   (root: - prevUhat) ;   lvconst_i[nu .. nu + nx) += eb_i - eb_anc   (root: eb_0)
+template <typename T>
+__global__ void k_fold_affine(T *lvconst, const T *uhat, const T *eb, const T *prevUhat, const int *parent, int nodes, int nu, int nx) {
+    const int w = nu + nx;
+    const long long n = (long long)nodes * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int node = (int)(i / w), t = (int)(i % w), par = parent[node];
+        T add;
+        if (t < nu) add = uhat[(size_t)node * nu + t] - (par < 0 ? prevUhat[t] : uhat[(size_t)par * nu + t]);
+        else { const int j = t - nu; add = eb[(size_t)node * nx + j] - (par < 0 ? (T)0 : eb[(size_t)par * nx + j]); }
+        lvconst[i] += add;
+    }
+}
+
 }  // namespace rn

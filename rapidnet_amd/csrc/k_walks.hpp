@@ -775,6 +775,9 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
         }
     }
     const int par = foldCrown ? 0 : a.tr.parent[ntop];
+    // a.lin & 4 (structured mode, composite operator): the affine terms uhat_i - uhat_anc, eb_i - eb_anc are part of the product's constant operand
+    // (Ctx::lin_const_refresh), so lvb's running sums ARE u_i and B u_i + e-sums: the walk requests neither uhat nor eb
+    const bool AF = (a.lin & 4) != 0;
     for (int t = crownWriter ? w : (int)threadIdx.x; t < w; t += CHAIN_THREADS) {
         if (t < nu) {
             T dv[PF], uh[PF], d0[PF];
@@ -784,18 +787,18 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     const int kk = k + j < a.N ? k + j : a.N - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
-                    uh[j] = uhat[node * nu + t];
+                    uh[j] = AF ? (T)0 : uhat[node * nu + t];
                     d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + 2 * nx + t];
                 }
             };
             request(top);
             T run;
             if (foldCrown) {
-                run = a.prevU[t] - a.prevUhat[t];
+                run = AF ? a.prevU[t] : a.prevU[t] - a.prevUhat[t];
                 T lv[CROWN_MAX_DEPTH], uhc[CROWN_MAX_DEPTH];
 #pragma unroll
                 for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uhc[dd] = uhat[(size_t)anc[dd] * nu + t]; }
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uhc[dd] = AF ? (T)0 : uhat[(size_t)anc[dd] * nu + t]; }
 #pragma unroll
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd < top) {
@@ -808,7 +811,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                             a.hx[(size_t)anc[dd] * ny + 2 * nx + t] = UNSC ? uv : spc * dyAll[(size_t)k * ny + 2 * nx + t] * uv;
                         }
                     }
-            } else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
+            } else if (AF) run = par < 0 ? a.prevU[t] : a.u[(size_t)par * nu + t];
+            else run = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
             for (int k = top; k < a.N; k += PF) {
 #pragma unroll
                 for (int j = 0; j < PF; j++) {
@@ -831,7 +835,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     const int kk = k + j < a.N ? k + j : a.N - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
-                    ev[j] = eb[node * nx + j0];
+                    ev[j] = AF ? (T)0 : eb[node * nx + j0];
                     d0[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + j0];
                     d1[j] = UNSC ? (T)0 : dyAll[(size_t)kk * ny + nx + j0];
                 }
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                 T lv[CROWN_MAX_DEPTH], evc[CROWN_MAX_DEPTH];
 #pragma unroll
                 for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; evc[dd] = eb[(size_t)anc[dd] * nx + j0]; }
+                    if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; evc[dd] = AF ? (T)0 : eb[(size_t)anc[dd] * nx + j0]; }
 #pragma unroll
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd < top) {
@@ -893,11 +897,11 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
             const T spj = a.tr.sqrtp[j];
             for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
                 if (t < nu) {
-                    T run = a.prevU[t] - a.prevUhat[t];
+                    T run = AF ? a.prevU[t] : a.prevU[t] - a.prevUhat[t];
                     T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
 #pragma unroll
                     for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = uhat[(size_t)pth[dd] * nu + t]; }
+                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = AF ? (T)0 : uhat[(size_t)pth[dd] * nu + t]; }
                     T uv = 0;
 #pragma unroll
                     for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
@@ -910,7 +914,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_down_chain(SweepArgs<T> a, in
                     T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
 #pragma unroll
                     for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = eb[(size_t)pth[dd] * nx + j0]; }
+                        if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = AF ? (T)0 : eb[(size_t)pth[dd] * nx + j0]; }
 #pragma unroll
                     for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                         if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }
@@ -930,16 +934,18 @@ __device__ __forceinline__ void down_crown_node(const SweepArgs<T> &a, int stage
     const int par = a.tr.parent[node];
     const T sp = a.tr.sqrtp[node];
     const T *dy = a.tr.dy + (size_t)stage * ny;
+    const bool AF = (a.lin & 4) != 0;       // the affine terms ride in lvb (k_down_chain)
     for (int t = tid; t < w; t += nthreads) {
         if (t < nu) {
-            const T wanc = par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]);
-            const T uv = a.uhat[(size_t)node * nu + t] + wanc + a.lvb[(size_t)node * w + t];
+            const T wanc = AF ? (par < 0 ? a.prevU[t] : a.u[(size_t)par * nu + t])
+                              : (par < 0 ? (a.prevU[t] - a.prevUhat[t]) : (a.u[(size_t)par * nu + t] - a.uhat[(size_t)par * nu + t]));
+            const T uv = (AF ? (T)0 : a.uhat[(size_t)node * nu + t]) + wanc + a.lvb[(size_t)node * w + t];
             a.u[(size_t)node * nu + t] = uv;
             a.hx[(size_t)node * ny + 2 * nx + t] = sp * dy[2 * nx + t] * uv;
         } else {
             const int j0 = t - nu;
             const T bw = (par < 0 ? a.bw0[j0] : a.bw[(size_t)par * nx + j0]) + a.lvb[(size_t)node * w + nu + j0];
-            const T xv = (par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0]) + a.eb[(size_t)node * nx + j0] + bw;
+            const T xv = (par < 0 ? a.curX[j0] : a.x[(size_t)par * nx + j0]) + (AF ? (T)0 : a.eb[(size_t)node * nx + j0]) + bw;
             a.bw[(size_t)node * nx + j0] = bw;
             a.x[(size_t)node * nx + j0] = xv;
             a.hx[(size_t)node * ny + j0] = sp * dy[j0] * xv;
@@ -1000,6 +1006,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
     const int r0 = crownWriter ? 0 : (int)((long long)part * L / P), r1 = crownWriter ? 0 : (int)((long long)(part + 1) * L / P);
     const int kEnd = top + r1;                         // stages [top, kEnd) are walked
     const bool primalWg = part == P - 1, crownRowsWg = part == 0;
+    const bool AF = (a.lin & 4) != 0;       // the affine terms ride in lvb: neither uhat nor eb is requested (k_down_chain)
     const int ntop = a.chain0 + s;
     const size_t nodeTop = (size_t)ntop;
     const T sp = a.tr.sqrtp[ntop];
@@ -1036,15 +1043,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
                     const int kk = k + j < kEnd ? k + j : kEnd - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + t];
-                    uh2[j] = uhat[node * nu + t];
+                    uh2[j] = AF ? (T)0 : uhat[node * nu + t];
                 }
             };
             if (kEnd > top) request(top);          // needs nothing but the chain's number: requested first (k_down_chain)
-            T run = a.prevU[t] - a.prevUhat[t];
+            T run = AF ? a.prevU[t] : a.prevU[t] - a.prevUhat[t];
             T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
 #pragma unroll
             for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uh[dd] = uhat[(size_t)anc[dd] * nu + t]; }
+                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + t]; uh[dd] = AF ? (T)0 : uhat[(size_t)anc[dd] * nu + t]; }
 #pragma unroll
             for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                 if (dd < top) {
@@ -1078,7 +1085,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
                     const int kk = k + j < kEnd ? k + j : kEnd - 1;
                     const size_t node = nodeTop + (size_t)(kk - top) * a.K;
                     dv[j] = lvb[node * w + nu + j0];
-                    ev[j] = eb[node * nx + j0];
+                    ev[j] = AF ? (T)0 : eb[node * nx + j0];
                 }
             };
             if (kEnd > top) request(top);
@@ -1086,7 +1093,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
             T lv[CROWN_MAX_DEPTH], ev0[CROWN_MAX_DEPTH];
 #pragma unroll
             for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; ev0[dd] = eb[(size_t)anc[dd] * nx + j0]; }
+                if (dd < top) { lv[dd] = lvb[(size_t)anc[dd] * w + nu + j0]; ev0[dd] = AF ? (T)0 : eb[(size_t)anc[dd] * nx + j0]; }
 #pragma unroll
             for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                 if (dd < top) {
@@ -1130,11 +1137,11 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
         const T spj = a.tr.sqrtp[j];
         for (int t = threadIdx.x; t < w; t += CHAIN_THREADS) {
             if (t < nu) {
-                T run = a.prevU[t] - a.prevUhat[t];
+                T run = AF ? a.prevU[t] : a.prevU[t] - a.prevUhat[t];
                 T lv[CROWN_MAX_DEPTH], uh[CROWN_MAX_DEPTH];
 #pragma unroll
                 for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = uhat[(size_t)pth[dd] * nu + t]; }
+                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + t]; uh[dd] = AF ? (T)0 : uhat[(size_t)pth[dd] * nu + t]; }
                 T uv = 0;
 #pragma unroll
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
@@ -1147,7 +1154,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS, 2) k_down_chain_dual(SweepArgs<
                 T lv[CROWN_MAX_DEPTH], ev[CROWN_MAX_DEPTH];
 #pragma unroll
                 for (int dd = 0; dd < CROWN_MAX_DEPTH; dd++)
-                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = eb[(size_t)pth[dd] * nx + j0]; }
+                    if (dd <= kj) { lv[dd] = lvb[(size_t)pth[dd] * w + nu + j0]; ev[dd] = AF ? (T)0 : eb[(size_t)pth[dd] * nx + j0]; }
 #pragma unroll
                 for (int dd = CROWN_MAX_DEPTH - 1; dd >= 0; dd--)
                     if (dd <= kj) { bw = bw + lv[dd]; xr = xr + ev[dd] + bw; }

@@ -575,6 +575,9 @@ struct Ctx : CtxBase {
     // d_lvconst = [L ; B L] c_i.  RN_KNOB_STRUCT_LINEAR 4: the two products kept apart.
     T *d_MCp = nullptr, *d_MCf = nullptr, *d_lvconst = nullptr;
     bool lin_comp() const { return lin_const() && knob[RN_KNOB_STRUCT_LINEAR] != 4 && d_MCp != nullptr; }
+    // ... and the forward walk's affine terms (uhat_i - uhat_anc, eb_i - eb_anc) join that constant (k_fold_affine), so the walk requests neither
+    // uhat nor eb (SweepArgs::lin bit 2).  RN_KNOB_STRUCT_LINEAR 5: the composite operator without them.
+    bool lin_fold() const { return lin_comp() && knob[RN_KNOB_STRUCT_LINEAR] != 5; }
     // the form applies to unsharded structured sweeps whose v / Lv slab (16 nodes x (nv + nx + nu) and 16 x nv values) fits a workgroup's 64 KB;
     // otherwise (the wide fp32 network) the structured sweep keeps its first product k_gemm_prep_m2
     bool lin_fits() const { return (size_t)16 * (slab_stride(pad4(d.nv + d.nx + d.nu)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024; }
@@ -1217,6 +1220,11 @@ struct Ctx : CtxBase {
             hipLaunchKernelGGL(k_up_crown_lin<T>, dim3(h_stageCum[k + 1] - h_stageCum[k]), dim3(CROWN_THREADS), crown_lin_lds(1), stream, c, k, h_stageCum[k + 1] - h_stageCum[k], FinArgs{});
         launch_gemm<EPI_V>(d_RT2p, d.nv, d.nv, d_sk2, d.nv + d.nx + d.nu, d_vconst, d.nv, nullptr, 0);
         if (d_MCp) launch_gemm<EPI_LV>(d_LBLp, d.nu + d.nx, d.nv, d_vconst, d.nv, d_lvconst, d.nu + d.nx, nullptr, 0);      // [L ; B L] c_i
+        if (lin_fold()) {
+            const long long tot = (long long)d.nodes * (d.nu + d.nx);
+            hipLaunchKernelGGL(k_fold_affine<T>, dim3((unsigned)std::min<long long>((tot + 255) / 256, (long long)numCUs * 8)), dim3(256), 0, stream, d_lvconst, d_uhat, d_eb, d_prevUhat,
+                               d_parent, d.nodes, d.nu, d.nx);
+        }
         RN_HIP(hipGetLastError());
         linConstValid = true;
         return RN_OK;
@@ -1332,7 +1340,7 @@ struct Ctx : CtxBase {
         }
         if (a.lin && lin_const()) {
             if (!hessianInput && !linConstValid) { if (int rc = lin_const_refresh(a)) return rc; }
-            a.lin = 3;              // the walks leave the Bs columns alone
+            a.lin = lin_fold() ? 7 : 3;      // the walks leave the Bs columns alone (bit 1); the forward walk's affine terms ride in the product's constant (bit 2)
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (phase != 2 && !a.lin) {      // (the structured mode's linear form has no product in front of the chain walks: class 0 stays empty)

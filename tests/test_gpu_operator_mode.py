@@ -142,8 +142,9 @@ def test_linear_form_of_the_structured_sweep(name, precision, tol):
     o.initialise(dh, ah)
     runs = []
     # the linear form as it ships (the subtree sums of beta a constant of the control step, one product with the composite operator), the form with the
-    # first product, the linear form with beta walked every iteration, and the constant with v / [Lv; BLv] as two products
-    for lin in (1, 0, 3, 4):
+    # first product, the linear form with beta walked every iteration, the constant with v / [Lv; BLv] as two products, and the composite operator
+    # without the forward walk's affine terms in its constant
+    for lin in (1, 0, 3, 4, 5):
         s = capi.Solver(p["network"], p["tree"], p["config"], operator_mode="structured", precision=precision, knobs={"struct_linear": lin})
         s.initialiseSmpcController(dh, ah)
         s.apgReset()
@@ -164,6 +165,8 @@ def test_linear_form_of_the_structured_sweep(name, precision, tol):
     assert relmax(runs[0][1]["x"], runs[2][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
     assert relmax(runs[0][1]["x"], runs[3][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
     assert relmax(runs[0][1]["v"], runs[3][1]["v"]) < (1e-10 if precision == "f64" else 2e-4)      # v_i by its own launch in the iterations that store it
+    assert relmax(runs[0][1]["x"], runs[4][1]["x"]) < (1e-10 if precision == "f64" else 2e-4)
+    assert relmax(runs[0][1]["u"], runs[4][1]["u"]) < (1e-10 if precision == "f64" else 2e-4)
 
 
 def test_linear_form_launches_no_first_product():
