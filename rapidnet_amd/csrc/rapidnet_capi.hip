@@ -578,6 +578,18 @@ struct Ctx : CtxBase {
     // ... and the forward walk's affine terms (uhat_i - uhat_anc, eb_i - eb_anc) join that constant (k_fold_affine), so the walk requests neither
     // uhat nor eb (SweepArgs::lin bit 2).  RN_KNOB_STRUCT_LINEAR 5: the composite operator without them.
     bool lin_fold() const { return lin_comp() && knob[RN_KNOB_STRUCT_LINEAR] != 5; }
+    // v_i is an output only in this form (nothing of the sweep reads it): the sweeps that store the primal iterates leave it PENDING and the product
+    // runs when somebody asks for RN_BUF_V (rn_get / rn_set / rn_get_range / rn_set_range) -- from the product's input of that very sweep, which is
+    // still in place: a later sweep drops the pending product (its state is no longer observable) or, a Hessian sweep, runs it first.  A context
+    // whose raw v pointer has been handed out (rn_device_pointer) computes v with every such sweep, as the pointer's contract says.
+    bool vPending = false, vEager = false;
+    int v_flush() {
+        if (!vPending) return RN_OK;
+        vPending = false;
+        launch_gemm<EPI_V>(d_T12p, d.nv, d.nx + d.nu, d_sk2 + d.nv, d.nv + d.nx + d.nu, d_v, d.nv, d_vconst, d.nv);
+        RN_HIP(hipGetLastError());
+        return RN_OK;
+    }
     // the form applies to unsharded structured sweeps whose v / Lv slab (16 nodes x (nv + nx + nu) and 16 x nv values) fits a workgroup's 64 KB;
     // otherwise (the wide fp32 network) the structured sweep keeps its first product k_gemm_prep_m2
     bool lin_fits() const { return (size_t)16 * (slab_stride(pad4(d.nv + d.nx + d.nu)) + slab_stride(pad4(d.nv))) * sizeof(T) <= 64 * 1024; }
@@ -777,6 +789,7 @@ struct Ctx : CtxBase {
         RN_CHECK(s && s->matB && s->matGd && s->matL && s->matLhat && s->costW && s->matDiagPrecnd && s->vecXmin && s->vecXmax &&
                      s->vecXsafe && s->vecUmin && s->vecUmax && s->costAlpha1, RN_E_ARG, "rn_factor_step: null input");
         RN_HIP(hipSetDevice(device));
+        if (int rc = v_flush()) return rc;       // (a pending v is the previous operators')
         const int nx = d.nx, nu = d.nu, nv = d.nv, nd = d.nd, N = d.N;
         if (opsMode == RN_OPS_AUTO && s->matB != h_sys.B.data()) {   // (not when materialise_dense re-runs the step on the saved copy)
             h_sys.B.assign(s->matB, s->matB + (size_t)nx * nu); h_sys.Gd.assign(s->matGd, s->matGd + (size_t)nx * nd);
@@ -1251,7 +1264,10 @@ struct Ctx : CtxBase {
             const int nwc = slab_waves((nu + nx + 15) / 16, gC.kp / 4, 0, 0);
             if (few_slabs()) hipLaunchKernelGGL((k_gemm_comp<T, true>), dim3(nSlabs), dim3(64 * nwc), (size_t)16 * SBc * sizeof(T), stream, gC, SBc, a, foldRoot);
             else hipLaunchKernelGGL((k_gemm_comp<T, false>), dim3(nSlabs), dim3(64 * nwc), (size_t)16 * SBc * sizeof(T), stream, gC, SBc, a, foldRoot);
-            if (a.writePrimal) launch_gemm<EPI_V>(d_T12p, nv, nx + nu, a.sk2 + nv, nv + nx + nu, a.v, nv, hess ? nullptr : d_vconst, nv);
+            if (a.writePrimal) {
+                if (hess || vEager || a.v != d_v) launch_gemm<EPI_V>(d_T12p, nv, nx + nu, a.sk2 + nv, nv + nx + nu, a.v, nv, hess ? nullptr : d_vconst, nv);
+                else vPending = true;
+            }
             return;
         }
         const int SB = slab_stride(gV.kp), SV = slab_stride(gL.kp);
@@ -1308,6 +1324,7 @@ struct Ctx : CtxBase {
     int launch_sweep(int phase = 0, const T *hessianInput = nullptr, bool primalOut = true, const T *hessianInput2 = nullptr, bool allowPending = false) {
         SweepArgs<T> a = sweep_args();
         a.writePrimal = primalOut ? 1 : 0;
+        if (vPending) { if (hessianInput) { if (int rc = v_flush()) return rc; } else vPending = false; }      // (see v_flush)
         if (hessianInput) {
             a.w = hessianInput;
             a.beta = d_zero; a.uhat = d_zero; a.e = d_zero; a.eb = d_zero; a.bw0 = d_zero;
@@ -2337,6 +2354,7 @@ struct Ctx : CtxBase {
             return RN_OK;
         }
         size_t cnt = 0;
+        if (id == RN_BUF_V) { vEager = true; if (int rc = v_flush()) return rc; }      // from now on v is computed with every sweep that stores the primal iterates
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr && cnt > 0, RN_E_ARG, "rn_device_pointer: this buffer is not kept in the reference's layout on the device (or not allocated yet): use rn_get");
         *ptr = p; *n = cnt;
@@ -2359,6 +2377,7 @@ struct Ctx : CtxBase {
             RN_HIP(hipGetLastError());
             return download(host, d_tmp, n);
         }
+        if (id == RN_BUF_V) { if (int rc = v_flush()) return rc; }
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr, RN_E_ARG, "rn_get: unknown buffer id");
         RN_CHECK(n == cnt, RN_E_ARG, "rn_get: size mismatch");
@@ -2383,6 +2402,7 @@ struct Ctx : CtxBase {
             }
             return RN_OK;
         }
+        if (id == RN_BUF_V) vPending = false;      // the caller's values replace it
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr, RN_E_ARG, "rn_set: unknown buffer id");
         RN_CHECK(n == cnt, RN_E_ARG, "rn_set: size mismatch");
@@ -2400,6 +2420,7 @@ struct Ctx : CtxBase {
             RN_HIP(hipGetLastError());
             return download(host, d_tmp, n);
         }
+        if (id == RN_BUF_V) { if (int rc = v_flush()) return rc; }
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr, RN_E_ARG, "rn_get_range: unknown buffer id");
         RN_CHECK(first + n <= cnt, RN_E_ARG, "rn_get_range: range outside the buffer");
@@ -2420,6 +2441,7 @@ struct Ctx : CtxBase {
             else if (id == RN_BUF_XI || id == RN_BUF_PSI || id == RN_BUF_UPD_XI || id == RN_BUF_UPD_PSI) acc_ready = false;
             return RN_OK;
         }
+        if (id == RN_BUF_V) { if (int rc = v_flush()) return rc; }      // (the rest of the buffer must be the sweep's)
         T *p = plain(id, &cnt);
         RN_CHECK(p != nullptr, RN_E_ARG, "rn_set_range: unknown buffer id");
         RN_CHECK(first + n <= cnt, RN_E_ARG, "rn_set_range: range outside the buffer");
@@ -2652,6 +2674,7 @@ struct Ctx : CtxBase {
     // more on the saved inputs, this time expanding every block (Engine.cu:721-745) into d_A
     int materialise_dense() {
         RN_CHECK(factored && structured && opsMode == RN_OPS_AUTO && !h_sys.B.empty(), RN_E_STATE, "materialise_dense: not an RN_OPS_AUTO context after its factor step");
+        if (int rc = v_flush()) return rc;       // (a pending v belongs to the structured form's last sweep)
         RN_HIP(hipStreamSynchronize(stream));
         structured = 0; splitFirst = -1;      // (the streaming kernel's launch shape is decided by the factor step)
         rn_system sy{h_sys.B.data(), h_sys.Gd.data(), h_sys.L.data(), h_sys.Lhat.data(), h_sys.W.data(), h_sys.diag.data(), h_sys.xmin.data(), h_sys.xmax.data(),
