@@ -19,7 +19,7 @@ public:
     // (Engine.cu:126-132).  precision: RN_F64 (default) or RN_F32; device: HIP device ordinal.
     // operatorMode: how the per-node operator blocks of the factor step (Engine.cu:166-189, :721-745) are kept.  RN_OPS_AUTO: never
     // materialised while they are the factor step's own -- block = shared matrix x stage diagonal x power of p_i, applied as shared-operator
-    // products: identical iterates, 33 instead of 334 ms per 500-iteration control step on the 493-scenario tree -- and dense from the
+    // products: identical iterates, 32 instead of 335 ms per 500-iteration control step on the 493-scenario tree -- and dense from the
     // first setOperator() on; RN_OPS_DENSE: the reference's storage (one dense block per node, streamed every iteration); RN_OPS_STRUCTURED:
     // never any block.  -1 (default): the configuration file's optional "operatorMode" key ("auto" | "dense" | "structured"; absent: auto).
     explicit Engine(SmpcConfiguration *smpcConfig, int precision = RN_F64, int device = 0, int operatorMode = -1);
