@@ -244,7 +244,9 @@ int rn_set_operator(rn_ctx *ctx, int op_id, int node, const double *host, size_t
  * SmpcController.cuh:336-462 devVecX / devVecU / devVecV): RN_BUF_X, _U, _V, _UHAT, _E, _BETA, _ALPHA, _XDIR, _UDIR, node-major
  * [node][dim].  *precision = RN_F64 / RN_F32 (the element type is the context's), *n = element count.  The pointer stays valid until
  * rn_destroy; its contents are those of the last call that has COMPLETED on the context's stream (rn_synchronize, or order your own
- * work behind rn_stream).  x, u, v are stored by the last iteration of a batch and by every step-wise call.
+ * work behind rn_stream).  x, u, v are stored by the last iteration of a batch and by every step-wise call.  (In the structured operator
+ * mode v feeds nothing inside the solver and is normally computed when rn_get asks for it; asking for ITS raw pointer switches the context
+ * to computing it with every such iteration, so the sentence before holds for the pointer's whole life.)
  * The scaled bounds RN_BUF_XMIN, _XMAX, _XS, _UMIN, _UMAX (Engine.cuh:294-314 getSysXmin ... getSysUmax) are kept interleaved in the dual
  * layout; the first request for one of them (after rn_factor_step) makes node-major copies of all five in the reference's layout
  * ((3 nx + 2 nu) reals per node: this call allocates), which every later rn_factor_step refreshes.  The dual iterates (RN_BUF_XI ...
