@@ -135,53 +135,6 @@ class _FullSizeOracle:
 _fullsize_oracle = _FullSizeOracle()
 
 
-# ---- the wide fp32 network's numpy evaluation, behind the other tests --------------------------------------------------------------
-# tests/test_gpu_baseline_configs.py::test_wide4096_fp32_full_size checks the GPU's factor step and affine terms at FULL size (86 289
-# nodes) against tests/numpy_engine.py: ten seconds of host numpy in which the GPU has nothing to do.  Same idea as above: the numpy side
-# starts on a background thread when the tests are collected (the session's first minute is bench.py subprocesses) and the test collects it.
-class _Wide4096Numpy:
-    SAMPLE = (0, 1, 16, 17, 272, 273, 4368, 4369, 40000, 86288)
-
-    def __init__(self):
-        self.thread, self.out, self.error = None, None, None
-
-    def start(self):
-        import threading
-
-        def run():
-            try:
-                from numpy_engine import NumpyEngine
-                from rapidnet_amd import synth
-
-                p = synth.make_problem("wide4096")
-                dh, ah = synth.forecast_at(p["forecast"], 0)
-                ne = NumpyEngine(p["network"], p["tree"], p["config"])
-                sample = sorted(set(self.SAMPLE))
-                self.out = {"problem": p, "forecast": (dh, ah), "sample": sample, "ops": {n: ne.operators(n) for n in sample},
-                            "bounds": ne.bounds_of(sample), "affine": ne.affine(dh, ah)}
-            except BaseException as e:   # noqa: BLE001 -- handed to the test
-                self.error = e
-
-        self.thread = threading.Thread(target=run, daemon=True)
-        self.thread.start()
-
-    def result(self):
-        if self.thread is None:
-            self.start()
-        self.thread.join()
-        if self.error is not None:
-            raise self.error
-        return self.out
-
-
-_wide4096_numpy = _Wide4096Numpy()
-
-
-@pytest.fixture(scope="session")
-def wide4096_numpy():
-    return _wide4096_numpy.result()
-
-
 def pytest_collection_modifyitems(session, config, items):
     """the test that collects the full-size oracle's 100 s background run goes last: by then the run has finished behind the other tests
     (in file order it came up after ~90 s and waited for the rest)"""
@@ -191,8 +144,6 @@ def pytest_collection_modifyitems(session, config, items):
 
 
 def pytest_collection_finish(session):
-    if any("test_wide4096_fp32_full_size" in item.nodeid for item in session.items) and not session.config.option.collectonly:
-        _wide4096_numpy.start()
     if any("test_500_iterations_against_the_oracle_at_full_size" in item.nodeid for item in session.items) and not session.config.option.collectonly:
         _fullsize_oracle.start()
 

@@ -159,9 +159,9 @@ def test_wide_network_fp32_against_the_oracle(structured):
     s.close()
 
 
-def test_wide4096_fp32_full_size(wide4096_numpy):
-    w = wide4096_numpy          # the numpy side has been running behind the other tests since the session started (tests/conftest.py)
-    p, (dh, ah) = w["problem"], w["forecast"]
+def test_wide4096_fp32_full_size():
+    p = synth.make_problem("wide4096")
+    dh, ah = synth.forecast_at(p["forecast"], 0)
     d = capi.Solver(p["network"], p["tree"], p["config"], precision="f32")              # 160 GB of per-node blocks
     d.initialiseSmpcController(dh, ah)
     assert d.nodes == 86289 and d.nx == 200 and d.K == 4096
@@ -169,24 +169,27 @@ def test_wide4096_fp32_full_size(wide4096_numpy):
     # are node-local formulas -- tests/numpy_engine.py evaluates them node by node (pinned to the oracle on small trees,
     # tests/test_numpy_engine.py): operator blocks at 10 sampled nodes incl. the root, both ends of the crown and the last node,
     # the scaled bounds of those nodes, and uhat / e / alpha / beta of ALL nodes (Engine.cu:671-774, 1147-1298)
+    from numpy_engine import NumpyEngine
+
+    ne = NumpyEngine(p["network"], p["tree"], p["config"])
     nv, nx, nu = d.nv, d.nx, d.nu
-    sample = w["sample"]
-    assert sample[-1] == d.nodes - 1
+    sample = sorted({0, 1, 16, 17, 272, 273, 4368, 4369, 40000, d.nodes - 1})
     for node in sample:
-        ops = w["ops"][node]
+        ops = ne.operators(node)
         for op, key in ((capi.OP_PHI, "Phi"), (capi.OP_D, "D"), (capi.OP_PSI, "Psi"), (capi.OP_F, "Ftil")):
             assert relmax(d.getOperator(op, node), ops[key].ravel(order="F")) < 2e-6, (key, node)      # fp32 storage of fp64-evaluated blocks
-    b = w["bounds"]
+    b = ne.bounds_of(sample)
     for bid, key, dim in ((capi.BUF_XMIN, "xmin", nx), (capi.BUF_XMAX, "xmax", nx), (capi.BUF_XS, "xs", nx), (capi.BUF_UMIN, "umin", nu),
                           (capi.BUF_UMAX, "umax", nu)):
         got = d.get(bid).reshape(d.nodes, dim)[sample]
         assert relmax(got, b[key]) < 2e-6, key
-    a = w["affine"]
+    a = ne.affine(dh, ah)
     worst = {}
     for bid, key in ((capi.BUF_UHAT, "uhat"), (capi.BUF_E, "e"), (capi.BUF_ALPHA, "alpha"), (capi.BUF_BETA, "beta")):
         worst[key] = relmax(d.get(bid), a[key].ravel())
     print("wide4096 fp32, full size, affine terms vs the fp64 numpy evaluation:", {k: "%.1e" % v for k, v in worst.items()})
     assert max(worst[k] for k in ("uhat", "e", "alpha")) < 2e-5 and worst["beta"] < 1e-4, worst       # fp32 sums over nd = 280 / nu = 360 terms
+    del ne, a, b
     st = capi.Solver(p["network"], p["tree"], p["config"], precision="f32", structured=True)
     st.initialiseSmpcController(dh, ah)
     # (i) two implementations of the operator, 10 device-resident iterations
