@@ -1,6 +1,6 @@
 """One-off fuzz of the structured operator mode against the CPU oracle on random shapes (tests/test_gpu_random_shapes.py's generator): optimistic
 batches (the chain walk riding in the fused launch), a short exact batch, a second control step (the constants of the control step refreshed), fp64.
-    python tools/fuzz_structured.py [first_seed] [n]"""
+    python tests/fuzz_structured.py [first_seed] [n]"""
 import os
 import sys
 
